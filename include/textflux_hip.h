@@ -1,0 +1,147 @@
+/* libtextflux_hip.so -- C ABI of the MI355X (gfx950) TextFlux / FLUX.1-Fill denoising engine.
+ *
+ * The reference (yyyyyxie/textflux @ 2025-09-26) has no FFI: its hot path sits behind Python object protocols of the
+ * vendored diffusers 0.32.0.dev0.  Each entry point below names the reference call site(s) it
+ * replaces; `D/` = diffusers/src/diffusers in the reference tree.  INTEGRATION.md shows the ctypes binding and how
+ * the reference-side classes would call it.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; tfx_last_error() then describes it (thread local);
+ *   - all tensor arguments are DEVICE pointers to bf16 (uint16 bit pattern) unless typed otherwise; nothing is
+ *     allocated or freed by the library, no pointer is retained after a call returns;
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued asynchronously on it and is safe to
+ *     capture into a hipGraph (no allocation, no synchronisation, no host read-back inside any entry point);
+ *   - row-major matrices with explicit leading dimensions (`ld*`, in elements) and batch strides (`*_bstride`).
+ */
+#ifndef TEXTFLUX_HIP_H
+#define TEXTFLUX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tfx_stream;
+
+/* ---- library -------------------------------------------------------------------------------------------- */
+const char* tfx_version(void);
+const char* tfx_last_error(void);
+/* Writes the gcnArchName of the current device (e.g. "gfx950:sramecc+:xnack-") into buf.  Needs a GPU. */
+int tfx_query_arch(char* buf, int buflen);
+
+/* ---- GEMM:  C[b] = epi(A[b] @ W^T + bias)  (every nn.Linear on the path: D/models/attention_processor.py:1990-1992,
+ *      2009-2011, 2052, 2056; D/models/attention.py:1217-1232; transformer_flux.py:724, 732, 1086, 1099, 1203;
+ *      D/models/normalization.py:168, 200, 364; D/models/embeddings.py:1008-1021, 1926-1931).
+ *      A [batch][M,K] (lda, a_bstride), W [N,K] nn.Linear layout (ldw), bias [N] or NULL, C [batch][M,N].
+ *      epilogue: 0 bias | 1 bias, then tanh-GELU on columns >= gelu_from_col (activations.py:83; the split form is the
+ *      fused [k|v|q|mlp] projection of FluxSingleTransformerBlock) | 2 C = res + gate[b,:] * (A@W^T + bias)
+ *      (gated residual, transformer_flux.py:733-735, 817-818, 824-826, 830-831, 837; res may alias C).
+ *      variant: -1 auto, 0 generic FMA kernel (any shape), 1 MFMA kernel (K % 64 == 0, N % 8 == 0, 16-byte aligned). */
+typedef struct tfx_gemm_args {
+  const void* A; int64_t lda; int64_t a_bstride;
+  const void* W; int64_t ldw;
+  const void* bias;
+  void* C; int64_t ldc; int64_t c_bstride;
+  int32_t M, N, K, batch;
+  int32_t epilogue;
+  int32_t gelu_from_col;
+  const void* gate; int64_t gate_bstride;
+  const void* res; int64_t ldr; int64_t r_bstride;
+} tfx_gemm_args;
+int tfx_gemm_bf16(const tfx_gemm_args* args, int variant, tfx_stream stream);
+
+/* ---- LayerNorm(no affine, eps) * (1 + scale[b]) + shift[b]   (AdaLayerNormZero / ZeroSingle / Continuous,
+ *      D/models/normalization.py:170, 202, 365; norm2 + modulation, transformer_flux.py:820-821, 833-834).
+ *      x, out: [batch][rows_per_batch, D]; shift, scale: [batch][D] with stride mod_bstride.  D % 8 == 0, D <= 3072. */
+int tfx_ln_modulate(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride,
+                    const void* shift, const void* scale, int64_t mod_bstride, int32_t rows_per_batch, int32_t batch,
+                    int32_t D, float eps, tfx_stream stream);
+
+/* ---- per-head RMSNorm * weight, then RoPE, in place on the q and k column ranges of a fused projection buffer
+ *      [B][Ntok, ld] (heads of 128) (FluxAttnProcessor2_0, D/models/attention_processor.py:2001-2004, 2023-2037;
+ *      RMSNorm D/models/normalization.py:534-549; apply_rotary_emb D/models/embeddings.py:899-918).
+ *      Rows < T use w*_txt (norm_added_q/k), rows >= T use w*_img (norm_q/k).  cos/sin: fp32 [Ntok,128]. */
+int tfx_rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int32_t q_off, int32_t k_off, int32_t H, int32_t Ntok,
+                     int32_t T, int32_t B, const void* wq_img, const void* wk_img, const void* wq_txt,
+                     const void* wk_txt, const float* cos_tab, const float* sin_tab, float eps, tfx_stream stream);
+
+/* ---- joint attention softmax(q k^T * scale) v, head_dim 128, no mask (F.scaled_dot_product_attention,
+ *      D/models/attention_processor.py:2039-2041).  Element (b, n, h, d) of q is q[b*q_bstride + n*ldq + h*128 + d];
+ *      same for k, v, o.  o may alias q. */
+typedef struct tfx_attn_args {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t ldq, ldk, ldv, ldo;
+  int64_t q_bstride, k_bstride, v_bstride, o_bstride;
+  int32_t B, H, N;
+  float scale;
+} tfx_attn_args;
+int tfx_joint_attention(const tfx_attn_args* args, tfx_stream stream);
+
+/* ---- scheduler steps on packed latents x [rows, C] with model output v [rows, C]; the result is also written
+ *      into columns [0, C) of xin [rows, ldxin] when xin != NULL (next x_embedder input; replaces the torch.cat of
+ *      D/pipelines/flux/pipeline_flux_fill.py:2085).  The step index is *step_ptr (device int) when step_ptr != NULL,
+ *      else `step`.
+ *      Euler: coef[step] = sigma_{i+1} - sigma_i  (FlowMatchEulerDiscreteScheduler.step,
+ *             D/schedulers/scheduling_flow_match_euler_discrete.py:319-330)
+ *      AMO:   coef[3*step..] = {t_over - t, a, b}, noise fp32 [rows, C]  (StochasticRFOvershotDiscreteScheduler.step,
+ *             D/schedulers/scheduling_stochastic_rf_discrete_overshot.py:306-361 with attn_map None). */
+int tfx_euler_step(const void* v, void* x, void* xin, int64_t ldxin, int32_t C, int64_t rows, const float* coef,
+                   const int32_t* step_ptr, int32_t step, tfx_stream stream);
+int tfx_amo_step(const void* v, void* x, void* xin, int64_t ldxin, int32_t C, int64_t rows, const float* coef,
+                 const int32_t* step_ptr, int32_t step, const float* noise, tfx_stream stream);
+
+/* ---- small ops of the conditioning path (CombinedTimestepGuidanceTextProjEmbeddings, D/models/embeddings.py:1327-1339) */
+int tfx_timestep_embedding(const float* t, void* out /* [n,256] = cos|sin */, int32_t n, tfx_stream stream);
+int tfx_silu(const void* a, void* out, int64_t n, tfx_stream stream);
+int tfx_add(const void* a, const void* b, void* out, int64_t n, tfx_stream stream);
+/* dst[r, col0 : col0+C] = src[r, :]  (initial fill of the x_embedder input; C, col0, ld multiples of 8) */
+int tfx_scatter_cols(const void* src, void* dst, int64_t rows, int32_t C, int64_t ld, int32_t col0, tfx_stream stream);
+/* generic strided 2-D copy dst[b][r, 0:cols] = src[b][r, 0:cols]  (cols % 8 == 0) */
+int tfx_copy_rows(const void* src, int64_t src_ld, int64_t src_bstride, void* dst, int64_t dst_ld, int64_t dst_bstride,
+                  int32_t rows, int32_t cols, int32_t batch, tfx_stream stream);
+/* device-side step cursor for single-graph replay: cur[:] = table[*step_ptr][:]; *step_ptr += 1 */
+int tfx_select_step(const void* table, void* cur, int64_t per_step_elems, int32_t* step_ptr, tfx_stream stream);
+int tfx_advance_step(int32_t* step_ptr, tfx_stream stream);
+
+/* ---- one full FluxTransformer2DModel.forward (D/models/transformers/transformer_flux.py:1028-1212) ------------------
+ * Weight layout (all bf16, nn.Linear [out,in]); fusions are pure row concatenations done at load time:
+ *   double block: qkv_img = [to_k; to_v; to_q] (3D x D), qkv_txt = [add_k_proj; add_v_proj; add_q_proj],
+ *                 out_img = to_out.0, out_txt = to_add_out, ff1/ff2 = ff.net.0.proj / ff.net.2 (and ff_context)
+ *   single block: qkv_mlp = [to_k; to_v; to_q; proj_mlp] (7D x D), proj_out (D x 5D: attn | mlp columns)
+ * Modulation: mod [B][mod_len] for THIS step = Linear(SiLU(temb)) of every norm*.linear stacked in the order
+ *   double i: [img: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp | txt: same six]   (12D each)
+ *   single j: [shift scale gate] (3D each), then norm_out: [scale shift] (2D).
+ * Workspace (caller-owned, bf16): hid [B][N,D], xn [B][N,D], y [B][N,7D], with N = T + S (text rows first). */
+typedef struct tfx_linear { const void* w; const void* b; } tfx_linear;
+typedef struct tfx_double_block {
+  tfx_linear qkv_img, qkv_txt, out_img, out_txt, ff1_img, ff2_img, ff1_txt, ff2_txt;
+  const void *norm_q, *norm_k, *norm_added_q, *norm_added_k;
+} tfx_double_block;
+typedef struct tfx_single_block {
+  tfx_linear qkv_mlp, proj_out;
+  const void *norm_q, *norm_k;
+} tfx_single_block;
+typedef struct tfx_dit_desc {
+  int32_t D, H, in_channels, out_channels, n_double, n_single;
+  int32_t B, S, T;
+  tfx_linear x_embedder, proj_out;
+  const tfx_double_block* dbl;   /* host array [n_double] */
+  const tfx_single_block* sgl;   /* host array [n_single] */
+  const void* xin;               /* [B][S, in_channels] */
+  const void* ctx0;              /* [B][T, D] context_embedder output (step invariant) */
+  const void* mod; int64_t mod_bstride;
+  const float* cos_tab; const float* sin_tab;  /* fp32 [N,128] */
+  void* hid; void* xn; void* y;
+  void* out;                     /* [B][S, out_channels] */
+  /* Partial runs (block-level parity tests): blocks [first_block, last_block) of the n_double + n_single sequence
+   * (last_block < 0 = all); flags bit 0: skip x_embedder / ctx0 copy (hid is preloaded with [text | image] rows),
+   * bit 1: skip norm_out + proj_out.  A full forward is first_block = 0, last_block = -1, flags = 0. */
+  int32_t first_block, last_block, flags;
+} tfx_dit_desc;
+int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEXTFLUX_HIP_H */

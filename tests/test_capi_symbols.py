@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every symbol
+include/textflux_hip.h declares (no compute calls -- there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+from textflux_amd import _lib as L
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    L.build()
+    return L.lib()
+
+
+def header_symbols():
+    src = open(os.path.join(REPO, "include", "textflux_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tfx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_bound_and_exported(lib):
+    syms = header_symbols()
+    assert len(syms) >= 17
+    assert sorted(L.SIGNATURES) == syms
+    for s in syms:
+        assert hasattr(lib, s)
+
+
+def test_version_and_error_strings(lib):
+    assert b"gfx950" in lib.tfx_version()
+    assert isinstance(lib.tfx_last_error(), bytes)
+
+
+def test_null_arguments_are_rejected_without_a_gpu(lib):
+    assert lib.tfx_gemm_bf16(None, -1, None) != 0
+    assert b"null" in lib.tfx_last_error()
+    assert lib.tfx_dit_forward(None, None) != 0
+    assert lib.tfx_joint_attention(None, None) != 0
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof/offsetof as gcc sees include/textflux_hip.h == the ctypes mirror in textflux_amd/_lib.py."""
+    import ctypes as C
+    import subprocess
+    structs = {"tfx_gemm_args": L.GemmArgs, "tfx_attn_args": L.AttnArgs, "tfx_linear": L.Linear,
+               "tfx_double_block": L.DoubleBlock, "tfx_single_block": L.SingleBlock, "tfx_dit_desc": L.DitDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "textflux_hip.h"', 'int main(void){']
+    for cname, ct in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, ct in structs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "textflux_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f

@@ -1,0 +1,209 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against the CPU oracle / golden vectors.
+
+Tolerances: bf16 has 8 bits of mantissa, so one rounding is a relative error of 2^-9 = 0.2 %.  Kernels that
+reproduce the reference's rounding chain are compared bit-exactly or to 1 bf16 ulp; GEMM / attention outputs are
+compared with the fp32 oracle evaluated on the same bf16 inputs: |err| <= 1e-2 * max|ref| (max-norm) and a mean
+absolute error <= 2e-3 * mean|ref|.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import flux_oracle as fo
+from oracle import pipeline_oracle as po
+from oracle import sched_oracle as so
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from textflux_amd import ops as o
+    return o
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def close(got, ref, max_rel=1e-2, mae_rel=2e-3):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert err.max().item() <= max_rel * ref.abs().max().item() + 1e-6, (err.max().item(), ref.abs().max().item())
+    assert err.mean().item() <= mae_rel * ref.abs().mean().item() + 1e-7, (err.mean().item(), ref.abs().mean().item())
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,batch", [(256, 256, 64, 1), (300, 264, 128, 2), (37, 72, 192, 3), (1024, 768, 3072, 1),
+                                         (520, 3072, 384, 2), (8, 3072, 256, 1), (4, 64, 64, 1)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_bias(ops, M, N, K, batch, variant):
+    a, w, b = rnd((batch, M, K), 1).to(BF), rnd((N, K), 2, 0.05).to(BF), rnd((N,), 3).to(BF)
+    ref = a.float() @ w.float().T + b.float()
+    got = ops.gemm(a.cuda(), w.cuda(), b.cuda(), variant=variant)
+    close(got, ref.to(BF))
+
+
+def test_gemm_generic_odd_k(ops):
+    a, w, b = rnd((2, 19, 32), 1).to(BF), rnd((24, 32), 2).to(BF), rnd((24,), 3).to(BF)
+    close(ops.gemm(a.cuda(), w.cuda(), b.cuda()), (a.float() @ w.float().T + b.float()).to(BF))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_gelu_split_and_strided(ops, variant):
+    """The single-block fused projection: plain bias below column 256, tanh-GELU from column 256 on; A and C are
+    column slices of wider buffers (lda/ldc > row length)."""
+    B, M, K, N = 2, 130, 128, 512
+    abuf = rnd((B, M, K + 64), 4).to(BF).cuda()
+    a = abuf[:, :, 64:]
+    w, b = rnd((N, K), 5, 0.1).to(BF), rnd((N,), 6).to(BF)
+    cbuf = torch.zeros(B, M, N + 128, dtype=BF, device="cuda")
+    out = cbuf[:, :, 128:]
+    ops.gemm(a, w.cuda(), b.cuda(), out=out, epilogue=ops.EPI_BIAS_GELU, gelu_from_col=256, variant=variant)
+    lin = a.float().cpu() @ w.float().T + b.float()
+    ref = torch.cat([lin[..., :256], torch.nn.functional.gelu(lin[..., 256:], approximate="tanh")], -1)
+    close(out, ref.to(BF))
+    assert cbuf[:, :, :128].abs().max().item() == 0  # nothing written outside the slice
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_gemm_gate_residual_inplace(ops, variant):
+    B, M, K, N = 2, 200, 256, 256
+    a, w, b = rnd((B, M, K), 7).to(BF), rnd((N, K), 8, 0.05).to(BF), rnd((N,), 9).to(BF)
+    gate, res = rnd((B, N), 10).to(BF), rnd((B, M, N), 11).to(BF)
+    lin = (a.float() @ w.float().T + b.float()).to(BF)
+    ref = res.float() + (gate.float()[:, None] * lin.float()).to(BF).float()
+    h = res.clone().cuda()
+    ops.gemm(a.cuda(), w.cuda(), b.cuda(), out=h, epilogue=ops.EPI_BIAS_GATE_RES, gate=gate.cuda(), res=h, variant=variant)
+    close(h, ref.to(BF))
+
+
+def test_gemm_fast_matches_generic_on_device(ops):
+    """Asymmetric data, long K: the MFMA kernel against the fp32-FMA kernel on the same device inputs."""
+    a = (rnd((3, 777, 3072), 12) + 0.3).to(BF).cuda()
+    w = (rnd((1032, 3072), 13, 0.03) - 0.01).to(BF).cuda()
+    b = rnd((1032,), 14).to(BF).cuda()
+    close(ops.gemm(a, w, b, variant=1), ops.gemm(a, w, b, variant=0), max_rel=5e-3, mae_rel=1e-3)
+
+
+# ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,N", [(1, 1, 64), (2, 2, 96), (1, 3, 300), (2, 2, 1664), (1, 24, 520)])
+def test_attention(ops, B, H, N):
+    q, k, v = (rnd((B, N, H * 128), s).to(BF) for s in (20, 21, 22))
+    qh, kh, vh = (t.float().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, N, H * 128)
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda())
+    close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+
+
+def test_attention_online_softmax_rescale_branch(ops):
+    """A key far above the rest in a LATE tile forces the running-max rescale of the accumulated output."""
+    B, H, N = 1, 1, 256
+    q, k, v = (rnd((B, N, 128), s).to(BF) for s in (23, 24, 25))
+    k[0, 200] = q[0, 17] * 4.0  # q17 . k200 >> anything seen in tiles 0..2
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    close(ops.attention(q.cuda(), k.cuda(), v.cuda()), ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+
+
+def test_attention_strided_inplace_over_q(ops):
+    """Layout used by the blocks: [k | v | q | pad] rows, output written over q."""
+    B, N, H = 2, 200, 2
+    D = H * 128
+    y = rnd((B, N, 4 * D), 26).to(BF).cuda()
+    k, v, q = y[:, :, :D], y[:, :, D:2 * D], y[:, :, 2 * D:3 * D]
+    qc, kc, vc = (t.float().cpu().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qc, kc, vc).transpose(1, 2).reshape(B, N, D)
+    pad_before = y[:, :, 3 * D:].clone()
+    ops.attention(q, k, v, out=q)
+    close(y[:, :, 2 * D:3 * D], ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+    assert torch.equal(y[:, :, 3 * D:], pad_before)
+
+
+# ----------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("D", [256, 3072])
+def test_ln_modulate_matches_bf16_oracle(ops, D):
+    B, R = 2, 37
+    x, shift, scale = rnd((B, R, D), 30).to(BF), rnd((B, D), 31, 0.5).to(BF), rnd((B, D), 32, 0.5).to(BF)
+    ref = fo.layer_norm(x) * (1 + scale[:, None]) + shift[:, None]  # bf16 op chain of the reference
+    got = ops.ln_modulate(x.cuda(), shift.cuda(), scale.cuda()).cpu()
+    # identical rounding chain; the only freedom is the fp32 summation order of mean/var -> allow 1 bf16 ulp rarely
+    diff = (got.float() - ref.float()).abs()
+    ulp = ref.float().abs() * 2 ** -7 + 1e-3
+    assert (diff <= ulp).all()
+    assert (diff > 0).float().mean().item() < 0.02
+
+
+def test_rmsnorm_rope_matches_bf16_oracle(ops, golden):
+    g = golden("g1_ops")
+    B, H, N, T = 2, 3, 29, 5
+    x = g["rope.x"].to(BF)                       # [2,3,29,128] heads-major as the reference sees it
+    wq, wk, waq, wak = (1 + 0.1 * rnd((128,), 40)).to(BF), (1 + 0.1 * rnd((128,), 41)).to(BF), \
+        (1 + 0.1 * rnd((128,), 42)).to(BF), (1 + 0.1 * rnd((128,), 43)).to(BF)
+    cos, sin = g["rope.cos"], g["rope.sin"]
+
+    def ref(xh, w_txt, w_img):
+        y = torch.cat([fo.rms_norm(xh[:, :, :T], w_txt), fo.rms_norm(xh[:, :, T:], w_img)], 2)
+        return fo.apply_rope(y, cos, sin)
+
+    k = rnd((2, 3, 29, 128), 44).to(BF)
+    buf = torch.zeros(B, N, 3 * H * 128, dtype=BF)
+    buf[:, :, :H * 128] = k.transpose(1, 2).reshape(B, N, -1)
+    buf[:, :, 2 * H * 128:] = x.transpose(1, 2).reshape(B, N, -1)
+    got = ops.rmsnorm_rope_(buf.cuda(), 2 * H * 128, 0, H, T, wq.cuda(), wk.cuda(), waq.cuda(), wak.cuda(),
+                            cos.cuda(), sin.cuda()).cpu()
+    rq = ref(x, waq, wq).transpose(1, 2).reshape(B, N, -1)
+    rk = ref(k, wak, wk).transpose(1, 2).reshape(B, N, -1)
+    for gt, rf in ((got[:, :, 2 * H * 128:], rq), (got[:, :, :H * 128], rk)):
+        diff = (gt.float() - rf.float()).abs()
+        assert (diff <= rf.float().abs() * 2 ** -7 + 1e-3).all()
+        assert (diff > 0).float().mean().item() < 0.02
+    assert got[:, :, H * 128:2 * H * 128].abs().max().item() == 0  # v columns untouched
+
+
+def test_scheduler_steps_bitexact_vs_reference_trajectories(ops, golden):
+    g = golden("g4_sched")
+    n, S = 6, 4096
+    mu = so.calculate_shift(S, 256, 4096, 0.5, 1.15)
+    lin = so.pipeline_sigmas(n)
+    es, as_ = so.euler_sigmas(lin, mu), so.amo_sigmas(lin, mu)
+    ecoef = (es[1:] - es[:-1]).cuda()
+    acoef = torch.tensor([so.amo_coefficients(as_[i].item(), as_[i + 1].item(), 2.0) for i in range(n)],
+                         dtype=torch.float32).cuda()
+    x = g["traj.x0"].to(BF).cuda()
+    xin = torch.zeros(2, 16, 96, dtype=BF, device="cuda")
+    for i in range(n):
+        ops.euler_step_(g[f"traj.v{i}"].to(BF).cuda(), x, ecoef, step=i, xin=xin)
+        assert torch.equal(x.cpu(), g[f"traj.euler.bf16.x{i}"])
+        assert torch.equal(xin[:, :, :64], x) and xin[:, :, 64:].abs().max().item() == 0
+    x = g["traj.x0"].to(BF).cuda()
+    step_ptr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for i in range(n):
+        ops.amo_step_(g[f"traj.v{i}"].to(BF).cuda(), x, acoef, g[f"traj.amo.eps{i}"].cuda(), step_ptr=step_ptr)
+        ops.advance_step_(step_ptr)
+        assert torch.equal(x.cpu(), g[f"traj.amo.bf16.x{i}"])
+    assert step_ptr.item() == n
+
+
+def test_timestep_embedding(ops, golden):
+    g = golden("g1_ops")
+    got = ops.timestep_embedding(g["tsemb.t"].cuda()).cpu().float()
+    ref = g["tsemb.out"].to(BF).float()
+    assert (got - ref).abs().max().item() <= 2 ** -7  # values in [-1,1]: 1 bf16 ulp (device sinf/cosf vs torch CPU)
+
+
+def test_small_ops(ops):
+    a, b = rnd((3, 520), 50).to(BF), rnd((3, 520), 51).to(BF)
+    assert torch.equal(ops.add(a.cuda(), b.cuda()).cpu(), a + b)
+    s = ops.silu(a.cuda()).cpu()
+    assert (s.float() - torch.nn.functional.silu(a).float()).abs().max().item() <= 2 ** -6
+    src = rnd((2, 5, 64), 52).to(BF).cuda()
+    dst = torch.zeros(2, 5, 384, dtype=BF, device="cuda")
+    ops.scatter_cols_(src, dst, 64)
+    assert torch.equal(dst[:, :, 64:128], src) and dst[:, :, :64].abs().max().item() == 0
+    big = rnd((2, 9, 256), 53).to(BF).cuda()
+    out = torch.zeros(2, 20, 256, dtype=BF, device="cuda")
+    ops.copy_rows_(big, out[:, 4:13])
+    assert torch.equal(out[:, 4:13], big) and out[:, :4].abs().max().item() == 0

@@ -1,0 +1,130 @@
+"""ctypes binding of libtextflux_hip.so (include/textflux_hip.h).
+
+The shared library is the product: there is NO fallback.  If it is missing or fails to load, importing the
+ops raises -- a CPU or eager-PyTorch path would silently void every parity claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtextflux_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+c_void_p, c_int, c_int32, c_int64, c_float, c_char_p = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_char_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64), ("a_bstride", c_int64),
+        ("W", c_void_p), ("ldw", c_int64),
+        ("bias", c_void_p),
+        ("C", c_void_p), ("ldc", c_int64), ("c_bstride", c_int64),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("batch", c_int32),
+        ("epilogue", c_int32), ("gelu_from_col", c_int32),
+        ("gate", c_void_p), ("gate_bstride", c_int64),
+        ("res", c_void_p), ("ldr", c_int64), ("r_bstride", c_int64),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p),
+        ("ldq", c_int64), ("ldk", c_int64), ("ldv", c_int64), ("ldo", c_int64),
+        ("q_bstride", c_int64), ("k_bstride", c_int64), ("v_bstride", c_int64), ("o_bstride", c_int64),
+        ("B", c_int32), ("H", c_int32), ("N", c_int32), ("scale", c_float),
+    ]
+
+
+class Linear(C.Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p)]
+
+
+class DoubleBlock(C.Structure):
+    _fields_ = [(n, Linear) for n in ("qkv_img", "qkv_txt", "out_img", "out_txt", "ff1_img", "ff2_img", "ff1_txt",
+                                      "ff2_txt")] + [(n, c_void_p) for n in ("norm_q", "norm_k", "norm_added_q",
+                                                                             "norm_added_k")]
+
+
+class SingleBlock(C.Structure):
+    _fields_ = [("qkv_mlp", Linear), ("proj_out", Linear), ("norm_q", c_void_p), ("norm_k", c_void_p)]
+
+
+class DitDesc(C.Structure):
+    _fields_ = [
+        ("D", c_int32), ("H", c_int32), ("in_channels", c_int32), ("out_channels", c_int32),
+        ("n_double", c_int32), ("n_single", c_int32),
+        ("B", c_int32), ("S", c_int32), ("T", c_int32),
+        ("x_embedder", Linear), ("proj_out", Linear),
+        ("dbl", C.POINTER(DoubleBlock)), ("sgl", C.POINTER(SingleBlock)),
+        ("xin", c_void_p), ("ctx0", c_void_p),
+        ("mod", c_void_p), ("mod_bstride", c_int64),
+        ("cos_tab", c_void_p), ("sin_tab", c_void_p),
+        ("hid", c_void_p), ("xn", c_void_p), ("y", c_void_p),
+        ("out", c_void_p),
+        ("first_block", c_int32), ("last_block", c_int32), ("flags", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/textflux_hip.h declares must appear here (tests check it)
+SIGNATURES = {
+    "tfx_version": (c_char_p, []),
+    "tfx_last_error": (c_char_p, []),
+    "tfx_query_arch": (c_int, [c_char_p, c_int]),
+    "tfx_gemm_bf16": (c_int, [C.POINTER(GemmArgs), c_int, c_void_p]),
+    "tfx_ln_modulate": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                                c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "tfx_rmsnorm_rope": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "tfx_joint_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),
+    "tfx_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int32,
+                               c_void_p]),
+    "tfx_amo_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int32,
+                             c_void_p, c_void_p]),
+    "tfx_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "tfx_silu": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "tfx_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "tfx_scatter_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32, c_void_p]),
+    "tfx_copy_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
+                              c_void_p]),
+    "tfx_select_step": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "tfx_advance_step": (c_int, [c_void_p, c_void_p]),
+    "tfx_dit_forward": (c_int, [C.POINTER(DitDesc), c_void_p]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile textflux_amd/csrc for gfx950 into libtextflux_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", "Makefile"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "textflux_hip.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building libtextflux_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (once).  Raises if it is not there -- there is no non-HIP product path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  textflux_amd has no CPU / eager fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"textflux_hip {what} failed: {lib().tfx_last_error().decode()}")

@@ -1,0 +1,223 @@
+// Joint image+text attention of the FLUX blocks: softmax(Q K^T / sqrt(128)) V, no mask, non-causal, head_dim 128
+// (reference site: F.scaled_dot_product_attention, D/models/attention_processor.py:2039-2041).
+//
+// Flash-style, one workgroup = 256 query rows of one (batch, head): 8 waves x 32 rows.  Per 64-key tile:
+//   S^T[key][q] = K . Q^T      v_mfma_f32_32x32x16_bf16(A = K rows from LDS, B = Q rows held in registers)
+//   online softmax in fp32, lane-local: with the swapped product every lane owns ONE query row (col = lane&31)
+//                               and 32 of the tile's 64 keys; the partner lane (lane^32) owns the other 32.
+//   O^T[d][q] += V^T . P^T     A = V^T fragments via ds_read_b64_tr_b16 (hardware transpose read), B = P straight
+//                               from the S accumulator registers (bf16-packed) -- the MFMA k-slot order is chosen
+//                               to match the accumulator's row order, so P never moves between lanes.
+// K and V tiles are staged global -> registers -> LDS (issue early / write late), double buffered, one barrier
+// per tile.  K rows (256 B) have their 16-byte chunks XOR-swizzled with (key & 15); V rows have their 64-byte
+// segments XOR-swizzled with (key & 3); both make the respective LDS reads bank-conflict free.
+#include "common.h"
+#include "launch.h"
+
+namespace tfx {
+
+constexpr int QBLK = 256, KVBLK = 64, HD = 128;
+constexpr int K_BYTES = KVBLK * HD * 2;          // 16 KiB
+constexpr int ATT_LDS = 2 * 2 * K_BYTES;         // K,V x 2 buffers = 64 KiB
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// Q and O may alias (the single-stream blocks write O over Q; a block only touches its own 256 rows of one head).
+__global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
+                                                   const bf16_t* __restrict__ Vp, bf16_t* O,
+                                                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs,
+                                                   int64_t k_bs, int64_t v_bs, int64_t o_bs, int H, int N, int nqb,
+                                                   float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  // block -> (b, h, q-block).  Blocks are dealt round-robin to the 8 XCDs; remap so that each XCD gets a
+  // contiguous range of (b, h, q-block), i.e. all q-blocks of a head share one XCD's L2 for that head's K/V.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int qb = bid % nqb;
+  bid /= nqb;
+  const int h = bid % H;
+  const int b = bid / H;
+
+  const bf16_t* Qb = Q + b * q_bs + h * HD;
+  const bf16_t* Kb = Kp + b * k_bs + h * HD;
+  const bf16_t* Vb = Vp + b * v_bs + h * HD;
+  bf16_t* Ob = O + b * o_bs + h * HD;
+
+  // ---- Q fragments: lane (q = l31, hi) holds d = s*16 + hi*8 + [0,8) for s = 0..7
+  const int qrow = qb * QBLK + wave * 32 + l31;
+  const int qrow_c = qrow < N ? qrow : N - 1;
+  bf16x8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    qf[s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qrow_c * ldq + s * 16 + hi * 8);
+
+  // ---- staging: thread t copies chunks c = t and t + 512 of the 1024 16-byte chunks of a K (and V) tile
+  const int nkv = (N + KVBLK - 1) / KVBLK;
+  u32x4 kreg[2], vreg[2];
+  auto load_tile = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 512;
+      int key = j * KVBLK + (c >> 4);
+      if (key > N - 1) key = N - 1;
+      kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (int64_t)key * ldk + (c & 15) * 8);
+      vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (int64_t)key * ldv + (c & 15) * 8);
+    }
+  };
+  auto write_tile = [&](int buf) {
+    char* kd = smem + buf * 2 * K_BYTES;
+    char* vd = kd + K_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 512;
+      const int key = c >> 4, ch = c & 15;
+      *reinterpret_cast<u32x4*>(kd + key * 256 + ((ch ^ (key & 15)) << 4)) = kreg[i];
+      *reinterpret_cast<u32x4*>(vd + key * 256 + ((((ch >> 2) ^ (key & 3)) << 6) | ((ch & 3) << 4))) = vreg[i];
+    }
+  };
+
+  // ---- per-lane LDS read offsets
+  // K: row key = kb*32 + l31, chunk (2s+hi) ^ (key & 15); key & 15 == lane & 15.
+  uint32_t koff[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) koff[s] = l31 * 256 + (((2 * s + hi) ^ (lane & 15)) << 4);
+  // V (transpose read): lane i = lane & 15 of a 16-lane group supplies the address of row (i >> 2),
+  // 8-byte piece (i & 3) of the group's 4-key x 16-d block; the group's d offset is 16 * ((lane >> 4) & 1).
+  const int vi = lane & 15;
+  const uint32_t vrow = (4 * hi + (vi >> 2)) * 256 + 32 * ((lane >> 4) & 1) + (vi & 3) * 8;
+  uint32_t voff[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) voff[db] = vrow + ((db ^ ((vi >> 2) & 3)) << 6);
+
+  f32x16 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  load_tile(0);
+  write_tile(0);
+  __syncthreads();
+
+  for (int j = 0; j < nkv; ++j) {
+    const int buf = j & 1;
+    if (j + 1 < nkv) load_tile(j + 1);  // global loads in flight under this tile's math
+    const char* kt = smem + buf * 2 * K_BYTES;
+    const char* vt = kt + K_BYTES;
+
+    // ---- S^T = K Q^T : two 32-key blocks
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kt + koff[s]);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kt + koff[s] + 32 * 256);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+    }
+    if (j == nkv - 1 && (N & (KVBLK - 1))) {  // ragged last tile: keys >= N get -inf
+      const int kbase = j * KVBLK + 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        if (key >= N) s0[r] = -INFINITY;
+        if (key + 32 >= N) s1[r] = -INFINITY;
+      }
+    }
+    // ---- online softmax (this lane: one query row, 32 keys; partner lane^32: the other 32)
+    float mx = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float mc = m_new * scale_log2e;
+    const float alpha = __builtin_amdgcn_exp2f(m_run * scale_log2e - mc);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(s0[r] * scale_log2e - mc);
+      s1[r] = __builtin_amdgcn_exp2f(s1[r] * scale_log2e - mc);
+      psum += s0[r] + s1[r];
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    // P as MFMA B operands: step ks covers keys 16*ks + {0..3, 8..11} + 4*hi = accumulator regs 8*(ks&1)..+7
+    bf16x8 pf[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pf[0][e] = (__bf16)s0[e];
+      pf[1][e] = (__bf16)s0[8 + e];
+      pf[2][e] = (__bf16)s1[e];
+      pf[3][e] = (__bf16)s1[8 + e];
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const char* va = vt + voff[db] + ks * 16 * 256;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 8 * 256));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[db], 0, 0, 0);
+      }
+    }
+    if (j + 1 < nkv) write_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- finish: combine the two half-row sums, normalise, store 4 consecutive d per (db, quad)
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < N) {
+    bf16_t* orow = Ob + (int64_t)qrow * ldo + 4 * hi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        u32x2 w;
+        w[0] = pack_bf2(o[db][qd * 4 + 0] * inv, o[db][qd * 4 + 1] * inv);
+        w[1] = pack_bf2(o[db][qd * 4 + 2] * inv, o[db][qd * 4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(orow + db * 32 + qd * 8) = w;
+      }
+  }
+}
+
+int joint_attention(const AttnArgs& a, hipStream_t st) {
+  if (a.B <= 0 || a.H <= 0 || a.N <= 0) return 0;
+  if ((a.ldq | a.ldk | a.ldv | a.q_bstride | a.k_bstride | a.v_bstride) % 8 || (a.ldo | a.o_bstride) % 4)
+    return fail("attention: strides must be multiples of 8 elements (q,k,v) / 4 (o)");
+  if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 || (uintptr_t)a.o % 8)
+    return fail("attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
+      return fail("attention: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  const int nqb = (a.N + QBLK - 1) / QBLK;
+  const unsigned grid = (unsigned)(a.B * a.H * nqb);
+  attn_kernel<<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
+                                          a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
+                                          a.N, nqb, a.scale * 1.4426950408889634f);
+  return check_launch("joint_attention");
+}
+
+}  // namespace tfx

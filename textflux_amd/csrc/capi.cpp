@@ -1,0 +1,240 @@
+// extern "C" surface of libtextflux_hip.so (declared in include/textflux_hip.h) and the host-side DiT forward
+// that strings the kernels together (one FluxTransformer2DModel.forward, reference:
+// diffusers/src/diffusers/models/transformers/transformer_flux.py:1028-1212).
+#include "../../include/textflux_hip.h"
+
+#include <cstring>
+
+#include "launch.h"
+
+using namespace tfx;
+
+namespace {
+
+inline hipStream_t S(tfx_stream s) { return (hipStream_t)s; }
+inline const uint16_t* bf(const void* p) { return (const uint16_t*)p; }
+inline uint16_t* bf(void* p) { return (uint16_t*)p; }
+
+struct Gemm {
+  GemmArgs a;
+  Gemm(const void* A, int64_t lda, int64_t abs_, const tfx_linear& lin, int64_t ldw, void* C, int64_t ldc, int64_t cbs,
+       int M, int N, int K, int batch) {
+    std::memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.a_bstride = abs_;
+    a.W = lin.w; a.ldw = ldw; a.bias = lin.b;
+    a.C = C; a.ldc = ldc; a.c_bstride = cbs;
+    a.M = M; a.N = N; a.K = K; a.batch = batch;
+    a.epilogue = EPI_BIAS;
+  }
+  Gemm& gelu(int from_col) { a.epilogue = EPI_BIAS_GELU; a.gelu_from_col = from_col; return *this; }
+  Gemm& gate_res(const void* gate, int64_t gbs, const void* res, int64_t ldr, int64_t rbs) {
+    a.epilogue = EPI_BIAS_GATE_RES; a.gate = gate; a.gate_bstride = gbs; a.res = res; a.ldr = ldr; a.r_bstride = rbs;
+    return *this;
+  }
+  int run(hipStream_t st) const { return gemm_bf16(a, st); }
+};
+
+#define TRY(x)            \
+  do {                    \
+    if (int _e = (x)) return _e; \
+  } while (0)
+
+int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
+  const int D = d.D, H = d.H, B = d.B, Sn = d.S, T = d.T, N = Sn + T;
+  if (D != H * 128) return fail("dit_forward: inner dim %d != heads %d * 128", D, H);
+  if (B <= 0 || Sn <= 0 || T < 0) return fail("dit_forward: bad B/S/T");
+  const int64_t D7 = 7ll * D;
+  const int64_t hid_bs = (int64_t)N * D, y_bs = (int64_t)N * D7;
+  uint16_t* hid = bf(d.hid);
+  uint16_t* xn = bf(d.xn);
+  uint16_t* y = bf(d.y);
+  uint16_t* hid_img = hid + (int64_t)T * D;
+  uint16_t* xn_img = xn + (int64_t)T * D;
+  uint16_t* y_img = y + (int64_t)T * D7;
+  const uint16_t* mod = bf(d.mod);
+  const int64_t mbs = d.mod_bstride;
+  const float eps = 1e-6f;
+  const float att_scale = 0.08838834764831845f;  // 128^-0.5
+  const int nblk = d.n_double + d.n_single;
+  const int first = d.first_block < 0 ? 0 : d.first_block;
+  const int last = (d.last_block < 0 || d.last_block > nblk) ? nblk : d.last_block;
+
+  if (!(d.flags & 1)) {
+    // x_embedder (transformer_flux.py:1086) straight into the image rows of the joint stream; text rows <- ctx0
+    TRY(Gemm(d.xin, d.in_channels, (int64_t)Sn * d.in_channels, d.x_embedder, d.in_channels, hid_img, D, hid_bs, Sn, D,
+             d.in_channels, B).run(st));
+    if (T > 0) TRY(copy_rows(d.ctx0, D, (int64_t)T * D, hid, D, hid_bs, T, D, B, st));
+  }
+
+  auto attention = [&](int Ttxt, const void* nq, const void* nk, const void* naq, const void* nak) -> int {
+    // y = [k | v | q | ...]; RMSNorm+RoPE in place on q,k; attention output overwrites q
+    TRY(rmsnorm_rope(y, D7, y_bs, 2 * D, 0, H, N, Ttxt, B, nq, nk, naq, nak, d.cos_tab, d.sin_tab, eps, st));
+    AttnArgs a;
+    a.q = y + 2 * D; a.k = y; a.v = y + D; a.o = y + 2 * D;
+    a.ldq = a.ldk = a.ldv = a.ldo = D7;
+    a.q_bstride = a.k_bstride = a.v_bstride = a.o_bstride = y_bs;
+    a.B = B; a.H = H; a.N = N; a.scale = att_scale;
+    return joint_attention(a, st);
+  };
+
+  for (int blk = first; blk < last; ++blk) {
+    if (blk < d.n_double) {
+      // ---- FluxTransformerBlock.forward (transformer_flux.py:794-841)
+      const tfx_double_block& w = d.dbl[blk];
+      const uint16_t* mi = mod + (int64_t)blk * 12 * D;  // img: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp
+      const uint16_t* mt = mi + 6 * D;                   // txt: same six
+      TRY(ln_modulate(hid_img, xn_img, mi, mi + D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
+      if (T > 0) TRY(ln_modulate(hid, xn, mt, mt + D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
+      TRY(Gemm(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B).run(st));
+      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.qkv_txt, D, y, D7, y_bs, T, 3 * D, D, B).run(st));
+      TRY(attention(T, w.norm_q, w.norm_k, w.norm_added_q, w.norm_added_k));
+      // hidden += gate_msa * to_out(attn)   (:817-818, 830-831)
+      TRY(Gemm(y_img + 2 * D, D7, y_bs, w.out_img, D, hid_img, D, hid_bs, Sn, D, D, B)
+              .gate_res(mi + 2 * D, mbs, hid_img, D, hid_bs).run(st));
+      if (T > 0)
+        TRY(Gemm(y + 2 * D, D7, y_bs, w.out_txt, D, hid, D, hid_bs, T, D, D, B)
+                .gate_res(mt + 2 * D, mbs, hid, D, hid_bs).run(st));
+      // MLP: norm2 * (1 + scale_mlp) + shift_mlp -> ff -> gated residual (:820-826, 833-837)
+      TRY(ln_modulate(hid_img, xn_img, mi + 3 * D, mi + 4 * D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
+      if (T > 0) TRY(ln_modulate(hid, xn, mt + 3 * D, mt + 4 * D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
+      TRY(Gemm(xn_img, D, hid_bs, w.ff1_img, D, y_img + 3 * D, D7, y_bs, Sn, 4 * D, D, B).gelu(0).run(st));
+      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.ff1_txt, D, y + 3 * D, D7, y_bs, T, 4 * D, D, B).gelu(0).run(st));
+      TRY(Gemm(y_img + 3 * D, D7, y_bs, w.ff2_img, 4 * D, hid_img, D, hid_bs, Sn, D, 4 * D, B)
+              .gate_res(mi + 5 * D, mbs, hid_img, D, hid_bs).run(st));
+      if (T > 0)
+        TRY(Gemm(y + 3 * D, D7, y_bs, w.ff2_txt, 4 * D, hid, D, hid_bs, T, D, 4 * D, B)
+                .gate_res(mt + 5 * D, mbs, hid, D, hid_bs).run(st));
+    } else {
+      // ---- FluxSingleTransformerBlock.forward (transformer_flux.py:715-739) on the joint [text | image] sequence
+      const int j = blk - d.n_double;
+      const tfx_single_block& w = d.sgl[j];
+      const uint16_t* ms = mod + (int64_t)d.n_double * 12 * D + (int64_t)j * 3 * D;  // shift scale gate
+      TRY(ln_modulate(hid, xn, ms, ms + D, mbs, N, B, D, D, hid_bs, D, hid_bs, eps, st));
+      TRY(Gemm(xn, D, hid_bs, w.qkv_mlp, D, y, D7, y_bs, N, 7 * D, D, B).gelu(3 * D).run(st));
+      TRY(attention(0, w.norm_q, w.norm_k, w.norm_q, w.norm_k));
+      TRY(Gemm(y + 2 * D, D7, y_bs, w.proj_out, 5 * D, hid, D, hid_bs, N, D, 5 * D, B)
+              .gate_res(ms + 2 * D, mbs, hid, D, hid_bs).run(st));
+    }
+  }
+
+  if (!(d.flags & 2)) {
+    // norm_out (AdaLayerNormContinuous: chunk order scale, shift) + proj_out on the image rows (:1200-1203)
+    const uint16_t* mo = mod + (int64_t)d.n_double * 12 * D + (int64_t)d.n_single * 3 * D;
+    TRY(ln_modulate(hid_img, xn_img, mo + D, mo, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
+    TRY(Gemm(xn_img, D, hid_bs, d.proj_out, D, d.out, d.out_channels, (int64_t)Sn * d.out_channels, Sn, d.out_channels,
+             D, B).run(st));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tfx_version(void) { return "textflux_hip 0.1 (gfx950)"; }
+const char* tfx_last_error(void) { return last_error(); }
+
+int tfx_query_arch(char* buf, int buflen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail("tfx_query_arch: no HIP device");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("tfx_query_arch: hipGetDeviceProperties failed");
+  if (buf && buflen > 0) {
+    std::strncpy(buf, prop.gcnArchName, buflen - 1);
+    buf[buflen - 1] = 0;
+  }
+  return 0;
+}
+
+int tfx_gemm_bf16(const tfx_gemm_args* g, int variant, tfx_stream stream) {
+  if (!g) return fail("tfx_gemm_bf16: null args");
+  GemmArgs a;
+  a.A = g->A; a.lda = g->lda; a.a_bstride = g->a_bstride;
+  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias;
+  a.C = g->C; a.ldc = g->ldc; a.c_bstride = g->c_bstride;
+  a.M = g->M; a.N = g->N; a.K = g->K; a.batch = g->batch;
+  a.epilogue = g->epilogue; a.gelu_from_col = g->gelu_from_col;
+  a.gate = g->gate; a.gate_bstride = g->gate_bstride;
+  a.res = g->res; a.ldr = g->ldr; a.r_bstride = g->r_bstride;
+  if (!a.A || !a.W || !a.C) return fail("tfx_gemm_bf16: null matrix pointer");
+  return variant < 0 ? gemm_bf16(a, S(stream)) : gemm_bf16_variant(a, variant, S(stream));
+}
+
+int tfx_ln_modulate(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride,
+                    const void* shift, const void* scale, int64_t mod_bstride, int32_t rows_per_batch, int32_t batch,
+                    int32_t D, float eps, tfx_stream stream) {
+  if (!x || !out || !shift || !scale) return fail("tfx_ln_modulate: null pointer");
+  return ln_modulate(x, out, shift, scale, mod_bstride, rows_per_batch, batch, D, ldx, x_bstride, ldo, o_bstride, eps,
+                     S(stream));
+}
+
+int tfx_rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int32_t q_off, int32_t k_off, int32_t H, int32_t Ntok,
+                     int32_t T, int32_t B, const void* wq_img, const void* wk_img, const void* wq_txt,
+                     const void* wk_txt, const float* cos_tab, const float* sin_tab, float eps, tfx_stream stream) {
+  if (!buf || !wq_img || !wk_img || !wq_txt || !wk_txt || !cos_tab || !sin_tab) return fail("tfx_rmsnorm_rope: null pointer");
+  if (ld % 8 || bstride % 8 || q_off % 8 || k_off % 8) return fail("tfx_rmsnorm_rope: offsets/strides must be multiples of 8");
+  return rmsnorm_rope(buf, ld, bstride, q_off, k_off, H, Ntok, T, B, wq_img, wk_img, wq_txt, wk_txt, cos_tab, sin_tab,
+                      eps, S(stream));
+}
+
+int tfx_joint_attention(const tfx_attn_args* g, tfx_stream stream) {
+  if (!g || !g->q || !g->k || !g->v || !g->o) return fail("tfx_joint_attention: null pointer");
+  AttnArgs a;
+  a.q = g->q; a.k = g->k; a.v = g->v; a.o = g->o;
+  a.ldq = g->ldq; a.ldk = g->ldk; a.ldv = g->ldv; a.ldo = g->ldo;
+  a.q_bstride = g->q_bstride; a.k_bstride = g->k_bstride; a.v_bstride = g->v_bstride; a.o_bstride = g->o_bstride;
+  a.B = g->B; a.H = g->H; a.N = g->N; a.scale = g->scale;
+  return joint_attention(a, S(stream));
+}
+
+int tfx_euler_step(const void* v, void* x, void* xin, int64_t ldxin, int32_t C, int64_t rows, const float* coef,
+                   const int32_t* step_ptr, int32_t step, tfx_stream stream) {
+  if (!v || !x || !coef) return fail("tfx_euler_step: null pointer");
+  return sched_step(false, v, x, xin, ldxin, C, rows, coef, step_ptr, step, nullptr, S(stream));
+}
+int tfx_amo_step(const void* v, void* x, void* xin, int64_t ldxin, int32_t C, int64_t rows, const float* coef,
+                 const int32_t* step_ptr, int32_t step, const float* noise, tfx_stream stream) {
+  if (!v || !x || !coef) return fail("tfx_amo_step: null pointer");
+  return sched_step(true, v, x, xin, ldxin, C, rows, coef, step_ptr, step, noise, S(stream));
+}
+
+int tfx_timestep_embedding(const float* t, void* out, int32_t n, tfx_stream stream) {
+  if (!t || !out) return fail("tfx_timestep_embedding: null pointer");
+  return timestep_embedding(t, out, n, S(stream));
+}
+int tfx_silu(const void* a, void* out, int64_t n, tfx_stream stream) {
+  if (!a || !out) return fail("tfx_silu: null pointer");
+  return silu_bf16(a, out, n, S(stream));
+}
+int tfx_add(const void* a, const void* b, void* out, int64_t n, tfx_stream stream) {
+  if (!a || !b || !out) return fail("tfx_add: null pointer");
+  return add_bf16(a, b, out, n, S(stream));
+}
+int tfx_scatter_cols(const void* src, void* dst, int64_t rows, int32_t C, int64_t ld, int32_t col0, tfx_stream stream) {
+  if (!src || !dst) return fail("tfx_scatter_cols: null pointer");
+  return scatter_cols(src, dst, rows, C, ld, col0, S(stream));
+}
+int tfx_copy_rows(const void* src, int64_t src_ld, int64_t src_bstride, void* dst, int64_t dst_ld, int64_t dst_bstride,
+                  int32_t rows, int32_t cols, int32_t batch, tfx_stream stream) {
+  if (!src || !dst) return fail("tfx_copy_rows: null pointer");
+  return copy_rows(src, src_ld, src_bstride, dst, dst_ld, dst_bstride, rows, cols, batch, S(stream));
+}
+int tfx_select_step(const void* table, void* cur, int64_t per_step_elems, int32_t* step_ptr, tfx_stream stream) {
+  if (!table || !cur || !step_ptr) return fail("tfx_select_step: null pointer");
+  return select_step(table, cur, per_step_elems, step_ptr, S(stream));
+}
+int tfx_advance_step(int32_t* step_ptr, tfx_stream stream) {
+  if (!step_ptr) return fail("tfx_advance_step: null pointer");
+  return advance_step(step_ptr, S(stream));
+}
+
+int tfx_dit_forward(const tfx_dit_desc* d, tfx_stream stream) {
+  if (!d) return fail("tfx_dit_forward: null descriptor");
+  if (!d->xin || !d->mod || !d->hid || !d->xn || !d->y || !d->out || !d->cos_tab || !d->sin_tab)
+    return fail("tfx_dit_forward: null buffer in descriptor");
+  if ((d->n_double > 0 && !d->dbl) || (d->n_single > 0 && !d->sgl)) return fail("tfx_dit_forward: null block table");
+  if (d->T > 0 && !d->ctx0) return fail("tfx_dit_forward: ctx0 is null");
+  return dit_forward(*d, S(stream));
+}
+
+}  // extern "C"

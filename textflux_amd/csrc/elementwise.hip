@@ -1,0 +1,318 @@
+// HBM-bound kernels of the DiT step: fused LayerNorm+AdaLN modulation, fused per-head RMSNorm+RoPE,
+// flow-matching Euler / AMO scheduler steps, sinusoidal timestep embedding, SiLU, bf16 add.
+// All loads/stores are 16 B per lane (bf16x8); math is fp32; every bf16 rounding point of the
+// reference's unfused op chain is reproduced so results track the bf16 reference.
+#include "common.h"
+#include "launch.h"
+
+namespace tfx {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm(no affine, eps) * (1 + scale[b]) + shift[b]     (reference: AdaLayerNormZero /
+// AdaLayerNormZeroSingle / AdaLayerNormContinuous, D/models/normalization.py:170, :202, :365 and the
+// norm2 path of FluxTransformerBlock, transformer_flux.py:820-821).
+// One wave per token row, row held in registers (<= NCH*8*64 elements), two-pass statistics.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ shift,
+                                                          const bf16_t* __restrict__ scale, int64_t mod_bstride,
+                                                          int rows_per_batch, int64_t rows, int D, int64_t ldx,
+                                                          int64_t x_bstride, int64_t ldo, int64_t o_bstride, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = (int)(row / rows_per_batch);
+  const int r = (int)(row - (int64_t)b * rows_per_batch);
+  const bf16_t* xr = x + b * x_bstride + r * ldx;
+  bf16_t* orow = out + b * o_bstride + r * ldo;
+  const int nchunk = D >> 3;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nchunk) {
+      u32x4 raw = *reinterpret_cast<const u32x4*>(xr + ch * 8);
+      unpack8(raw, v[c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += v[c][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (lane + c * 64 < nchunk) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = v[c][i] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  const bf16_t* sh = shift + b * mod_bstride;
+  const bf16_t* sc = scale + b * mod_bstride;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + c * 64;
+    if (ch < nchunk) {
+      float s8[8], h8[8], o8[8];
+      unpack8(*reinterpret_cast<const u32x4*>(sc + ch * 8), s8);
+      unpack8(*reinterpret_cast<const u32x4*>(sh + ch * 8), h8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xn = round_bf((v[c][i] - mean) * rstd);   // F.layer_norm output, bf16
+        const float t = round_bf(1.0f + s8[i]);               // (1 + scale), bf16
+        o8[i] = round_bf(xn * t) + h8[i];                     // product rounded, sum rounded by pack8
+      }
+      *reinterpret_cast<u32x4*>(orow + ch * 8) = pack8(o8);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-head RMSNorm (fp32 variance, eps) * weight, then interleaved-pair RoPE, in place on the q and k
+// column ranges of a fused projection buffer [B, Ntok, ld].  Rows < T (text tokens) use the
+// norm_added_{q,k} weights, rows >= T the norm_{q,k} weights (FluxAttnProcessor2_0,
+// D/models/attention_processor.py:2001-2037; RMSNorm normalization.py:534-549; apply_rotary_emb
+// embeddings.py:899-918).  16 lanes per 128-wide head row, 8 elements (one 16-B chunk) per lane.
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ buf, int64_t ld, int64_t bstride,
+                                                           int q_off, int k_off, int H, int Ntok, int T, int B,
+                                                           const bf16_t* __restrict__ wq_img,
+                                                           const bf16_t* __restrict__ wk_img,
+                                                           const bf16_t* __restrict__ wq_txt,
+                                                           const bf16_t* __restrict__ wk_txt,
+                                                           const float* __restrict__ cosT,
+                                                           const float* __restrict__ sinT, float eps) {
+  const int sub = threadIdx.x & 15;
+  const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;  // head-row id
+  const int64_t total = (int64_t)B * Ntok * 2 * H;
+  if (g >= total) return;
+  const int h = (int)(g % H);
+  const int which = (int)((g / H) & 1);
+  const int64_t tokrow = g / (2 * H);
+  const int b = (int)(tokrow / Ntok);
+  const int n = (int)(tokrow - (int64_t)b * Ntok);
+  bf16_t* p = buf + b * bstride + (int64_t)n * ld + (which ? k_off : q_off) + h * 128 + sub * 8;
+  const bf16_t* w = (n < T) ? (which ? wk_txt : wq_txt) : (which ? wk_img : wq_img);
+  float x[8], wv[8];
+  unpack8(*reinterpret_cast<const u32x4*>(p), x);
+  unpack8(*reinterpret_cast<const u32x4*>(w + sub * 8), wv);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+  const float4* c4 = reinterpret_cast<const float4*>(cosT + (int64_t)n * 128 + sub * 8);
+  const float4* s4 = reinterpret_cast<const float4*>(sinT + (int64_t)n * 128 + sub * 8);
+  const float4 ca = c4[0], cb = c4[1], sa = s4[0], sb = s4[1];
+  const float cs[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+  const float sn[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+  float y[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = round_bf(round_bf(x[i] * r) * wv[i]);  // .to(bf16) then * weight (bf16)
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    o[i] = y[i] * cs[i] + (-y[i + 1]) * sn[i];
+    o[i + 1] = y[i + 1] * cs[i + 1] + y[i] * sn[i + 1];
+  }
+  *reinterpret_cast<u32x4*>(p) = pack8(o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scheduler steps on packed latents [rows, C] (C = 64): results are written both to the bf16 latent
+// state and, when xin != nullptr, into columns [0, C) of the next step's x_embedder input [rows, ldxin]
+// (this replaces the per-step torch.cat of pipeline_flux_fill.py:2085).
+//   Euler  (scheduling_flow_match_euler_discrete.py:322-330):  x' = bf16( f32(x) + bf16(dsigma * v) )
+//   AMO    (scheduling_stochastic_rf_discrete_overshot.py:340-361, attn_map None):
+//            x' = bf16( (f32(x) + bf16(dt * (-v))) * a + eps * b )
+// coef points at {dsigma} (Euler) or {dt_over, a, b} (AMO) per step; step index read from *step_ptr when
+// given (device-side, so that one captured graph serves every step), else `step`.
+template <bool AMO>
+__global__ __launch_bounds__(256) void sched_step_kernel(const bf16_t* __restrict__ v, bf16_t* __restrict__ x,
+                                                         bf16_t* __restrict__ xin, int64_t ldxin, int C,
+                                                         int64_t nchunks, const float* __restrict__ coef,
+                                                         const int* __restrict__ step_ptr, int step,
+                                                         const float* __restrict__ noise) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const int s = step_ptr ? *step_ptr : step;
+  float vv[8], xx[8], o[8];
+  unpack8(*reinterpret_cast<const u32x4*>(v + i * 8), vv);
+  unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), xx);
+  if (AMO) {
+    const float dt = coef[3 * s], a = coef[3 * s + 1], bcoef = coef[3 * s + 2];
+    const float4 n0 = reinterpret_cast<const float4*>(noise + i * 8)[0];
+    const float4 n1 = reinterpret_cast<const float4*>(noise + i * 8)[1];
+    const float e[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)  // explicit _rn ops: no FMA contraction, bit-identical to the unfused torch chain
+      o[j] = __fadd_rn(__fmul_rn(__fadd_rn(xx[j], round_bf(__fmul_rn(dt, -vv[j]))), a), __fmul_rn(e[j], bcoef));
+  } else {
+    const float ds = coef[s];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = __fadd_rn(xx[j], round_bf(__fmul_rn(ds, vv[j])));
+  }
+  const u32x4 packed = pack8(o);
+  *reinterpret_cast<u32x4*>(x + i * 8) = packed;
+  if (xin) {
+    const int64_t e0 = i * 8;
+    const int64_t row = e0 / C;
+    const int col = (int)(e0 - row * C);
+    *reinterpret_cast<u32x4*>(xin + row * ldxin + col) = packed;
+  }
+}
+
+// Sinusoidal timestep embedding, flip_sin_to_cos=True, downscale_freq_shift=0, dim 256, fp32 -> bf16
+// (get_timestep_embedding, D/models/embeddings.py:27-78 as configured at :1322).  out[n, 256] = cos | sin.
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int n) {
+  const int i = blockIdx.x;
+  const int j = threadIdx.x;  // 0..127
+  if (i >= n) return;
+  const float freq = expf(-9.210340371976184f * (float)j / 128.0f);  // -ln(10000) * j / half_dim
+  const float ang = t[i] * freq;
+  out[i * 256 + j] = f2bf(cosf(ang));
+  out[i * 256 + 128 + j] = f2bf(sinf(ang));
+}
+
+// mode 0: out = silu(a);  mode 1: out = a + b.   bf16 in/out, fp32 math.
+__global__ __launch_bounds__(256) void unary_binary_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                           bf16_t* __restrict__ out, int64_t n, int mode) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = bf2f(a[i]);
+  out[i] = f2bf(mode == 0 ? x / (1.0f + expf(-x)) : x + bf2f(b[i]));
+}
+
+// Copies rows of a [rows, C] bf16 matrix into columns [col0, col0+C) of a wider [rows, ld] matrix
+// (initial fill of the x_embedder input: latents -> cols 0..63, masked_image_latents -> cols 64..383).
+__global__ __launch_bounds__(256) void scatter_cols_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                           int64_t rows, int C, int64_t ld, int col0) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cpr = C >> 3;
+  if (i >= rows * cpr) return;
+  const int64_t row = i / cpr;
+  const int c = (int)(i - row * cpr);
+  *reinterpret_cast<u32x4*>(dst + row * ld + col0 + c * 8) = *reinterpret_cast<const u32x4*>(src + row * C + c * 8);
+}
+
+// dst[b][r, 0:cols] = src[b][r, 0:cols], 16 bytes per thread.
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict__ src, int64_t sld, int64_t sbs,
+                                                        bf16_t* __restrict__ dst, int64_t dld, int64_t dbs, int rows,
+                                                        int cpr, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cpr);
+  const int64_t rr = i / cpr;
+  const int r = (int)(rr % rows);
+  const int b = (int)(rr / rows);
+  *reinterpret_cast<u32x4*>(dst + b * dbs + (int64_t)r * dld + c * 8) =
+      *reinterpret_cast<const u32x4*>(src + b * sbs + (int64_t)r * sld + c * 8);
+}
+
+// Device-side step cursor for graph replay: cur_mod[b, :] = mod_table[*step, b, :]; optionally ++*step.
+__global__ __launch_bounds__(256) void select_step_kernel(const bf16_t* __restrict__ table, bf16_t* __restrict__ cur,
+                                                          int64_t per_step_chunks, int* step_ptr, int advance) {
+  const int s = *step_ptr;
+  const u32x4* src = reinterpret_cast<const u32x4*>(table) + (int64_t)s * per_step_chunks;
+  u32x4* dst = reinterpret_cast<u32x4*>(cur);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_step_chunks; i += (int64_t)gridDim.x * 256)
+    dst[i] = src[i];
+  (void)advance;
+}
+__global__ void advance_step_kernel(int* step_ptr) { *step_ptr += 1; }
+
+// ---------------------------------------------------------------------------------------------
+int ln_modulate(const void* x, void* out, const void* shift, const void* scale, int64_t mod_bstride,
+                int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldo,
+                int64_t o_bstride, float eps, hipStream_t st) {
+  if (D % 8 || D > 6 * 512) return fail("ln_modulate: D must be a multiple of 8 and <= 3072");
+  const int64_t rows = (int64_t)rows_per_batch * batch;
+  if (rows == 0) return 0;
+  ln_modulate_kernel<6><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(
+      (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)shift, (const bf16_t*)scale, mod_bstride, rows_per_batch, rows, D,
+      ldx, x_bstride, ldo, o_bstride, eps);
+  return check_launch("ln_modulate");
+}
+
+int rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int q_off, int k_off, int H, int Ntok, int T, int B,
+                 const void* wq_img, const void* wk_img, const void* wq_txt, const void* wk_txt, const float* cosT,
+                 const float* sinT, float eps, hipStream_t st) {
+  const int64_t groups = (int64_t)B * Ntok * 2 * H;
+  if (groups == 0) return 0;
+  rmsnorm_rope_kernel<<<dim3((unsigned)((groups + 15) / 16)), 256, 0, st>>>(
+      (bf16_t*)buf, ld, bstride, q_off, k_off, H, Ntok, T, B, (const bf16_t*)wq_img, (const bf16_t*)wk_img,
+      (const bf16_t*)wq_txt, (const bf16_t*)wk_txt, cosT, sinT, eps);
+  return check_launch("rmsnorm_rope");
+}
+
+int sched_step(bool amo, const void* v, void* x, void* xin, int64_t ldxin, int C, int64_t rows, const float* coef,
+               const int* step_ptr, int step, const float* noise, hipStream_t st) {
+  if (C % 8) return fail("sched_step: C must be a multiple of 8");
+  const int64_t nch = rows * C / 8;
+  if (nch == 0) return 0;
+  dim3 grid((unsigned)((nch + 255) / 256));
+  if (amo) {
+    if (!noise) return fail("amo_step: noise pointer is null");
+    sched_step_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)v, (bf16_t*)x, (bf16_t*)xin, ldxin, C, nch, coef,
+                                                  step_ptr, step, noise);
+  } else {
+    sched_step_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)v, (bf16_t*)x, (bf16_t*)xin, ldxin, C, nch, coef,
+                                                   step_ptr, step, nullptr);
+  }
+  return check_launch("sched_step");
+}
+
+int timestep_embedding(const float* t, void* out, int n, hipStream_t st) {
+  if (n == 0) return 0;
+  timestep_embedding_kernel<<<n, 128, 0, st>>>(t, (bf16_t*)out, n);
+  return check_launch("timestep_embedding");
+}
+
+int silu_bf16(const void* a, void* out, int64_t n, hipStream_t st) {
+  if (n == 0) return 0;
+  unary_binary_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const bf16_t*)a, nullptr, (bf16_t*)out, n, 0);
+  return check_launch("silu");
+}
+int add_bf16(const void* a, const void* b, void* out, int64_t n, hipStream_t st) {
+  if (n == 0) return 0;
+  unary_binary_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b,
+                                                                        (bf16_t*)out, n, 1);
+  return check_launch("add");
+}
+int scatter_cols(const void* src, void* dst, int64_t rows, int C, int64_t ld, int col0, hipStream_t st) {
+  if (C % 8 || col0 % 8 || ld % 8) return fail("scatter_cols: C, col0, ld must be multiples of 8");
+  const int64_t n = rows * (C / 8);
+  if (n == 0) return 0;
+  scatter_cols_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, rows, C, ld,
+                                                                         col0);
+  return check_launch("scatter_cols");
+}
+int copy_rows(const void* src, int64_t sld, int64_t sbs, void* dst, int64_t dld, int64_t dbs, int rows, int cols,
+              int batch, hipStream_t st) {
+  if (cols % 8 || sld % 8 || dld % 8 || sbs % 8 || dbs % 8) return fail("copy_rows: cols/strides must be multiples of 8");
+  const int64_t total = (int64_t)batch * rows * (cols / 8);
+  if (total == 0) return 0;
+  copy_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>((const bf16_t*)src, sld, sbs, (bf16_t*)dst, dld,
+                                                                          dbs, rows, cols / 8, total);
+  return check_launch("copy_rows");
+}
+int select_step(const void* table, void* cur, int64_t per_step_elems, int* step_ptr, hipStream_t st) {
+  if (per_step_elems % 8) return fail("select_step: per-step size must be a multiple of 8 elements");
+  const int64_t ch = per_step_elems / 8;
+  unsigned grid = (unsigned)((ch + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  select_step_kernel<<<grid, 256, 0, st>>>((const bf16_t*)table, (bf16_t*)cur, ch, step_ptr, 0);
+  return check_launch("select_step");
+}
+int advance_step(int* step_ptr, hipStream_t st) {
+  advance_step_kernel<<<1, 1, 0, st>>>(step_ptr);
+  return check_launch("advance_step");
+}
+
+}  // namespace tfx

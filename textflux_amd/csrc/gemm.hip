@@ -1,0 +1,400 @@
+// bf16 GEMM for the DiT linear layers:  C[b][M,N] = epi( A[b][M,K] @ W[N,K]^T + bias ).
+//
+// Fast path (gemm8p_kernel): 256x256x64 block tile, 8 waves (512 threads) as 2 row-groups x 4 column
+// stripes, v_mfma_f32_32x32x16_bf16 with the operands swapped (MFMA "A" = weight rows, "B" = token rows) so
+// that every lane ends up holding 4 consecutive output columns of one token row -> 8-byte row-major stores.
+// Operand tiles go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip); the 16-byte chunks of each
+// 128-byte LDS row are XOR-swizzled with ((row>>1)&7) (applied on the per-lane *source* address, LDS image
+// stays lane-linear) so every ds_read_b128 lane group is bank-conflict free.  The two row-groups run a
+// ping-pong schedule offset by one s_barrier: while one group's 4 waves (one per SIMD) issue 8 MFMAs, the
+// other group reads its next fragments from LDS and issues the prefetch of a quarter K-tile that is one and
+// a half K-tiles ahead; waits are counted (vmcnt(6)), never drained, inside the main loop.
+//
+// Schedule (slots = half phases, tile t, phase q in 0..3; group g runs loads(p) at slot 2p-1+g, MFMA(p) at
+// 2p+g).  Each wave keeps X fragments for 64 rows and both 32-column W fragments in registers:
+//   q0: read X_lo, W_lo | q1: read W_hi | q2: read X_hi | q3: no reads.
+// so the last LDS read of tile t is W_lo@q0, W_hi@q1, X_lo@q0, X_hi@q2, and the buffer of tile t (2 sets)
+// is refilled for tile t+2 by:  G1@q2:W_lo(a)  G0@q3:W_lo(b)  G1@q3:X0_lo  G0@q0':X1_lo  G1@q0':W_hi(a)
+// G0@q1':W_hi(b)  G1@q1':X0_hi  G0@q2':X1_hi  (' = next tile).  Every refill is issued >= 2 barriers after
+// the last read of the bytes it overwrites and is waited for (own vmcnt(6) + barrier) >= 1 barrier before
+// its first reader; see DESIGN.md "GEMM schedule" for the slot table.
+#include "common.h"
+#include "launch.h"
+
+namespace tfx {
+
+struct GemmParams {
+  const bf16_t* A; int64_t lda, a_bs;
+  const bf16_t* W; int64_t ldw;
+  const bf16_t* bias;
+  bf16_t* C; int64_t ldc, c_bs;
+  int M, N, K, batch, tm, tn;
+  int gelu_from;
+  const bf16_t* gate; int64_t gate_bs;
+  const bf16_t* res; int64_t ldr, r_bs;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Generic fallback: any M, N, K (K % 8 == 0 not even required), fp32 FMA on 64x64x16 LDS tiles.
+// Only used for shapes the MFMA kernel does not take (K % 64 != 0: unit-test configs) and as the
+// on-device cross-check of the fast kernel.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
+  __shared__ float As[16][65];
+  __shared__ float Ws[16][65];
+  const int b = blockIdx.z;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const bf16_t* A = p.A + b * p.a_bs;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < p.K; k0 += 16) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      const int m = m0 + r, n = n0 + r, k = k0 + c;
+      As[c][r] = (m < p.M && k < p.K) ? bf2f(A[(int64_t)m * p.lda + k]) : 0.f;
+      Ws[c][r] = (n < p.N && k < p.K) ? bf2f(p.W[(int64_t)n * p.ldw + k]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; w[i] = Ws[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * w[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= p.N) continue;
+      float v = acc[i][j] + (p.bias ? bf2f(p.bias[n]) : 0.f);
+      if (EPI == EPI_BIAS_GELU) { if (n >= p.gelu_from) v = gelu_tanh(v); }
+      if (EPI == EPI_BIAS_GATE_RES) {
+        const float g = bf2f(p.gate[b * p.gate_bs + n]);
+        const float r = bf2f(p.res[b * p.r_bs + (int64_t)m * p.ldr + n]);
+        v = r + round_bf(g * round_bf(v));
+      }
+      p.C[b * p.c_bs + (int64_t)m * p.ldc + n] = f2bf(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int LDS_X = 0;            // X_g set s at g*32768 + s*16384   (128 rows x 128 B)
+constexpr int LDS_W = 65536;        // W   set s at 65536 + s*32768     (256 rows x 128 B)
+constexpr int LDS_DUMMY = 131072;   // 8 x 1 KiB sink for out-of-range prefetches (keeps vmcnt counts uniform)
+constexpr int LDS_TOTAL = 131072 + 8 * 1024;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const bf16_t* g, char* smem, uint32_t lds_off) {
+  __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(smem + lds_off), 16, 0, 0);
+}
+
+#define TFX_BARRIER()                          \
+  do {                                         \
+    __builtin_amdgcn_sched_barrier(0);         \
+    __builtin_amdgcn_s_barrier();              \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2;   // row group: rows g*128 .. +128 of the block tile
+  const int wc = wave & 3;   // column stripe: cols wc*64 .. +64
+
+  // ---- tile coordinates: XCD-contiguous remap (bijective), then grouped (8 row tiles) ordering.
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int per_batch = p.tm * p.tn;
+  const int b = bid / per_batch;
+  int idx = bid - b * per_batch;
+  constexpr int GM = 8;
+  const int grp = idx / (GM * p.tn);
+  const int first_m = grp * GM;
+  const int gsz = min(GM, p.tm - first_m);
+  idx -= grp * GM * p.tn;
+  const int tile_m = first_m + idx % gsz;
+  const int tile_n = idx / gsz;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+  const bf16_t* Xb = p.A + b * p.a_bs + (int64_t)m0 * p.lda;
+  const bf16_t* Wb = p.W + (int64_t)n0 * p.ldw;
+  const int nt = p.K >> 6;
+
+  // ---- prefetch bookkeeping.  Item table of this wave's group, in phase order q0..q3:
+  //   G0: X1_lo(u+1)  W_hi_b(u+1)  X1_hi(u+1)  W_lo_b(u+2)
+  //   G1: W_hi_a(u+1) X0_hi(u+1)   W_lo_a(u+2) X0_lo(u+2)
+  // Every lane issues 2 x 16-byte loads per item; piece = 8 consecutive LDS rows written by one wave-instr.
+  const int lr = lane >> 3, cphys = lane & 7;
+  int goff[4][2];        // per-lane element offset from Xb / Wb (without the k offset)
+  uint32_t ldst[4][2];   // wave-uniform LDS byte offset inside set 0 of the destination tile
+  bool isx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool x_item = g == 0 ? (q == 0 || q == 2) : (q == 1 || q == 3);
+    isx[q] = x_item;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pc = wc * 2 + j;  // piece 0..7 (wc doubles as the wave's index inside its group)
+      int row0;                   // first tile-local row of the piece
+      if (x_item) {
+        const int rb = g == 0 ? (q == 0 ? 0 : 64) : (q == 1 ? 64 : 0);
+        row0 = rb + pc * 8;
+      } else {
+        const int hi = g == 0 ? (q == 1) : (q == 0);  // W_hi items
+        const int half = g == 0 ? 128 : 0;            // G0 stages the "b" halves (rows 128..255)
+        row0 = half + (pc >> 2) * 64 + hi * 32 + (pc & 3) * 8;
+      }
+      const int row = row0 + lr;
+      const int key = (row >> 1) & 7;
+      const int clog = cphys ^ key;
+      if (x_item) {
+        const int h = 1 - g;  // G0 stages X1, G1 stages X0
+        int grow = h * 128 + row;
+        if (m0 + grow > p.M - 1) grow = p.M - 1 - m0;
+        goff[q][j] = grow * (int)p.lda + clog * 8;
+        ldst[q][j] = LDS_X + h * 32768 + row0 * 128;
+      } else {
+        int grow = row;
+        if (n0 + grow > p.N - 1) grow = p.N - 1 - n0;
+        goff[q][j] = grow * (int)p.ldw + clog * 8;
+        ldst[q][j] = LDS_W + row0 * 128;
+      }
+    }
+  }
+  const uint32_t dummy = LDS_DUMMY + wave * 1024;
+
+  auto stage = [&](int q, int tile) {
+    const bool ok = tile < nt;
+    const int kt = ok ? tile : nt - 1;
+    const bf16_t* base = (isx[q] ? Xb : Wb) + (int64_t)kt * 64;
+    const uint32_t setoff = (tile & 1) * (isx[q] ? 16384u : 32768u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(base + goff[q][j], smem, ok ? ldst[q][j] + setoff : dummy);
+  };
+
+  // ---- fragment read addresses (set 0); per-lane swizzle key is (lane>>1)&7 because fragment rows are
+  // 32-aligned block + (lane & 31).
+  const int hi = lane >> 5;
+  const int key = (lane >> 1) & 7;
+  uint32_t fx[4], fw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const uint32_t o = (lane & 31) * 128 + (((kk * 2 + hi) ^ key) << 4);
+    fx[kk] = LDS_X + g * 32768 + o;
+    fw[kk] = LDS_W + wc * 64 * 128 + o;
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: all of tile 0, plus the part of tile 1 that the steady state would have issued
+  // during "tile -1" (the (u+2)-type items).
+#pragma unroll
+  for (int q = 0; q < 4; ++q) stage(q, 0);
+  if (g == 0) {
+    stage(3, 1);
+  } else {
+    stage(2, 1);
+    stage(3, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TFX_BARRIER();
+  if (g == 1) TFX_BARRIER();  // stagger: G1 runs one barrier behind G0
+
+  bf16x8 xf[2][4], wlo[4], whi[4];
+
+#define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
+#define MFMA8(WF, ROWBASE, NJ)                                                                            \
+  do {                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+      acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
+      acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
+    }                                                                                                     \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+  } while (0)
+#define WAIT_PREFETCH() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+
+  auto tile_body = [&](int u, const uint32_t xs, const uint32_t ws) {
+    // xs / ws: byte offset of this tile's set inside the X / W regions (0 or 16384 / 32768)
+    // ---- q0: X_lo (rows 0..63 of the group's half), W_lo (cols 0..31 of the stripe)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      xf[0][kk] = LDS_FRAG(fx[kk] + xs);
+      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);
+      wlo[kk] = LDS_FRAG(fw[kk] + ws);
+    }
+    stage(0, u + 1);
+    WAIT_PREFETCH();
+    TFX_BARRIER();
+    MFMA8(wlo, 0, 0);
+    TFX_BARRIER();
+    // ---- q1: W_hi (cols 32..63)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);
+    stage(1, u + 1);
+    WAIT_PREFETCH();
+    TFX_BARRIER();
+    MFMA8(whi, 0, 1);
+    TFX_BARRIER();
+    // ---- q2: X_hi (rows 64..127)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      xf[0][kk] = LDS_FRAG(fx[kk] + xs + 8192);
+      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);
+    }
+    stage(2, g == 0 ? u + 1 : u + 2);
+    WAIT_PREFETCH();
+    TFX_BARRIER();
+    MFMA8(whi, 2, 1);
+    TFX_BARRIER();
+    // ---- q3: no reads
+    stage(3, u + 2);
+    WAIT_PREFETCH();
+    TFX_BARRIER();
+    MFMA8(wlo, 2, 0);
+    TFX_BARRIER();
+  };
+
+  for (int u = 0; u < nt; u += 2) {
+    tile_body(u, 0u, 0u);
+    if (u + 1 < nt) tile_body(u + 1, 16384u, 32768u);
+  }
+  if (g == 0) TFX_BARRIER();  // re-align the two groups
+#undef LDS_FRAG
+#undef MFMA8
+#undef WAIT_PREFETCH
+
+  // ---- epilogue: lane holds, per (mi, nj, quad), 4 consecutive columns of one row:
+  //   m = m0 + g*128 + mi*32 + (lane & 31),  n = n0 + wc*64 + nj*32 + quad*8 + hi*4 + (r & 3)
+  const int mrow = m0 + g * 128 + (lane & 31);
+  const int ncol = n0 + wc * 64 + hi * 4;
+  const bool do_gelu = (EPI == EPI_BIAS_GELU) && (n0 >= p.gelu_from);
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int n = ncol + nj * 32 + qd * 8;
+      if (n >= p.N) continue;
+      float bs[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n);
+        bs[0] = __uint_as_float(raw[0] << 16); bs[1] = __uint_as_float(raw[0] & 0xffff0000u);
+        bs[2] = __uint_as_float(raw[1] << 16); bs[3] = __uint_as_float(raw[1] & 0xffff0000u);
+      }
+      if (EPI == EPI_BIAS_GATE_RES) {
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + n);
+        gt[0] = __uint_as_float(raw[0] << 16); gt[1] = __uint_as_float(raw[0] & 0xffff0000u);
+        gt[2] = __uint_as_float(raw[1] << 16); gt[3] = __uint_as_float(raw[1] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = mrow + mi * 32;
+        if (m >= p.M) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][qd * 4 + e] + bs[e];
+        if (do_gelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+        }
+        if (EPI == EPI_BIAS_GATE_RES) {
+          const u32x2 raw = *reinterpret_cast<const u32x2*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + n);
+          const float r4[4] = {__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
+                               __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = r4[e] + round_bf(gt[e] * round_bf(v[e]));
+        }
+        u32x2 o;
+        o[0] = pack_bf2(v[0], v[1]);
+        o[1] = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static GemmParams make_params(const GemmArgs& a) {
+  GemmParams p;
+  p.A = (const bf16_t*)a.A; p.lda = a.lda; p.a_bs = a.a_bstride;
+  p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
+  p.bias = (const bf16_t*)a.bias;
+  p.C = (bf16_t*)a.C; p.ldc = a.ldc; p.c_bs = a.c_bstride;
+  p.M = a.M; p.N = a.N; p.K = a.K; p.batch = a.batch;
+  p.tm = (a.M + 255) / 256; p.tn = (a.N + 255) / 256;
+  p.gelu_from = a.gelu_from_col;
+  p.gate = (const bf16_t*)a.gate; p.gate_bs = a.gate_bstride;
+  p.res = (const bf16_t*)a.res; p.ldr = a.ldr; p.r_bs = a.r_bstride;
+  return p;
+}
+
+static bool fast_ok(const GemmArgs& a) {
+  const bool al16 = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.C % 8 == 0);
+  return a.K % 64 == 0 && a.K >= 64 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 4 == 0 &&
+         a.a_bstride % 8 == 0 && a.c_bstride % 4 == 0 && al16 && (int64_t)255 * a.lda < (1ll << 31) &&
+         (int64_t)255 * a.ldw < (1ll << 31) &&
+         (a.epilogue != EPI_BIAS_GATE_RES || (a.ldr % 4 == 0 && a.r_bstride % 4 == 0 && a.gate_bstride % 4 == 0)) &&
+         (a.epilogue != EPI_BIAS_GELU || a.gelu_from_col % 256 == 0);
+}
+
+template <int EPI>
+static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
+  if (variant == 1) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)gemm8p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_TOTAL) != hipSuccess)
+        return fail("gemm: cannot raise dynamic LDS limit to %d bytes", LDS_TOTAL);
+      attr_set = true;
+    }
+    const unsigned grid = (unsigned)(p.batch * p.tm * p.tn);
+    gemm8p_kernel<EPI><<<grid, 512, LDS_TOTAL, st>>>(p);
+  } else {
+    dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch);
+    gemm_generic_kernel<EPI><<<grid, 256, 0, st>>>(p);
+  }
+  return check_launch("gemm_bf16");
+}
+
+int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return 0;
+  if (a.K <= 0) return fail("gemm: K must be positive");
+  if (variant == 1 && !fast_ok(a)) return fail("gemm: shape/alignment not supported by the MFMA kernel");
+  if (a.epilogue == EPI_BIAS_GATE_RES && (!a.gate || !a.res)) return fail("gemm: gate/res pointers required");
+  const GemmParams p = make_params(a);
+  switch (a.epilogue) {
+    case EPI_BIAS: return launch_variant<EPI_BIAS>(p, variant, st);
+    case EPI_BIAS_GELU: return launch_variant<EPI_BIAS_GELU>(p, variant, st);
+    case EPI_BIAS_GATE_RES: return launch_variant<EPI_BIAS_GATE_RES>(p, variant, st);
+  }
+  return fail("gemm: unknown epilogue %d", a.epilogue);
+}
+
+int gemm_bf16(const GemmArgs& a, hipStream_t st) { return gemm_bf16_variant(a, fast_ok(a) ? 1 : 0, st); }
+
+}  // namespace tfx

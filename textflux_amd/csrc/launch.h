@@ -1,0 +1,62 @@
+// Internal (C++) launch API shared between the kernel translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfx {
+
+// Error plumbing: every launcher returns 0 on success; on failure the message is kept per thread and is
+// readable through tfx_last_error().
+int fail(const char* fmt, ...);
+int check_launch(const char* what);
+const char* last_error();
+
+// GEMM epilogues (C = epi(A @ W^T + bias)).
+enum Epilogue : int {
+  EPI_BIAS = 0,           // C = acc + bias
+  EPI_BIAS_GELU = 1,      // C = gelu_tanh(acc + bias) for columns >= gelu_from_col, plain bias below it
+  EPI_BIAS_GATE_RES = 2,  // C = res + gate[b, col] * (acc + bias)
+};
+
+struct GemmArgs {
+  const void* A; int64_t lda; int64_t a_bstride;     // activations  [batch][M, K] bf16, row stride lda
+  const void* W;                                      // weights      [N, K] bf16 (nn.Linear layout), row stride ldw
+  int64_t ldw;
+  const void* bias;                                   // [N] bf16 or null
+  void* C; int64_t ldc; int64_t c_bstride;           // output       [batch][M, N] bf16
+  int M, N, K, batch;
+  int epilogue;
+  int gelu_from_col;                                  // EPI_BIAS_GELU: first column that gets GELU
+  const void* gate; int64_t gate_bstride;             // EPI_BIAS_GATE_RES: gate [batch][N] bf16
+  const void* res; int64_t ldr; int64_t r_bstride;    // residual [batch][M, N] bf16 (may alias C)
+};
+int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
+int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
+
+struct AttnArgs {
+  const void* q; const void* k; const void* v; void* o;   // bf16, element (b, n, h, d) at base + b*bstride + n*ld + h*128 + d
+  int64_t ldq, ldk, ldv, ldo;
+  int64_t q_bstride, k_bstride, v_bstride, o_bstride;
+  int B, H, N;
+  float scale;
+};
+int joint_attention(const AttnArgs& a, hipStream_t st);
+
+int ln_modulate(const void* x, void* out, const void* shift, const void* scale, int64_t mod_bstride,
+                int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldo,
+                int64_t o_bstride, float eps, hipStream_t st);
+int rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int q_off, int k_off, int H, int Ntok, int T, int B,
+                 const void* wq_img, const void* wk_img, const void* wq_txt, const void* wk_txt, const float* cosT,
+                 const float* sinT, float eps, hipStream_t st);
+int sched_step(bool amo, const void* v, void* x, void* xin, int64_t ldxin, int C, int64_t rows, const float* coef,
+               const int* step_ptr, int step, const float* noise, hipStream_t st);
+int timestep_embedding(const float* t, void* out, int n, hipStream_t st);
+int silu_bf16(const void* a, void* out, int64_t n, hipStream_t st);
+int add_bf16(const void* a, const void* b, void* out, int64_t n, hipStream_t st);
+int scatter_cols(const void* src, void* dst, int64_t rows, int C, int64_t ld, int col0, hipStream_t st);
+int copy_rows(const void* src, int64_t sld, int64_t sbs, void* dst, int64_t dld, int64_t dbs, int rows, int cols,
+              int batch, hipStream_t st);
+int select_step(const void* table, void* cur, int64_t per_step_elems, int* step_ptr, hipStream_t st);
+int advance_step(int* step_ptr, hipStream_t st);
+
+}  // namespace tfx

@@ -1,0 +1,189 @@
+"""Torch-tensor front end of the C-ABI kernels (device memory + stream plumbing only, no math here).
+
+Every function enqueues HIP kernels from libtextflux_hip.so on torch's current stream and returns torch
+tensors that alias / own the outputs.  Inputs must live on a ROCm device; bf16 unless stated.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES = 0, 1, 2
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("textflux_amd ops need tensors on the ROCm device (no CPU fallback exists)")
+
+
+def _rows_view(t: torch.Tensor):
+    """(ptr, ld, batch_stride, rows_per_batch, batch) of a [.., rows, cols] tensor with unit inner stride."""
+    assert t.stride(-1) == 1
+    if t.dim() == 2:
+        return t.data_ptr(), t.stride(0), 0, t.shape[0], 1
+    assert t.dim() == 3
+    return t.data_ptr(), t.stride(1), t.stride(0), t.shape[1], t.shape[0]
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+         epilogue: int = EPI_BIAS, gelu_from_col: int = 0, gate: Optional[torch.Tensor] = None,
+         res: Optional[torch.Tensor] = None, variant: int = -1) -> torch.Tensor:
+    """out[b] = epi(a[b] @ w.T + bias).  a: [M,K] or [B,M,K] (row/batch strided views allowed), w: [N,K]."""
+    _chk_dev(a, w, bias, out, gate, res)
+    assert a.dtype == BF16 and w.dtype == BF16 and w.dim() == 2 and w.stride(1) == 1
+    ap, lda, abs_, M, batch = _rows_view(a)
+    N, K = w.shape
+    assert a.shape[-1] == K
+    if out is None:
+        out = torch.empty(*a.shape[:-1], N, dtype=BF16, device=a.device)
+    cp, ldc, cbs, M2, b2 = _rows_view(out)
+    assert (M2, b2) == (M, batch) and out.shape[-1] == N
+    g = L.GemmArgs()
+    g.A, g.lda, g.a_bstride = ap, lda, abs_
+    g.W, g.ldw, g.bias = w.data_ptr(), w.stride(0), _p(bias)
+    g.C, g.ldc, g.c_bstride = cp, ldc, cbs
+    g.M, g.N, g.K, g.batch = M, N, K, batch
+    g.epilogue, g.gelu_from_col = epilogue, gelu_from_col
+    if epilogue == EPI_BIAS_GATE_RES:
+        assert gate is not None and res is not None and gate.stride(-1) == 1
+        g.gate = gate.data_ptr()
+        g.gate_bstride = gate.stride(0) if gate.dim() == 2 else 0
+        rp, ldr, rbs, _, _ = _rows_view(res)
+        g.res, g.ldr, g.r_bstride = rp, ldr, rbs
+    L.check(L.lib().tfx_gemm_bf16(C.byref(g), variant, _stream()), "gemm")
+    return out
+
+
+def ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None,
+                eps: float = 1e-6) -> torch.Tensor:
+    """LayerNorm(x) * (1 + scale[b]) + shift[b];  x [B,R,D], shift/scale [B,D] (row-strided views allowed)."""
+    _chk_dev(x, shift, scale, out)
+    assert x.dim() == 3 and x.dtype == BF16
+    if out is None:
+        out = torch.empty_like(x)
+    xp, ldx, xbs, R, B = _rows_view(x)
+    op, ldo, obs, _, _ = _rows_view(out)
+    assert shift.stride(-1) == 1 and scale.stride(-1) == 1 and shift.stride(0) == scale.stride(0)
+    L.check(L.lib().tfx_ln_modulate(xp, ldx, xbs, op, ldo, obs, shift.data_ptr(), scale.data_ptr(), shift.stride(0),
+                                    R, B, x.shape[-1], eps, _stream()), "ln_modulate")
+    return out
+
+
+def rmsnorm_rope_(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, wq_img, wk_img, wq_txt, wk_txt,
+                  cos: torch.Tensor, sin: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """In place on buf [B,N,ld]: q at columns q_off.., k at k_off.. (H heads of 128)."""
+    _chk_dev(buf, wq_img, wk_img, wq_txt, wk_txt, cos, sin)
+    assert buf.dim() == 3 and buf.dtype == BF16 and cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+    B, N, _ = buf.shape
+    assert cos.shape == (N, 128)
+    L.check(L.lib().tfx_rmsnorm_rope(buf.data_ptr(), buf.stride(1), buf.stride(0), q_off, k_off, H, N, T, B,
+                                     wq_img.data_ptr(), wk_img.data_ptr(), wq_txt.data_ptr(), wk_txt.data_ptr(),
+                                     cos.data_ptr(), sin.data_ptr(), eps, _stream()), "rmsnorm_rope")
+    return buf
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: Optional[torch.Tensor] = None,
+              scale: Optional[float] = None) -> torch.Tensor:
+    """q,k,v: [B,N,H*128] (views with row/batch strides allowed) -> out [B,N,H*128]."""
+    _chk_dev(q, k, v, out)
+    B, N, HD = q.shape
+    H = HD // 128
+    assert HD % 128 == 0 and q.dtype == BF16
+    if out is None:
+        out = torch.empty(B, N, HD, dtype=BF16, device=q.device)
+    a = L.AttnArgs()
+    a.q, a.k, a.v, a.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+    a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.B, a.H, a.N = B, H, N
+    a.scale = scale if scale is not None else 128 ** -0.5
+    L.check(L.lib().tfx_joint_attention(C.byref(a), _stream()), "joint_attention")
+    return out
+
+
+def euler_step_(v: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, step: int = 0,
+                step_ptr: Optional[torch.Tensor] = None, xin: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk_dev(v, x, coef, step_ptr, xin)
+    assert v.is_contiguous() and x.is_contiguous() and coef.dtype == torch.float32
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    L.check(L.lib().tfx_euler_step(v.data_ptr(), x.data_ptr(), _p(xin), xin.stride(-2) if xin is not None else 0, Cc,
+                                   rows, coef.data_ptr(), _p(step_ptr), step, _stream()), "euler_step")
+    return x
+
+
+def amo_step_(v: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, noise: torch.Tensor, step: int = 0,
+              step_ptr: Optional[torch.Tensor] = None, xin: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk_dev(v, x, coef, noise, step_ptr, xin)
+    assert v.is_contiguous() and x.is_contiguous() and noise.is_contiguous() and noise.dtype == torch.float32
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    L.check(L.lib().tfx_amo_step(v.data_ptr(), x.data_ptr(), _p(xin), xin.stride(-2) if xin is not None else 0, Cc,
+                                 rows, coef.data_ptr(), _p(step_ptr), step, noise.data_ptr(), _stream()), "amo_step")
+    return x
+
+
+def timestep_embedding(t: torch.Tensor) -> torch.Tensor:
+    _chk_dev(t)
+    t = t.contiguous().float()
+    out = torch.empty(t.numel(), 256, dtype=BF16, device=t.device)
+    L.check(L.lib().tfx_timestep_embedding(t.data_ptr(), out.data_ptr(), t.numel(), _stream()), "timestep_embedding")
+    return out
+
+
+def silu(a: torch.Tensor) -> torch.Tensor:
+    _chk_dev(a)
+    a = a.contiguous()
+    out = torch.empty_like(a)
+    L.check(L.lib().tfx_silu(a.data_ptr(), out.data_ptr(), a.numel(), _stream()), "silu")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _chk_dev(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    L.check(L.lib().tfx_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "add")
+    return out
+
+
+def scatter_cols_(src: torch.Tensor, dst: torch.Tensor, col0: int) -> torch.Tensor:
+    """dst[..., col0:col0+C] = src  (src [.., C] contiguous, dst [.., ld] contiguous)."""
+    _chk_dev(src, dst)
+    assert src.is_contiguous() and dst.is_contiguous()
+    Cc = src.shape[-1]
+    L.check(L.lib().tfx_scatter_cols(src.data_ptr(), dst.data_ptr(), src.numel() // Cc, Cc, dst.shape[-1], col0,
+                                     _stream()), "scatter_cols")
+    return dst
+
+
+def copy_rows_(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    _chk_dev(src, dst)
+    sp, sld, sbs, R, B = _rows_view(src)
+    dp, dld, dbs, R2, B2 = _rows_view(dst)
+    assert (R, B) == (R2, B2) and src.shape[-1] == dst.shape[-1]
+    L.check(L.lib().tfx_copy_rows(sp, sld, sbs, dp, dld, dbs, R, src.shape[-1], B, _stream()), "copy_rows")
+    return dst
+
+
+def select_step_(table: torch.Tensor, cur: torch.Tensor, step_ptr: torch.Tensor) -> None:
+    L.check(L.lib().tfx_select_step(table.data_ptr(), cur.data_ptr(), cur.numel(), step_ptr.data_ptr(), _stream()),
+            "select_step")
+
+
+def advance_step_(step_ptr: torch.Tensor) -> None:
+    L.check(L.lib().tfx_advance_step(step_ptr.data_ptr(), _stream()), "advance_step")

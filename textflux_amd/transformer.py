@@ -1,0 +1,373 @@
+"""FluxTransformer2DModel on the MI355X HIP engine.
+
+Drop-in for the reference class at the `forward(...)` / `from_pretrained(...)` / `.config` level
+(reference: diffusers/src/diffusers/models/transformers/transformer_flux.py:848-1212, "D/" below), plus an
+engine-level session API the pipeline uses to hoist everything that does not depend on the denoising step:
+
+* context_embedder(prompt_embeds)                      (D/.../transformer_flux.py:1099)  once per call
+* RoPE tables from txt/img ids                          (:1114-1115)                      once per call
+* time/guidance/pooled embedding -> temb -> SiLU -> every AdaLN modulation Linear of every block, as ONE
+  GEMM against the row-stacked modulation matrix, for ALL steps at once (:1094-1098 and
+  D/models/normalization.py:168, 200, 364)
+
+Weights are stored pre-fused (pure row concatenations): [to_k; to_v; to_q] per stream,
+[to_k; to_v; to_q; proj_mlp] per single block, and all norm*.linear stacked.  All arithmetic runs in
+libtextflux_hip.so; torch only owns the device buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+def rope_tables(ids: torch.Tensor, axes_dim=(16, 56, 56), theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin [N, sum(axes_dim)] fp32, float64 frequencies, each value repeated twice (interleaved pairs)
+    (FluxPosEmbed.forward, D/models/embeddings.py:953-973; get_1d_rotary_pos_embed :853-866).  Host logic."""
+    pos = ids.detach().to("cpu", torch.float64)
+    cos, sin = [], []
+    for i, d in enumerate(axes_dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+        ang = torch.outer(pos[:, i], freqs)
+        cos.append(ang.cos().repeat_interleave(2, dim=1).float())
+        sin.append(ang.sin().repeat_interleave(2, dim=1).float())
+    return torch.cat(cos, dim=-1).contiguous(), torch.cat(sin, dim=-1).contiguous()
+
+
+class _Config(SimpleNamespace):
+    def get(self, k, default=None):
+        return getattr(self, k, default)
+
+
+class FluxTransformer2DModel:
+    config_name = "config.json"
+
+    def __init__(self, patch_size: int = 1, in_channels: int = 64, out_channels: Optional[int] = None,
+                 num_layers: int = 19, num_single_layers: int = 38, attention_head_dim: int = 128,
+                 num_attention_heads: int = 24, joint_attention_dim: int = 4096, pooled_projection_dim: int = 768,
+                 guidance_embeds: bool = False, axes_dims_rope: Tuple[int, ...] = (16, 56, 56)):
+        if attention_head_dim != 128:
+            raise ValueError("the gfx950 attention / RMSNorm+RoPE kernels are specialised for head_dim 128 (FLUX.1)")
+        if sum(axes_dims_rope) != attention_head_dim:
+            raise ValueError("sum(axes_dims_rope) must equal attention_head_dim")
+        if patch_size != 1:
+            raise ValueError("patch_size must be 1 (FLUX.1)")
+        self.config = _Config(patch_size=patch_size, in_channels=in_channels, out_channels=out_channels,
+                              num_layers=num_layers, num_single_layers=num_single_layers,
+                              attention_head_dim=attention_head_dim, num_attention_heads=num_attention_heads,
+                              joint_attention_dim=joint_attention_dim, pooled_projection_dim=pooled_projection_dim,
+                              guidance_embeds=guidance_embeds, axes_dims_rope=tuple(axes_dims_rope))
+        self.out_channels = out_channels or in_channels
+        self.inner_dim = num_attention_heads * attention_head_dim
+        self.dtype = BF16
+        self.device = torch.device("cpu")
+        self.w: Dict[str, torch.Tensor] = {}     # fused weights (see module docstring)
+        self._session: Optional["DitSession"] = None
+        D = self.inner_dim
+        self.mod_len = 12 * D * num_layers + 3 * D * num_single_layers + 2 * D
+
+    # ------------------------------------------------------------------ weights
+    def _alloc(self, device) -> None:
+        c, D = self.config, self.inner_dim
+
+        def lin(name, o, i):
+            self.w[name + ".w"] = torch.empty(o, i, dtype=BF16, device=device)
+            self.w[name + ".b"] = torch.empty(o, dtype=BF16, device=device)
+
+        embs = ["timestep_embedder"] + (["guidance_embedder"] if c.guidance_embeds else [])
+        for e in embs:
+            lin(f"{e}.1", D, 256)
+            lin(f"{e}.2", D, D)
+        lin("text_embedder.1", D, c.pooled_projection_dim)
+        lin("text_embedder.2", D, D)
+        lin("context_embedder", D, c.joint_attention_dim)
+        lin("x_embedder", D, c.in_channels)
+        lin("proj_out", self.out_channels, D)
+        lin("mod", self.mod_len, D)
+        for i in range(c.num_layers):
+            for n in ("qkv_img", "qkv_txt"):
+                lin(f"d{i}.{n}", 3 * D, D)
+            for n in ("out_img", "out_txt"):
+                lin(f"d{i}.{n}", D, D)
+            for n in ("ff1_img", "ff1_txt"):
+                lin(f"d{i}.{n}", 4 * D, D)
+            for n in ("ff2_img", "ff2_txt"):
+                lin(f"d{i}.{n}", D, 4 * D)
+            for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                self.w[f"d{i}.{n}"] = torch.empty(128, dtype=BF16, device=device)
+        for j in range(c.num_single_layers):
+            lin(f"s{j}.qkv_mlp", 7 * D, D)
+            lin(f"s{j}.proj_out", D, 5 * D)
+            for n in ("norm_q", "norm_k"):
+                self.w[f"s{j}.{n}"] = torch.empty(128, dtype=BF16, device=device)
+        self.device = torch.device(device)
+
+    def _fusion_map(self) -> List[Tuple[str, str, int]]:
+        """(reference key prefix, fused tensor name, row offset) for every nn.Linear of the reference state dict."""
+        c, D = self.config, self.inner_dim
+        m: List[Tuple[str, str, int]] = []
+        embs = ["timestep_embedder"] + (["guidance_embedder"] if c.guidance_embeds else [])
+        for e in embs:
+            m += [(f"time_text_embed.{e}.linear_1", f"{e}.1", 0), (f"time_text_embed.{e}.linear_2", f"{e}.2", 0)]
+        m += [("time_text_embed.text_embedder.linear_1", "text_embedder.1", 0),
+              ("time_text_embed.text_embedder.linear_2", "text_embedder.2", 0),
+              ("context_embedder", "context_embedder", 0), ("x_embedder", "x_embedder", 0), ("proj_out", "proj_out", 0)]
+        for i in range(c.num_layers):
+            p = f"transformer_blocks.{i}"
+            m += [(p + ".norm1.linear", "mod", 12 * D * i), (p + ".norm1_context.linear", "mod", 12 * D * i + 6 * D)]
+            m += [(p + ".attn.to_k", f"d{i}.qkv_img", 0), (p + ".attn.to_v", f"d{i}.qkv_img", D),
+                  (p + ".attn.to_q", f"d{i}.qkv_img", 2 * D)]
+            m += [(p + ".attn.add_k_proj", f"d{i}.qkv_txt", 0), (p + ".attn.add_v_proj", f"d{i}.qkv_txt", D),
+                  (p + ".attn.add_q_proj", f"d{i}.qkv_txt", 2 * D)]
+            m += [(p + ".attn.to_out.0", f"d{i}.out_img", 0), (p + ".attn.to_add_out", f"d{i}.out_txt", 0),
+                  (p + ".ff.net.0.proj", f"d{i}.ff1_img", 0), (p + ".ff.net.2", f"d{i}.ff2_img", 0),
+                  (p + ".ff_context.net.0.proj", f"d{i}.ff1_txt", 0), (p + ".ff_context.net.2", f"d{i}.ff2_txt", 0)]
+        base = 12 * D * c.num_layers
+        for j in range(c.num_single_layers):
+            p = f"single_transformer_blocks.{j}"
+            m += [(p + ".norm.linear", "mod", base + 3 * D * j)]
+            m += [(p + ".attn.to_k", f"s{j}.qkv_mlp", 0), (p + ".attn.to_v", f"s{j}.qkv_mlp", D),
+                  (p + ".attn.to_q", f"s{j}.qkv_mlp", 2 * D), (p + ".proj_mlp", f"s{j}.qkv_mlp", 3 * D),
+                  (p + ".proj_out", f"s{j}.proj_out", 0)]
+        m += [("norm_out.linear", "mod", base + 3 * D * c.num_single_layers)]
+        return m
+
+    def _norm_map(self) -> List[Tuple[str, str]]:
+        c = self.config
+        m = []
+        for i in range(c.num_layers):
+            for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                m.append((f"transformer_blocks.{i}.attn.{n}.weight", f"d{i}.{n}"))
+        for j in range(c.num_single_layers):
+            for n in ("norm_q", "norm_k"):
+                m.append((f"single_transformer_blocks.{j}.attn.{n}.weight", f"s{j}.{n}"))
+        return m
+
+    def expected_keys(self) -> List[str]:
+        return [k + s for k, _, _ in self._fusion_map() for s in (".weight", ".bias")] + [k for k, _ in self._norm_map()]
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True, device=None):
+        """Load a reference-format state dict (SURVEY.md Appendix A key names) into the fused device layout."""
+        device = device or (self.device if self.device.type != "cpu" else "cuda")
+        missing = [k for k in self.expected_keys() if k not in sd]
+        unexpected = [k for k in sd if k not in set(self.expected_keys())]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"state dict mismatch: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        if not self.w:
+            self._alloc(device)
+        for key, name, off in self._fusion_map():
+            if key + ".weight" not in sd:
+                continue
+            wt, bs = sd[key + ".weight"], sd[key + ".bias"]
+            self.w[name + ".w"][off:off + wt.shape[0]].copy_(wt.to(BF16))
+            self.w[name + ".b"][off:off + bs.shape[0]].copy_(bs.to(BF16))
+        for key, name in self._norm_map():
+            if key in sd:
+                self.w[name].copy_(sd[key].to(BF16))
+        self._session = None
+        return self
+
+    def init_random_(self, seed: int = 0, device="cuda", w_std: float = 0.02):
+        """Random-init fused weights directly on the device (synthetic benchmarking; no checkpoints offline)."""
+        if not self.w:
+            self._alloc(device)
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for k, t in self.w.items():
+            if t.dim() == 1 and t.numel() == 128 and ".norm_" in k:
+                t.copy_((1 + 0.1 * torch.randn(t.shape, generator=g, device=t.device)).to(BF16))
+            else:
+                # chunked so that a 1 GB fused matrix never needs a 2 GB fp32 temporary
+                flat = t.view(-1)
+                for s in range(0, flat.numel(), 1 << 26):
+                    e = min(flat.numel(), s + (1 << 26))
+                    flat[s:e].copy_((torch.randn(e - s, generator=g, device=t.device) * w_std).to(BF16))
+        self._session = None
+        return self
+
+    @classmethod
+    def from_config(cls, cfg: Dict[str, Any]) -> "FluxTransformer2DModel":
+        keys = ("patch_size", "in_channels", "out_channels", "num_layers", "num_single_layers", "attention_head_dim",
+                "num_attention_heads", "joint_attention_dim", "pooled_projection_dim", "guidance_embeds",
+                "axes_dims_rope")
+        return cls(**{k: cfg[k] for k in keys if k in cfg})
+
+    @classmethod
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, torch_dtype=BF16, device="cuda", **_):
+        """Reads the HF layout: config.json + diffusion_pytorch_model.safetensors or the sharded form with
+        diffusion_pytorch_model.safetensors.index.json (D/models/modeling_utils.py:468)."""
+        from safetensors import safe_open
+        if torch_dtype not in (BF16, None):
+            raise ValueError("the HIP engine computes in bf16; pass torch_dtype=torch.bfloat16")
+        root = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(root, cls.config_name)) as f:
+            model = cls.from_config(json.load(f))
+        index = os.path.join(root, "diffusion_pytorch_model.safetensors.index.json")
+        if os.path.exists(index):
+            with open(index) as f:
+                files = sorted(set(json.load(f)["weight_map"].values()))
+        else:
+            files = ["diffusion_pytorch_model.safetensors"]
+        model._alloc(device)
+        seen = set()
+        for fn in files:  # shard by shard: never more than one shard resident on the host
+            sd = {}
+            with safe_open(os.path.join(root, fn), framework="pt", device="cpu") as f:
+                for k in f.keys():
+                    sd[k] = f.get_tensor(k)
+            seen.update(sd)
+            model.load_state_dict(sd, strict=False, device=device)
+        missing = [k for k in model.expected_keys() if k not in seen]
+        if missing:
+            raise RuntimeError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:3]}")
+        return model
+
+    def to(self, device=None, dtype=None):
+        if dtype is not None and dtype != BF16:
+            raise ValueError("the HIP engine computes in bf16")
+        if device is not None and self.w and torch.device(device).type != self.device.type:
+            self.w = {k: v.to(device) for k, v in self.w.items()}
+            self.device = torch.device(device)
+            self._session = None
+        return self
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ conditioning (step-invariant work)
+    def _lin(self, x, name, **kw):
+        return ops.gemm(x, self.w[name + ".w"], self.w[name + ".b"], **kw)
+
+    def temb(self, t_f32: torch.Tensor, g_f32: Optional[torch.Tensor], pooled: torch.Tensor) -> torch.Tensor:
+        """CombinedTimestepGuidanceTextProjEmbeddings (D/models/embeddings.py:1327-1339).  t_f32 / g_f32: the values
+        the sinusoid sees (already x1000 and bf16-rounded by the caller), one per row; pooled [R, P] bf16."""
+        te = self._lin(ops.silu(self._lin(ops.timestep_embedding(t_f32), "timestep_embedder.1")), "timestep_embedder.2")
+        if self.config.guidance_embeds:
+            if g_f32 is None:
+                raise ValueError("guidance is required when guidance_embeds=True")
+            ge = self._lin(ops.silu(self._lin(ops.timestep_embedding(g_f32), "guidance_embedder.1")),
+                           "guidance_embedder.2")
+            te = ops.add(te, ge)
+        pe = self._lin(ops.silu(self._lin(pooled.contiguous(), "text_embedder.1")), "text_embedder.2")
+        return ops.add(te, pe)
+
+    def modulation(self, temb: torch.Tensor) -> torch.Tensor:
+        """Every norm*.linear(SiLU(temb)) of the model in one GEMM -> [R, mod_len]."""
+        return self._lin(ops.silu(temb), "mod")
+
+    # ------------------------------------------------------------------ sessions / forward
+    def session(self, B: int, S: int, T: int) -> "DitSession":
+        s = self._session
+        if s is None or (s.B, s.S, s.T) != (B, S, T):
+            s = self._session = DitSession(self, B, S, T)
+        return s
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
+                pooled_projections: torch.Tensor = None, timestep: torch.Tensor = None, img_ids: torch.Tensor = None,
+                txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
+                joint_attention_kwargs: Optional[Dict[str, Any]] = None, controlnet_block_samples=None,
+                controlnet_single_block_samples=None, return_dict: bool = True, controlnet_blocks_repeat: bool = False):
+        """Same contract as the reference forward (transformer_flux.py:1028-1212): returns (sample,) when
+        return_dict=False, else an object with `.sample`."""
+        if controlnet_block_samples is not None or controlnet_single_block_samples is not None:
+            raise NotImplementedError("ControlNet residuals are outside the TextFlux hot path (SURVEY.md §2.2)")
+        if not self.w:
+            raise RuntimeError("weights not loaded")
+        dev = self.device
+        hs = hidden_states.to(dev, BF16)
+        B, S, _ = hs.shape
+        T = encoder_hidden_states.shape[1]
+        if txt_ids.ndim == 3:
+            txt_ids = txt_ids[0]
+        if img_ids.ndim == 3:
+            img_ids = img_ids[0]
+        ses = self.session(B, S, T)
+        ses.set_conditioning(encoder_hidden_states.to(dev, BF16), txt_ids, img_ids)
+        # timestep.to(dtype) * 1000 and guidance.to(dtype) * 1000 in the model dtype (transformer_flux.py:1088-1090)
+        t = (timestep.to(dev, BF16) * 1000).float().expand(B)
+        g = (guidance.to(dev, BF16) * 1000).float().expand(B) if guidance is not None else None
+        mod = self.modulation(self.temb(t, g, pooled_projections.to(dev, BF16)))
+        ses.xin.copy_(hs)
+        out = ses.run(mod).clone()
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)
+
+    __call__ = forward
+
+
+class DitSession:
+    """Device workspace + C descriptor for one (B, S, T) problem size."""
+
+    def __init__(self, model: FluxTransformer2DModel, B: int, S: int, T: int):
+        self.model, self.B, self.S, self.T = model, B, S, T
+        c, D, dev = model.config, model.inner_dim, model.device
+        N = S + T
+        self.N = N
+        e = lambda *shape: torch.empty(*shape, dtype=BF16, device=dev)
+        self.xin = e(B, S, c.in_channels)
+        self.ctx0 = e(B, T, D)
+        self.hid, self.xn, self.y = e(B, N, D), e(B, N, D), e(B, N, 7 * D)
+        self.out = e(B, S, model.out_channels)
+        self.cos = self.sin = None
+        self._ids_key = None
+        w = model.w
+
+        def lin(name):
+            return L.Linear(w[name + ".w"].data_ptr(), w[name + ".b"].data_ptr())
+
+        self._dbl = (L.DoubleBlock * max(1, c.num_layers))()
+        for i in range(c.num_layers):
+            b = self._dbl[i]
+            for n in ("qkv_img", "qkv_txt", "out_img", "out_txt", "ff1_img", "ff2_img", "ff1_txt", "ff2_txt"):
+                setattr(b, n, lin(f"d{i}.{n}"))
+            for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                setattr(b, n, w[f"d{i}.{n}"].data_ptr())
+        self._sgl = (L.SingleBlock * max(1, c.num_single_layers))()
+        for j in range(c.num_single_layers):
+            b = self._sgl[j]
+            b.qkv_mlp, b.proj_out = lin(f"s{j}.qkv_mlp"), lin(f"s{j}.proj_out")
+            b.norm_q, b.norm_k = w[f"s{j}.norm_q"].data_ptr(), w[f"s{j}.norm_k"].data_ptr()
+        d = self.desc = L.DitDesc()
+        d.D, d.H, d.in_channels, d.out_channels = D, c.num_attention_heads, c.in_channels, model.out_channels
+        d.n_double, d.n_single = c.num_layers, c.num_single_layers
+        d.B, d.S, d.T = B, S, T
+        d.x_embedder, d.proj_out = lin("x_embedder"), lin("proj_out")
+        d.dbl, d.sgl = self._dbl, self._sgl
+        d.xin, d.ctx0 = self.xin.data_ptr(), self.ctx0.data_ptr()
+        d.hid, d.xn, d.y, d.out = self.hid.data_ptr(), self.xn.data_ptr(), self.y.data_ptr(), self.out.data_ptr()
+        d.first_block, d.last_block, d.flags = 0, -1, 0
+
+    def set_conditioning(self, prompt_embeds: torch.Tensor, txt_ids: torch.Tensor, img_ids: torch.Tensor) -> None:
+        """context_embedder(prompt_embeds) -> ctx0; RoPE tables for cat(txt_ids, img_ids)."""
+        m = self.model
+        assert prompt_embeds.shape[:2] == (self.B, self.T)
+        ops.gemm(prompt_embeds.contiguous(), m.w["context_embedder.w"], m.w["context_embedder.b"], out=self.ctx0)
+        ids = torch.cat((txt_ids.detach().float().cpu(), img_ids.detach().float().cpu()), dim=0)
+        key = (ids.shape, float(ids.sum()), float((ids * torch.arange(1, 4)).sum()))
+        if key != self._ids_key:
+            cos, sin = rope_tables(ids, m.config.axes_dims_rope)
+            self.cos, self.sin = cos.to(m.device), sin.to(m.device)
+            self._ids_key = key
+            self.desc.cos_tab, self.desc.sin_tab = self.cos.data_ptr(), self.sin.data_ptr()
+
+    def run(self, mod: torch.Tensor, first_block: int = 0, last_block: int = -1, flags: int = 0) -> torch.Tensor:
+        """One transformer forward with modulation rows `mod` [B, mod_len] (a view into a table is fine).
+        first_block/last_block/flags: partial runs for block-level tests (see tfx_dit_desc)."""
+        assert mod.shape == (self.B, self.model.mod_len) and mod.stride(1) == 1 and self.cos is not None
+        self._mod_keepalive = mod
+        d = self.desc
+        d.mod, d.mod_bstride = mod.data_ptr(), mod.stride(0)
+        d.first_block, d.last_block, d.flags = first_block, last_block, flags
+        L.check(L.lib().tfx_dit_forward(C.byref(d), ops._stream()), "dit_forward")
+        return self.out
