@@ -160,3 +160,34 @@ def driver_geometry(scene_w: int, scene_h: int, multiline: bool, strip_ratio: fl
     else:
         crop = (0, int(ph * (strip / (scene_h + strip))), pw, ph)
     return dict(concat=(cw, ch), pipe=(pw, ph), S=(ph // 16) * (pw // 16), crop=crop, direction=direction, strip=strip)
+
+
+# --------------------------------------------------------------------------- full Fill pipeline (image + mask in)
+def fill_pipeline(sd, cfg, vae_sd, vae_cfg, image: Tensor, mask: Tensor, prompt_embeds: Tensor, pooled: Tensor,
+                  lat_noise: Tensor, post_eps: Tensor, num_inference_steps: int, guidance_scale: float,
+                  scheduler: str = "euler", amo_noise=None, output_type: str = "np"):
+    """FluxFillPipeline.__call__ with tensor image [B,3,H,W] in [0,1] and mask [B,1,H,W] (P:1963-2137), the two RNG
+    draws injected (lat_noise: prepare_latents P:1825; post_eps: posterior sample P:1528, in that order -- SURVEY
+    Appendix E).  Preprocess = VaeImageProcessor on tensors: normalize to [-1,1]; mask binarize at 0.5
+    (D/image_processor.py:535-536, 700-716)."""
+    from . import vae_oracle as vo
+    dtype = prompt_embeds.dtype
+    B, _, H, W = image.shape
+    latents = pack_latents(lat_noise.to(dtype))
+    img = 2.0 * image - 1.0
+    m = mask.clone()
+    m[m < 0.5] = 0
+    m[m >= 0.5] = 1
+    masked = (img * (1 - m)).to(dtype)
+    mean, std = vo.encode_moments(masked, vae_sd, vae_cfg)
+    z = vo.sample_posterior(mean, std, post_eps.to(dtype))
+    mil = masked_image_latents_from(z, m, vae_cfg.shift_factor, vae_cfg.scaling_factor, dtype)
+    h2, w2 = H // 16, W // 16
+    final, traj = denoise(sd, cfg, latents, mil, prompt_embeds, pooled, h2, w2, num_inference_steps, guidance_scale,
+                          scheduler, amo_noise)
+    if output_type == "latent":
+        return final
+    zz = unpack_latents(final, H, W) / vae_cfg.scaling_factor + vae_cfg.shift_factor
+    dec = vo.decoder(zz, vae_sd, vae_cfg)
+    out = (dec / 2 + 0.5).clamp(0, 1)
+    return out.cpu().permute(0, 2, 3, 1).float()

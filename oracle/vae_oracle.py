@@ -1,0 +1,173 @@
+"""CPU restatement of the FLUX AutoencoderKL (the two ends of the hot path).  TEST INFRASTRUCTURE.
+
+Citations (D = /root/reference/diffusers/src/diffusers): AutoencoderKL.encode/decode
+D/models/autoencoders/autoencoder_kl.py:263-332; Encoder / Decoder / DiagonalGaussianDistribution
+D/models/autoencoders/vae.py:60-195, 198-360, 780-833; ResnetBlock2D D/models/resnet.py:320-373;
+UNetMidBlock2D D/models/unets/unet_2d_blocks.py:589-741 with AttnProcessor2_0 D/models/attention_processor.py:2799-2881;
+Downsample2D D/models/downsampling.py:132-150 (pad (0,1,0,1), stride 2); Upsample2D D/models/upsampling.py:142-192
+(nearest x2 then conv).  Weights: flat dict with the reference's state-dict key names.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+@dataclass(frozen=True)
+class VaeConfig:
+    in_channels: int = 3
+    out_channels: int = 3
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    latent_channels: int = 16
+    norm_num_groups: int = 32
+    scaling_factor: float = 0.3611
+    shift_factor: float = 0.1159
+
+
+def _conv(x, sd, name, stride=1, padding=1):
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=stride, padding=padding)
+
+
+def _gn(x, sd, name, groups):
+    return F.group_norm(x, groups, sd[name + ".weight"], sd[name + ".bias"], eps=1e-6)
+
+
+def resnet(x: Tensor, sd: SD, p: str, groups: int) -> Tensor:
+    h = _conv(F.silu(_gn(x, sd, p + ".norm1", groups)), sd, p + ".conv1")
+    h = _conv(F.silu(_gn(h, sd, p + ".norm2", groups)), sd, p + ".conv2")
+    if p + ".conv_shortcut.weight" in sd:
+        x = _conv(x, sd, p + ".conv_shortcut", padding=0)
+    return x + h
+
+
+def mid_attention(x: Tensor, sd: SD, p: str, groups: int) -> Tensor:
+    B, C, H, W = x.shape
+    res = x
+    h = x.view(B, C, H * W).transpose(1, 2)
+    h = F.group_norm(h.transpose(1, 2), groups, sd[p + ".group_norm.weight"], sd[p + ".group_norm.bias"], eps=1e-6).transpose(1, 2)
+    q = F.linear(h, sd[p + ".to_q.weight"], sd[p + ".to_q.bias"])
+    k = F.linear(h, sd[p + ".to_k.weight"], sd[p + ".to_k.bias"])
+    v = F.linear(h, sd[p + ".to_v.weight"], sd[p + ".to_v.bias"])
+    o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]  # one head of dim C
+    o = F.linear(o.to(q.dtype), sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+    return o.transpose(-1, -2).reshape(B, C, H, W) + res
+
+
+def mid_block(x, sd, p, groups):
+    x = resnet(x, sd, p + ".resnets.0", groups)
+    x = mid_attention(x, sd, p + ".attentions.0", groups)
+    return resnet(x, sd, p + ".resnets.1", groups)
+
+
+def encoder(x: Tensor, sd: SD, cfg: VaeConfig) -> Tensor:
+    g = cfg.norm_num_groups
+    h = _conv(x, sd, "encoder.conv_in")
+    n = len(cfg.block_out_channels)
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            h = resnet(h, sd, f"encoder.down_blocks.{i}.resnets.{j}", g)
+        if i != n - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = _conv(h, sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, padding=0)
+    h = mid_block(h, sd, "encoder.mid_block", g)
+    return _conv(F.silu(_gn(h, sd, "encoder.conv_norm_out", g)), sd, "encoder.conv_out")
+
+
+def decoder(z: Tensor, sd: SD, cfg: VaeConfig) -> Tensor:
+    g = cfg.norm_num_groups
+    h = _conv(z, sd, "decoder.conv_in")
+    h = mid_block(h, sd, "decoder.mid_block", g)
+    n = len(cfg.block_out_channels)
+    for i in range(n):
+        for j in range(cfg.layers_per_block + 1):
+            h = resnet(h, sd, f"decoder.up_blocks.{i}.resnets.{j}", g)
+        if i != n - 1:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = _conv(h, sd, f"decoder.up_blocks.{i}.upsamplers.0.conv")
+    return _conv(F.silu(_gn(h, sd, "decoder.conv_norm_out", g)), sd, "decoder.conv_out")
+
+
+def encode_moments(x: Tensor, sd: SD, cfg: VaeConfig) -> Tuple[Tensor, Tensor]:
+    """mean, std of the posterior (DiagonalGaussianDistribution.__init__, vae.py:781-793)."""
+    mean, logvar = torch.chunk(encoder(x, sd, cfg), 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    return mean, torch.exp(0.5 * logvar)
+
+
+def sample_posterior(mean: Tensor, std: Tensor, eps: Tensor) -> Tensor:
+    """DiagonalGaussianDistribution.sample (vae.py:795-802) with the drawn noise given explicitly."""
+    return mean + std * eps
+
+
+def state_dict_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, o, i, k=3):
+        out[name + ".weight"] = (o, i, k, k)
+        out[name + ".bias"] = (o,)
+
+    def norm(name, c):
+        out[name + ".weight"] = (c,)
+        out[name + ".bias"] = (c,)
+
+    def res(p, i, o):
+        norm(p + ".norm1", i); conv(p + ".conv1", o, i); norm(p + ".norm2", o); conv(p + ".conv2", o, o)
+        if i != o:
+            conv(p + ".conv_shortcut", o, i, 1)
+
+    def mid(p, c):
+        for w in ("group_norm",):
+            norm(f"{p}.attentions.0.{w}", c)
+        for w in ("to_q", "to_k", "to_v", "to_out.0"):
+            out[f"{p}.attentions.0.{w}.weight"] = (c, c)
+            out[f"{p}.attentions.0.{w}.bias"] = (c,)
+        res(p + ".resnets.0", c, c); res(p + ".resnets.1", c, c)
+
+    boc = cfg.block_out_channels
+    conv("encoder.conv_in", boc[0], cfg.in_channels)
+    oc = boc[0]
+    for i, c in enumerate(boc):
+        ic, oc = oc, c
+        for j in range(cfg.layers_per_block):
+            res(f"encoder.down_blocks.{i}.resnets.{j}", ic if j == 0 else oc, oc)
+        if i != len(boc) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", oc, oc)
+    mid("encoder.mid_block", boc[-1])
+    norm("encoder.conv_norm_out", boc[-1])
+    conv("encoder.conv_out", 2 * cfg.latent_channels, boc[-1])
+    rev = list(reversed(boc))
+    conv("decoder.conv_in", rev[0], cfg.latent_channels)
+    oc = rev[0]
+    for i, c in enumerate(rev):
+        ic, oc = oc, c
+        for j in range(cfg.layers_per_block + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", ic if j == 0 else oc, oc)
+        if i != len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", oc, oc)
+    mid("decoder.mid_block", rev[0])
+    norm("decoder.conv_norm_out", boc[0])
+    conv("decoder.conv_out", cfg.out_channels, boc[0])
+    return out
+
+
+def seeded_state_dict(cfg: VaeConfig, seed: int = 0, dtype=torch.float32) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+    for k, shape in sorted(state_dict_shapes(cfg).items()):
+        r = torch.randn(shape, generator=g)
+        if "norm" in k and k.endswith(".weight"):
+            t = 1.0 + 0.1 * r
+        elif k.endswith(".bias"):
+            t = 0.05 * r
+        else:
+            fan_in = shape[1] * (shape[2] * shape[3] if len(shape) == 4 else 1)
+            t = r / (fan_in ** 0.5)
+        sd[k] = t.to(dtype)
+    return sd

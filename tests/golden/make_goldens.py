@@ -312,8 +312,67 @@ def g6_g7():
     save("g6_layout", out)
 
 
+# ----------------------------------------------------------------------------- G9 VAE + VAE-inclusive pipeline
+G9_VAE = dict(block_out_channels=(8, 16, 16, 16), layers_per_block=1, latent_channels=16, norm_num_groups=4)
+
+
+def g9_vae():
+    from diffusers import AutoencoderKL
+    from oracle import vae_oracle as vo
+    out = {}
+    cfg = vo.VaeConfig(**G9_VAE)
+    vae = AutoencoderKL(in_channels=3, out_channels=3, block_out_channels=cfg.block_out_channels,
+                        layers_per_block=cfg.layers_per_block, down_block_types=("DownEncoderBlock2D",) * 4,
+                        up_block_types=("UpDecoderBlock2D",) * 4, latent_channels=16, norm_num_groups=4,
+                        use_quant_conv=False, use_post_quant_conv=False, shift_factor=0.1159, scaling_factor=0.3611)
+    sd = vo.seeded_state_dict(cfg, 900)
+    assert sorted(vae.state_dict().keys()) == sorted(sd.keys()), "oracle VAE keys != reference keys"
+    vae.load_state_dict(sd, strict=True)
+    vae.eval()
+    x = rnd((2, 3, 64, 96), 901).clamp(-1, 1)
+    out["x"] = x
+    post = vae.encode(x).latent_dist
+    out["enc.mean"], out["enc.std"] = post.mean, post.std
+    gen = torch.Generator().manual_seed(77)
+    st = gen.get_state()
+    eps = torch.randn(post.mean.shape, generator=gen)
+    gen.set_state(st)
+    out["enc.eps"] = eps
+    out["enc.sample"] = post.sample(generator=gen)
+    z = rnd((2, 16, 8, 12), 902)
+    out["z"] = z
+    out["dec.out"] = vae.decode(z, return_dict=False)[0]
+    # VAE-inclusive FluxFillPipeline.__call__: image + mask in, np image out (fp32, Euler, 3 steps)
+    m, _ = ref_model(G3_CFG, 7)
+    sch = FlowMatchEulerDiscreteScheduler(use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15,
+                                          base_image_seq_len=256, max_image_seq_len=4096, shift=3.0)
+    pipe = FluxFillPipeline(scheduler=sch, vae=vae, text_encoder=None, tokenizer=None, text_encoder_2=None,
+                            tokenizer_2=None, transformer=m)
+    pipe.set_progress_bar_config(disable=True)
+    H = W = 128
+    image = (rnd((2, 3, H, W), 903) * 0.3 + 0.5).clamp(0, 1)
+    mask = torch.zeros(2, 1, H, W)
+    mask[:, :, 32:96, 16:112] = 1.0
+    pe, pooled = rnd((2, 16, 64), 904), rnd((2, 32), 905)
+    gen = torch.Generator().manual_seed(4242)
+    st = gen.get_state()
+    lat_noise = torch.randn((2, 16, 16, 16), generator=gen)      # 1st draw: prepare_latents (pipeline :1825)
+    post_eps = torch.randn((2, 16, 16, 16), generator=gen)       # 2nd draw: posterior sample (:1528)
+    gen.set_state(st)
+    res = pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, image=image, mask_image=mask, height=H, width=W,
+               num_inference_steps=3, guidance_scale=30.0, generator=gen, output_type="np").images
+    out["pipe.image"], out["pipe.mask"], out["pipe.prompt_embeds"], out["pipe.pooled"] = image, mask, pe, pooled
+    out["pipe.lat_noise"], out["pipe.post_eps"] = lat_noise, post_eps
+    out["pipe.out_np"] = torch.from_numpy(res)
+    gen.set_state(st)
+    out["pipe.out_latent"] = pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, image=image, mask_image=mask, height=H,
+                                  width=W, num_inference_steps=3, guidance_scale=30.0, generator=gen,
+                                  output_type="latent").images
+    save("g9_vae", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
-    fns = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_sched, g5=g5_pipeline, g6=g6_g7)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g9"]
+    fns = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_sched, g5=g5_pipeline, g6=g6_g7, g9=g9_vae)
     for w in which:
         fns[w]()

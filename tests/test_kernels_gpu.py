@@ -131,7 +131,7 @@ def test_ln_modulate_matches_bf16_oracle(ops, D):
     got = ops.ln_modulate(x.cuda(), shift.cuda(), scale.cuda()).cpu()
     # identical rounding chain; the only freedom is the fp32 summation order of mean/var -> allow 1 bf16 ulp rarely
     diff = (got.float() - ref.float()).abs()
-    ulp = ref.float().abs() * 2 ** -7 + 1e-3
+    ulp = ref.float().abs() * 2 ** -7 + 4e-3   # 1 bf16 ulp of the value (+ 1 ulp of an O(0.5) intermediate near zero)
     assert (diff <= ulp).all()
     assert (diff > 0).float().mean().item() < 0.02
 
@@ -158,7 +158,7 @@ def test_rmsnorm_rope_matches_bf16_oracle(ops, golden):
     rk = ref(k, wak, wk).transpose(1, 2).reshape(B, N, -1)
     for gt, rf in ((got[:, :, 2 * H * 128:], rq), (got[:, :, :H * 128], rk)):
         diff = (gt.float() - rf.float()).abs()
-        assert (diff <= rf.float().abs() * 2 ** -7 + 1e-3).all()
+        assert (diff <= rf.float().abs() * 2 ** -7 + 4e-3).all()
         assert (diff > 0).float().mean().item() < 0.02
     assert got[:, :, H * 128:2 * H * 128].abs().max().item() == 0  # v columns untouched
 
@@ -169,9 +169,13 @@ def test_scheduler_steps_bitexact_vs_reference_trajectories(ops, golden):
     mu = so.calculate_shift(S, 256, 4096, 0.5, 1.15)
     lin = so.pipeline_sigmas(n)
     es, as_ = so.euler_sigmas(lin, mu), so.amo_sigmas(lin, mu)
-    ecoef = (es[1:] - es[:-1]).cuda()
+    # the reference multiplies the bf16 model output by a 0-dim f32 tensor: TensorIterator casts that scalar to the
+    # common dtype (bf16) first, so the Euler dsigma and the AMO (t_over - t) are bf16-rounded (a, b stay f32)
+    ecoef = (es[1:] - es[:-1]).to(BF).float().cuda()
     acoef = torch.tensor([so.amo_coefficients(as_[i].item(), as_[i + 1].item(), 2.0) for i in range(n)],
-                         dtype=torch.float32).cuda()
+                         dtype=torch.float32)
+    acoef[:, 0] = acoef[:, 0].to(BF).float()
+    acoef = acoef.cuda()
     x = g["traj.x0"].to(BF).cuda()
     xin = torch.zeros(2, 16, 96, dtype=BF, device="cuda")
     for i in range(n):

@@ -208,3 +208,32 @@ def test_prompt_strings():
     p = po.generate_prompt(["陕西", "ab"])
     assert "with the words '陕西', 'ab';" in p and "text content '陕西', 'ab' naturally" in p
     assert po.PROMPT_TEMPLATE2.count("[IMAGE1]") == 1 and "with the words;" in po.PROMPT_TEMPLATE2
+
+
+# ----------------------------------------------------------------------------- G9 VAE and the VAE-inclusive pipeline
+G9_VAE = dict(block_out_channels=(8, 16, 16, 16), layers_per_block=1, latent_channels=16, norm_num_groups=4)
+
+
+def test_vae_encode_decode(golden):
+    from oracle import vae_oracle as vo
+    g = golden("g9_vae")
+    cfg = vo.VaeConfig(**G9_VAE)
+    sd = vo.seeded_state_dict(cfg, 900)
+    mean, std = vo.encode_moments(g["x"], sd, cfg)
+    assert maxdiff(mean, g["enc.mean"]) <= 2e-5 and maxdiff(std, g["enc.std"]) <= 2e-5
+    assert maxdiff(vo.sample_posterior(mean, std, g["enc.eps"]), g["enc.sample"]) <= 2e-5
+    assert maxdiff(vo.decoder(g["z"], sd, cfg), g["dec.out"]) <= 5e-5
+
+
+def test_fill_pipeline_with_vae(golden):
+    from oracle import vae_oracle as vo
+    g = golden("g9_vae")
+    vcfg = vo.VaeConfig(**G9_VAE)
+    vsd = vo.seeded_state_dict(vcfg, 900)
+    sd = fo.seeded_state_dict(G3_CFG, 7)
+    kw = dict(image=g["pipe.image"], mask=g["pipe.mask"], prompt_embeds=g["pipe.prompt_embeds"], pooled=g["pipe.pooled"],
+              lat_noise=g["pipe.lat_noise"], post_eps=g["pipe.post_eps"], num_inference_steps=3, guidance_scale=30.0)
+    lat = po.fill_pipeline(sd, G3_CFG, vsd, vcfg, output_type="latent", **kw)
+    assert maxdiff(lat, g["pipe.out_latent"]) <= 1e-4
+    img = po.fill_pipeline(sd, G3_CFG, vsd, vcfg, output_type="np", **kw)
+    assert img.shape == g["pipe.out_np"].shape and maxdiff(img, g["pipe.out_np"]) <= 1e-4

