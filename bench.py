@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of FluxFillPipeline.__call__ at 1024x1024, 30 Euler steps, bf16, batch 8 per GPU
+(BASELINE.json metric; FLUX.1-Fill architecture, random-init weights, synthetic image/mask, injected prompt embeds).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one full pipeline call on one batch: VAE encode of the masked image, 30 denoising steps of the 12 B-param
+DiT (hand-written HIP: MFMA GEMMs, flash attention, fused norms / scheduler), VAE decode.  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line (contract in the task description), carrying
+  roofline     : MFMA roofline of the dominant kernel (gemm8p), measured live with HIP events on its launch stream
+  cpu_baseline : the CPU oracle (plain PyTorch restatement, `oracle/`) timed on this box's host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+D, T_TXT = 3072, 512
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def dit_flops(S: int) -> float:
+    """Algorithmic FLOPs of one transformer forward for one image."""
+    N = S + T_TXT
+    return 57 * (24 * D * D * N + 4 * N * N * D) + 2 * (384 * D * S + 4096 * D * T_TXT + 64 * D * S)
+
+
+def cpu_baseline(height, width, steps, budget_s=25.0):
+    """Oracle double + single block (full width, fp32) at this workload's token count, timed on the host cores and
+    extrapolated: s/img = steps * (19 t_double + 38 t_single).  A reported baseline, not a target."""
+    from oracle import flux_oracle as fo
+    from oracle import pipeline_oracle as po
+    S = (height // 16) * (width // 16)
+    torch.set_num_threads(os.cpu_count())
+    cfg = fo.FluxConfig(num_layers=1, num_single_layers=1)
+    g = torch.Generator().manual_seed(0)
+    sd = {k: torch.randn(s, generator=g) * 0.02 for k, s in fo.state_dict_shapes(cfg).items()
+          if k.startswith(("transformer_blocks.0", "single_transformer_blocks.0"))}
+    hidden, enc, temb = torch.randn(1, S, D, generator=g), torch.randn(1, T_TXT, D, generator=g), torch.randn(1, D, generator=g)
+    ids = torch.cat([torch.zeros(T_TXT, 3), po.latent_image_ids(height // 16, width // 16)], 0)
+    cos, sin = fo.flux_pos_embed(ids)
+    t0 = time.time()
+    with torch.no_grad():
+        fo.double_block(sd, "transformer_blocks.0", 24, hidden, enc, temb, cos, sin)  # warm-up (thread pool, allocs)
+        t1 = time.time()
+        fo.double_block(sd, "transformer_blocks.0", 24, hidden, enc, temb, cos, sin)
+        t_d = time.time() - t1
+        joint = torch.cat([enc, hidden], 1)
+        t2 = time.time()
+        fo.single_block(sd, "single_transformer_blocks.0", 24, joint, temb, cos, sin)
+        t_s = time.time() - t2
+    s_img = steps * (19 * t_d + 38 * t_s)
+    return {"value": 1.0 / s_img, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle/flux_oracle.py fp32: 1 double block ({t_d:.2f} s) + 1 single block ({t_s:.2f} s) at full "
+                      f"width (D=3072, N={S + T_TXT}, B=1) timed once after warm-up on {os.cpu_count()} threads; "
+                      f"extrapolated s/img = {steps} x (19 t_d + 38 t_s) = {s_img:.0f} s (VAE/text encoders excluded); "
+                      f"sample wall {time.time() - t0:.0f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per pipeline call")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--denoise-steps", type=int, default=30)
+    ap.add_argument("--sampler", choices=["euler", "amo"], default="euler")
+    ap.add_argument("--layers", type=int, nargs=2, default=[19, 38], help=argparse.SUPPRESS)  # debugging only
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from textflux_amd import distributed as tdist
+    from textflux_amd import ops
+    from textflux_amd.pipeline import FluxFillPipeline
+    from textflux_amd.schedulers import FlowMatchEulerDiscreteScheduler, StochasticRFOvershotDiscreteScheduler
+    from textflux_amd.transformer import FluxTransformer2DModel
+    from textflux_amd.vae import AutoencoderKL
+
+    rank, world, local = tdist.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    dev = torch.device("cuda", local)
+    B, H, W, n = a.batch, a.height, a.width, a.denoise_steps
+    S = (H // 16) * (W // 16)
+    full = a.layers == [19, 38]
+
+    # ---- model: FLUX.1-Fill architecture, random-init on the device (no checkpoints offline; throughput does not depend on values)
+    tr = FluxTransformer2DModel(in_channels=384, out_channels=64, num_layers=a.layers[0], num_single_layers=a.layers[1],
+                                guidance_embeds=True).init_random_(seed=1234 + rank, device=dev)
+    vae = AutoencoderKL().init_random_(seed=7, device=dev)
+    sched_cfg = dict(use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15, base_image_seq_len=256,
+                     max_image_seq_len=4096, shift=3.0)
+    if a.sampler == "euler":
+        sch = FlowMatchEulerDiscreteScheduler(**sched_cfg)
+    else:
+        sch = StochasticRFOvershotDiscreteScheduler(**sched_cfg)
+        sch.set_c(2.0)
+        sch.set_overshot_func(lambda t, dt: t + dt)
+    pipe = FluxFillPipeline(scheduler=sch, vae=vae, text_encoder=None, tokenizer=None, text_encoder_2=None,
+                            tokenizer_2=None, transformer=tr)
+    pipe.set_progress_bar_config(disable=True)
+
+    # ---- synthetic inputs, resident in HBM.  Conditioning is produced on rank 0 and broadcast over RCCL/xGMI
+    g = torch.Generator().manual_seed(42)
+    pe = pooled = None
+    if rank == 0:
+        pe = (torch.randn(1, T_TXT, 4096, generator=g) * 0.1).to(torch.bfloat16)
+        pooled = torch.randn(1, 768, generator=g).to(torch.bfloat16)
+    pe, pooled = tdist.broadcast_conditioning(pe, pooled, (1, T_TXT, 4096), (1, 768), torch.bfloat16, dev)
+    pe, pooled = pe.expand(B, -1, -1).contiguous(), pooled.expand(B, -1).contiguous()
+    gi = torch.Generator().manual_seed(100 + rank)
+    image = torch.rand(B, 3, H, W, generator=gi).to(dev)
+    mask = torch.zeros(B, 1, H, W, device=dev)
+    mask[:, :, H // 4: 3 * H // 4, W // 8: 7 * W // 8] = 1.0
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+
+    def one_call():
+        return pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, image=image, mask_image=mask, height=H, width=W,
+                    num_inference_steps=n, guidance_scale=30.0, generator=gen, output_type="pt").images
+
+    for _ in range(a.warmup):
+        one_call()
+    torch.cuda.synchronize()
+    tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        if k == a.steps - 1 and rank == 0:
+            ops.prof_enable(True)   # per-launch HIP events on the GEMM / attention launches of the last timed call
+        out = one_call()
+    torch.cuda.synchronize()
+    tdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = tdist.max_over_ranks(time.perf_counter() - t0, dev)
+    ops.prof_enable(False)
+
+    if rank == 0:
+        gemm_ms, gemm_fl, gemm_n = ops.prof_collect(0)
+        att_ms, att_fl, att_n = ops.prof_collect(1)
+        total_images = world * B * a.steps
+        ips = total_images / elapsed
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        rec = {
+            "metric": "images/sec (whole node), 1024x1024 30-step FLUX-Fill" if (H, W, n) == (1024, 1024, 30) else
+                      f"images/sec (whole node), {H}x{W} {n}-step FLUX-Fill",
+            "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (random-init FLUX.1-Fill-architecture weights, random image, box mask, "
+                                     "injected random prompt embeddings; text encoders bypassed)",
+            "config": {"workload": f"P1024: FluxFillPipeline.__call__ {H}x{W}, {n} {a.sampler} steps, guidance 30, "
+                                   f"batch {B}/GPU (S={S} image + 512 text tokens), VAE encode+decode included"
+                                   + ("" if full else f" [REDUCED MODEL {a.layers} - not a valid headline]"),
+                       "global_batch": world * B, "parallelism": f"dp{world} (batch shards, conditioning broadcast over RCCL)"},
+            "sec_per_img_per_gpu": elapsed / (B * a.steps),
+            "dit_algorithmic_tflops_per_gpu": dit_flops(S) * n * B * a.steps / elapsed / 1e12 if full else None,
+            "roofline": {"bound": "mfma", "kernel": "tfx::gemm8p_kernel (all epilogues)", "achieved": achieved,
+                         "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                         "traffic": None, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                         "flops_per_launch": gemm_fl / max(gemm_n, 1),
+                         "attention": {"achieved": att_fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0,
+                                       "launches": att_n, "avg_launch_ms": att_ms / max(att_n, 1)}},
+        }
+        rec["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline(H, W, n)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

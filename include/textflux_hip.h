@@ -141,6 +141,13 @@ typedef struct tfx_dit_desc {
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
 
+/* ---- measurement hooks (no reference counterpart: the reference has no profiling) --------------------
+ * When enabled, every MFMA-GEMM (kind 0) / attention (kind 1) launch is bracketed by hipEvents on its own stream and
+ * its algorithmic FLOPs (2*M*N*K*batch, 4*B*H*N^2*128) are recorded; tfx_prof_collect waits for those launches and
+ * returns the summed kernel time, FLOPs and launch count, then clears the records.  Not capturable into a graph. */
+int tfx_prof_enable(int on);
+int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,9 +217,12 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
   }
   const int nqb = (a.N + QBLK - 1) / QBLK;
   const unsigned grid = (unsigned)(a.B * a.H * nqb);
+  const bool prof = prof_on();
+  if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
   attn_kernel<<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
                                           a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
                                           a.N, nqb, a.scale * 1.4426950408889634f);
+  if (prof) prof_end(1, st);
   return check_launch("joint_attention");
 }
 

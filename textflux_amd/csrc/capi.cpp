@@ -228,6 +228,12 @@ int tfx_advance_step(int32_t* step_ptr, tfx_stream stream) {
   return advance_step(step_ptr, S(stream));
 }
 
+int tfx_prof_enable(int on) { prof_enable(on); return 0; }
+int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches) {
+  if (kind < 0 || kind > 1) return fail("tfx_prof_collect: kind must be 0 (gemm) or 1 (attention)");
+  return prof_collect(kind, total_ms, total_flops, launches);
+}
+
 int tfx_dit_forward(const tfx_dit_desc* d, tfx_stream stream) {
   if (!d) return fail("tfx_dit_forward: null descriptor");
   if (!d->xin || !d->mod || !d->hid || !d->xn || !d->y || !d->out || !d->cos_tab || !d->sin_tab)

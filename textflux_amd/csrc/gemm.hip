@@ -377,7 +377,10 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       attr_set = true;
     }
     const unsigned grid = (unsigned)(p.batch * p.tm * p.tn);
+    const bool prof = prof_on();
+    if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
     gemm8p_kernel<EPI><<<grid, 512, LDS_TOTAL, st>>>(p);
+    if (prof) prof_end(0, st);
   } else {
     dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch);
     gemm_generic_kernel<EPI><<<grid, 256, 0, st>>>(p);

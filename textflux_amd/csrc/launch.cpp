@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <vector>
 
 namespace tfx {
 
@@ -23,5 +24,46 @@ int check_launch(const char* what) {
 }
 
 const char* last_error() { return g_err; }
+
+// ---- launch-level profiler ------------------------------------------------------------------------------
+namespace {
+struct Rec { hipEvent_t a, b; double flops; };
+struct Prof {
+  bool on = false;
+  std::vector<Rec> recs[2];
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+  }
+} g_prof;
+}  // namespace
+
+void prof_enable(int on) { g_prof.on = on != 0; }
+bool prof_on() { return g_prof.on; }
+void prof_begin(int kind, double flops, hipStream_t st) {
+  Rec r{g_prof.get(), g_prof.get(), flops};
+  hipEventRecord(r.a, st);
+  g_prof.recs[kind].push_back(r);
+}
+void prof_end(int kind, hipStream_t st) { hipEventRecord(g_prof.recs[kind].back().b, st); }
+int prof_collect(int kind, double* total_ms, double* total_flops, int* launches) {
+  double ms = 0, fl = 0;
+  int n = 0;
+  for (Rec& r : g_prof.recs[kind]) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return fail("prof_collect: event sync failed");
+    float t = 0;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return fail("prof_collect: elapsed time failed");
+    ms += t; fl += r.flops; ++n;
+    g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b);
+  }
+  g_prof.recs[kind].clear();
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = n;
+  return 0;
+}
 
 }  // namespace tfx

@@ -11,6 +11,15 @@ int fail(const char* fmt, ...);
 int check_launch(const char* what);
 const char* last_error();
 
+// Optional per-launch timing of the dominant kernels (bench.py's live roofline measurement): when enabled, the
+// GEMM / attention launchers bracket each launch with hipEvents on the launch stream and account its algorithmic
+// FLOPs.  kind: 0 = gemm8p, 1 = attention.
+void prof_enable(int on);
+bool prof_on();
+void prof_begin(int kind, double flops, hipStream_t st);
+void prof_end(int kind, hipStream_t st);
+int prof_collect(int kind, double* total_ms, double* total_flops, int* launches);
+
 // GEMM epilogues (C = epi(A @ W^T + bias)).
 enum Epilogue : int {
   EPI_BIAS = 0,           // C = acc + bias

@@ -187,3 +187,14 @@ def select_step_(table: torch.Tensor, cur: torch.Tensor, step_ptr: torch.Tensor)
 
 def advance_step_(step_ptr: torch.Tensor) -> None:
     L.check(L.lib().tfx_advance_step(step_ptr.data_ptr(), _stream()), "advance_step")
+
+
+def prof_enable(on: bool) -> None:
+    L.check(L.lib().tfx_prof_enable(1 if on else 0), "prof_enable")
+
+
+def prof_collect(kind: int):
+    """(total kernel ms, total algorithmic FLOPs, launches) of the profiled launches of kind 0 (GEMM) / 1 (attention)."""
+    ms, fl, n = C.c_double(), C.c_double(), C.c_int()
+    L.check(L.lib().tfx_prof_collect(kind, C.byref(ms), C.byref(fl), C.byref(n)), "prof_collect")
+    return ms.value, fl.value, n.value
