@@ -10,14 +10,16 @@
 // other group reads its next fragments from LDS and issues the prefetch of a quarter K-tile that is one and
 // a half K-tiles ahead; waits are counted (vmcnt(6)), never drained, inside the main loop.
 //
-// Schedule (slots = half phases, tile t, phase q in 0..3; group g runs loads(p) at slot 2p-1+g, MFMA(p) at
-// 2p+g).  Each wave keeps X fragments for 64 rows and both 32-column W fragments in registers:
-//   q0: read X_lo, W_lo | q1: read W_hi | q2: read X_hi | q3: no reads.
-// so the last LDS read of tile t is W_lo@q0, W_hi@q1, X_lo@q0, X_hi@q2, and the buffer of tile t (2 sets)
-// is refilled for tile t+2 by:  G1@q2:W_lo(a)  G0@q3:W_lo(b)  G1@q3:X0_lo  G0@q0':X1_lo  G1@q0':W_hi(a)
-// G0@q1':W_hi(b)  G1@q1':X0_hi  G0@q2':X1_hi  (' = next tile).  Every refill is issued >= 2 barriers after
-// the last read of the bytes it overwrites and is waited for (own vmcnt(6) + barrier) >= 1 barrier before
-// its first reader; see DESIGN.md "GEMM schedule" for the slot table.
+// Schedule (slots = half phases; tile t, phase q in 0..3; group g runs loads(p) at slot 2p-1+g and MFMA(p) at
+// slot 2p+g, p = 4t+q).  Each wave keeps X fragments for 64 rows and both 32-column W fragments in registers:
+//   q0: read X_lo, W_lo | q1: read W_hi | q2: read X_hi | q3: no reads,
+// so the last LDS read of tile t is X_lo, W_lo @q0, W_hi @q1, X_hi @q2.  With 2 buffer sets tile t+2 overwrites tile t,
+// one 64-row quarter per slot, each in the first slot where every read of the overwritten bytes has been waited for
+// (own lgkmcnt) and fenced (>= 1 barrier):
+//   slot 8t+1 G0:X0_lo  +2 G1:W_lo_a  +3 G0:W_lo_b  +4 G1:X1_lo  +5 G0:W_hi_a  +6 G1:W_hi_b  +7 G0:X0_hi  +8 G1:X1_hi
+// first readers: X0_lo/W_lo 8t+15, X1_lo 8t+16, W_hi 8t+17, X0_hi 8t+19, X1_hi 8t+20 -> >= 11 slots in flight.
+// A request issued in slot s is waited for by its issuer at the end of its 5th following section (vmcnt(10), 2 loads
+// per section) = slot s+10, then one barrier -> readable from s+11.  See DESIGN.md "GEMM schedule".
 #include "common.h"
 #include "launch.h"
 
@@ -91,7 +93,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
 constexpr int LDS_X = 0;            // X_g set s at g*32768 + s*16384   (128 rows x 128 B)
 constexpr int LDS_W = 65536;        // W   set s at 65536 + s*32768     (256 rows x 128 B)
 constexpr int LDS_DUMMY = 131072;   // 8 x 1 KiB sink for out-of-range prefetches (keeps vmcnt counts uniform)
-constexpr int LDS_TOTAL = 131072 + 8 * 1024;
+constexpr int EPI_ROW_BYTES = 144;                  // 128 B of output columns + 16 B pad (bank spread, 16-B aligned)
+constexpr int EPI_WAVE_BYTES = 128 * EPI_ROW_BYTES;  // epilogue staging: 18 KiB per wave, reuses the operand buffers
+constexpr int LDS_TOTAL = 8 * EPI_WAVE_BYTES;        // 147456 >= 131072 + 8192 (operand sets + sink)
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -107,7 +111,9 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* smem, uint32_t lds
     __builtin_amdgcn_sched_barrier(0);         \
   } while (0)
 
-template <int EPI>
+// ABL (bench-only ablations, never dispatched by the product path): bit0 no prefetch in the main loop, bit1 no LDS
+// fragment reads, bit2 no barriers.  ABL = 0 is the real kernel.
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -135,43 +141,44 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   const int tile_n = idx / gsz;
   const int m0 = tile_m * 256, n0 = tile_n * 256;
 
-  const bf16_t* Xb = p.A + b * p.a_bs + (int64_t)m0 * p.lda;
-  const bf16_t* Wb = p.W + (int64_t)n0 * p.ldw;
+  const bf16_t* Xb = p.A + b * p.a_bs + (int64_t)((ABL & 8) ? 0 : m0) * p.lda;   // ABL bit3: every tile loads panel 0
+  const bf16_t* Wb = p.W + (int64_t)((ABL & 8) ? 0 : n0) * p.ldw;
   const int nt = p.K >> 6;
 
-  // ---- prefetch bookkeeping.  Item table of this wave's group, in phase order q0..q3:
-  //   G0: X1_lo(u+1)  W_hi_b(u+1)  X1_hi(u+1)  W_lo_b(u+2)
-  //   G1: W_hi_a(u+1) X0_hi(u+1)   W_lo_a(u+2) X0_lo(u+2)
-  // Every lane issues 2 x 16-byte loads per item; piece = 8 consecutive LDS rows written by one wave-instr.
+  // ---- prefetch bookkeeping.  Item table of this wave's group, in phase order q0..q3 (u = tile being computed):
+  //   G0: X0_hi(u+1)  X0_lo(u+2)   W_lo_b(u+2)  W_hi_a(u+2)
+  //   G1: X1_hi(u+1)  W_lo_a(u+2)  X1_lo(u+2)   W_hi_b(u+2)
+  // i.e. every 64-row quarter of the tile-(u+2) operands is re-requested in the first slot in which all reads of
+  // the bytes it overwrites are known complete, which leaves each request >= 11 slots (~2800 cycles at full MFMA
+  // rate) before its first reader.  Every lane issues 2 x 16-byte loads per item; piece = 8 consecutive LDS rows
+  // written by one wave instruction.
   const int lr = lane >> 3, cphys = lane & 7;
   int goff[4][2];        // per-lane element offset from Xb / Wb (without the k offset)
   uint32_t ldst[4][2];   // wave-uniform LDS byte offset inside set 0 of the destination tile
   bool isx[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const bool x_item = g == 0 ? (q == 0 || q == 2) : (q == 1 || q == 3);
+    const bool x_item = g == 0 ? (q == 0 || q == 1) : (q == 0 || q == 2);
     isx[q] = x_item;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int pc = wc * 2 + j;  // piece 0..7 (wc doubles as the wave's index inside its group)
       int row0;                   // first tile-local row of the piece
       if (x_item) {
-        const int rb = g == 0 ? (q == 0 ? 0 : 64) : (q == 1 ? 64 : 0);
-        row0 = rb + pc * 8;
+        row0 = (q == 0 ? 64 : 0) + pc * 8;
       } else {
-        const int hi = g == 0 ? (q == 1) : (q == 0);  // W_hi items
-        const int half = g == 0 ? 128 : 0;            // G0 stages the "b" halves (rows 128..255)
-        row0 = half + (pc >> 2) * 64 + hi * 32 + (pc & 3) * 8;
+        const int whi_item = (q == 3);                                   // q3 stages W_hi, q1/q2 stage W_lo
+        const int half = g == 0 ? (q == 2 ? 128 : 0) : (q == 1 ? 0 : 128);  // "a" = stripes 0,1; "b" = stripes 2,3
+        row0 = half + (pc >> 2) * 64 + whi_item * 32 + (pc & 3) * 8;
       }
       const int row = row0 + lr;
       const int key = (row >> 1) & 7;
       const int clog = cphys ^ key;
       if (x_item) {
-        const int h = 1 - g;  // G0 stages X1, G1 stages X0
-        int grow = h * 128 + row;
+        int grow = g * 128 + row;  // each group stages its own half of the X tile
         if (m0 + grow > p.M - 1) grow = p.M - 1 - m0;
         goff[q][j] = grow * (int)p.lda + clog * 8;
-        ldst[q][j] = LDS_X + h * 32768 + row0 * 128;
+        ldst[q][j] = LDS_X + g * 32768 + row0 * 128;
       } else {
         int grow = row;
         if (n0 + grow > p.N - 1) grow = p.N - 1 - n0;
@@ -215,12 +222,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   // during "tile -1" (the (u+2)-type items).
 #pragma unroll
   for (int q = 0; q < 4; ++q) stage(q, 0);
-  if (g == 0) {
-    stage(3, 1);
-  } else {
-    stage(2, 1);
-    stage(3, 1);
-  }
+#pragma unroll
+  for (int q = 1; q < 4; ++q) stage(q, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TFX_BARRIER();
   if (g == 1) TFX_BARRIER();  // stagger: G1 runs one barrier behind G0
@@ -230,6 +233,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
 #define MFMA8(WF, ROWBASE, NJ)                                                                            \
   do {                                                                                                    \
+    if (ABL & 16) {                                                                                       \
+      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
+        asm volatile("" ::"v"(WF[kk]), "v"(xf[0][kk]), "v"(xf[1][kk]));  /* keep the fragment reads live */ \
+      break;                                                                                              \
+    }                                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                                        \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
       acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
@@ -237,47 +245,62 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     }                                                                                                     \
     __builtin_amdgcn_s_setprio(0);                                                                        \
   } while (0)
-#define WAIT_PREFETCH() asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#define WAIT_PREFETCH() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")  // all but the 5 newest sections landed
 
+#define BODY_STAGE(q, t) do { if (!(ABL & 1)) stage(q, t); } while (0)
+#define BODY_BARRIER() do { if (!(ABL & 4)) TFX_BARRIER(); } while (0)
+  if (ABL & 2) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      xf[0][kk] = LDS_FRAG(fx[kk]); xf[1][kk] = LDS_FRAG(fx[kk] + 4096);
+      wlo[kk] = LDS_FRAG(fw[kk]); whi[kk] = LDS_FRAG(fw[kk] + 4096);
+    }
+  }
   auto tile_body = [&](int u, const uint32_t xs, const uint32_t ws) {
     // xs / ws: byte offset of this tile's set inside the X / W regions (0 or 16384 / 32768)
     // ---- q0: X_lo (rows 0..63 of the group's half), W_lo (cols 0..31 of the stripe)
+    if (!(ABL & 2)) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      xf[0][kk] = LDS_FRAG(fx[kk] + xs);
-      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);
-      wlo[kk] = LDS_FRAG(fw[kk] + ws);
+      for (int kk = 0; kk < 4; ++kk) {
+        xf[0][kk] = LDS_FRAG(fx[kk] + xs);
+        xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);
+        wlo[kk] = LDS_FRAG(fw[kk] + ws);
+      }
     }
-    stage(0, u + 1);
+    BODY_STAGE(0, u + 1);
     WAIT_PREFETCH();
-    TFX_BARRIER();
+    BODY_BARRIER();
     MFMA8(wlo, 0, 0);
-    TFX_BARRIER();
+    BODY_BARRIER();
     // ---- q1: W_hi (cols 32..63)
+    if (!(ABL & 2)) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);
-    stage(1, u + 1);
-    WAIT_PREFETCH();
-    TFX_BARRIER();
-    MFMA8(whi, 0, 1);
-    TFX_BARRIER();
-    // ---- q2: X_hi (rows 64..127)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      xf[0][kk] = LDS_FRAG(fx[kk] + xs + 8192);
-      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);
+      for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);
     }
-    stage(2, g == 0 ? u + 1 : u + 2);
+    BODY_STAGE(1, u + 2);
     WAIT_PREFETCH();
-    TFX_BARRIER();
+    BODY_BARRIER();
+    MFMA8(whi, 0, 1);
+    BODY_BARRIER();
+    // ---- q2: X_hi (rows 64..127)
+    if (!(ABL & 2)) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        xf[0][kk] = LDS_FRAG(fx[kk] + xs + 8192);
+        xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);
+      }
+    }
+    BODY_STAGE(2, u + 2);
+    WAIT_PREFETCH();
+    BODY_BARRIER();
     MFMA8(whi, 2, 1);
-    TFX_BARRIER();
+    BODY_BARRIER();
     // ---- q3: no reads
-    stage(3, u + 2);
+    BODY_STAGE(3, u + 2);
     WAIT_PREFETCH();
-    TFX_BARRIER();
+    BODY_BARRIER();
     MFMA8(wlo, 2, 0);
-    TFX_BARRIER();
+    BODY_BARRIER();
   };
 
   for (int u = 0; u < nt; u += 2) {
@@ -288,10 +311,16 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 #undef LDS_FRAG
 #undef MFMA8
 #undef WAIT_PREFETCH
+#undef BODY_STAGE
+#undef BODY_BARRIER
 
-  // ---- epilogue: lane holds, per (mi, nj, quad), 4 consecutive columns of one row:
-  //   m = m0 + g*128 + mi*32 + (lane & 31),  n = n0 + wc*64 + nj*32 + quad*8 + hi*4 + (r & 3)
-  const int mrow = m0 + g * 128 + (lane & 31);
+  // ---- epilogue.  Lane holds, per (mi, nj, quad), 4 consecutive columns of one row:
+  //   m = m0 + g*128 + mi*32 + (lane & 31),  n = n0 + wc*64 + nj*32 + quad*8 + hi*4 + (r & 3).
+  // bias / GELU / gate are applied here in fp32, the bf16 results are transposed through a wave-private LDS
+  // region (128 rows x 144 B, rows padded by 16 B) and leave as 16-byte stores in which 8 lanes cover one full
+  // 128-byte line of a row (16 store instructions per lane instead of 32 row-strided 8-byte ones).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // out-of-range prefetches may still target the sink region
+  char* stg = smem + wave * EPI_WAVE_BYTES;
   const int ncol = n0 + wc * 64 + hi * 4;
   const bool do_gelu = (EPI == EPI_BIAS_GELU) && (n0 >= p.gelu_from);
 #pragma unroll
@@ -299,22 +328,20 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const int n = ncol + nj * 32 + qd * 8;
-      if (n >= p.N) continue;
+      const int nc = n < p.N ? n : 0;  // columns beyond N are computed but never stored
       float bs[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) {
-        const u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n);
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + nc);
         bs[0] = __uint_as_float(raw[0] << 16); bs[1] = __uint_as_float(raw[0] & 0xffff0000u);
         bs[2] = __uint_as_float(raw[1] << 16); bs[3] = __uint_as_float(raw[1] & 0xffff0000u);
       }
       if (EPI == EPI_BIAS_GATE_RES) {
-        const u32x2 raw = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + n);
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + nc);
         gt[0] = __uint_as_float(raw[0] << 16); gt[1] = __uint_as_float(raw[0] & 0xffff0000u);
         gt[2] = __uint_as_float(raw[1] << 16); gt[3] = __uint_as_float(raw[1] & 0xffff0000u);
       }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        const int m = mrow + mi * 32;
-        if (m >= p.M) continue;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][qd * 4 + e] + bs[e];
@@ -323,17 +350,36 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
           for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
         }
         if (EPI == EPI_BIAS_GATE_RES) {
-          const u32x2 raw = *reinterpret_cast<const u32x2*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + n);
-          const float r4[4] = {__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
-                               __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = r4[e] + round_bf(gt[e] * round_bf(v[e]));
+          for (int e = 0; e < 4; ++e) v[e] = gt[e] * round_bf(v[e]);
         }
         u32x2 o;
         o[0] = pack_bf2(v[0], v[1]);
         o[1] = pack_bf2(v[2], v[3]);
-        *reinterpret_cast<u32x2*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + n) = o;
+        *reinterpret_cast<u32x2*>(stg + (mi * 32 + (lane & 31)) * EPI_ROW_BYTES + (nj * 32 + qd * 8 + hi * 4) * 2) = o;
       }
+    }
+  }
+  // wave-private region + in-order LDS pipe: no barrier needed between the writes above and the reads below
+  const int crow = lane >> 3, cchunk = lane & 7;
+  const int nst = n0 + wc * 64 + cchunk * 8;
+  if (nst < p.N) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 8 + crow;
+      const int m = m0 + g * 128 + row;
+      if (m >= p.M) continue;
+      u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * EPI_ROW_BYTES + cchunk * 16);
+      if (EPI == EPI_BIAS_GATE_RES) {
+        const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + nst);
+        float fv[8], fr[8];
+        unpack8(val, fv);
+        unpack8(rr, fr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+        val = pack8(fv);
+      }
+      *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
     }
   }
 }
@@ -354,16 +400,39 @@ static GemmParams make_params(const GemmArgs& a) {
 }
 
 static bool fast_ok(const GemmArgs& a) {
-  const bool al16 = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.C % 8 == 0);
-  return a.K % 64 == 0 && a.K >= 64 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 4 == 0 &&
-         a.a_bstride % 8 == 0 && a.c_bstride % 4 == 0 && al16 && (int64_t)255 * a.lda < (1ll << 31) &&
+  const bool al16 = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.C % 16 == 0) &&
+                    ((uintptr_t)a.bias % 8 == 0);
+  return a.K % 64 == 0 && a.K >= 64 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0 &&
+         a.a_bstride % 8 == 0 && a.c_bstride % 8 == 0 && al16 && (int64_t)255 * a.lda < (1ll << 31) &&
          (int64_t)255 * a.ldw < (1ll << 31) &&
-         (a.epilogue != EPI_BIAS_GATE_RES || (a.ldr % 4 == 0 && a.r_bstride % 4 == 0 && a.gate_bstride % 4 == 0)) &&
+         (a.epilogue != EPI_BIAS_GATE_RES || (a.ldr % 8 == 0 && a.r_bstride % 8 == 0 && a.gate_bstride % 4 == 0 &&
+                                              (uintptr_t)a.res % 16 == 0 && (uintptr_t)a.gate % 8 == 0)) &&
          (a.epilogue != EPI_BIAS_GELU || a.gelu_from_col % 256 == 0);
+}
+
+template <int ABL>
+static int launch_ablation(const GemmParams& p, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)gemm8p_kernel<EPI_BIAS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+  gemm8p_kernel<EPI_BIAS, ABL><<<(unsigned)(p.batch * p.tm * p.tn), 512, LDS_TOTAL, st>>>(p);
+  return check_launch("gemm_ablation");
 }
 
 template <int EPI>
 static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
+  if (variant >= 10) {  // tools/bench_kernels.py only: timing ablations with WRONG results by construction
+    switch (variant - 10) {
+      case 1: return launch_ablation<1>(p, st);
+      case 2: return launch_ablation<2>(p, st);
+      case 3: return launch_ablation<3>(p, st);
+      case 4: return launch_ablation<4>(p, st);
+      case 7: return launch_ablation<7>(p, st);
+      case 8: return launch_ablation<8>(p, st);
+      case 16: return launch_ablation<16>(p, st);
+      case 18: return launch_ablation<18>(p, st);
+      case 17: return launch_ablation<17>(p, st);
+    }
+    return fail("gemm: unknown ablation");
+  }
   if (variant == 1) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -391,7 +460,7 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return 0;
   if (a.K <= 0) return fail("gemm: K must be positive");
-  if (variant == 1 && !fast_ok(a)) return fail("gemm: shape/alignment not supported by the MFMA kernel");
+  if (variant >= 1 && !fast_ok(a)) return fail("gemm: shape/alignment not supported by the MFMA kernel");
   if (a.epilogue == EPI_BIAS_GATE_RES && (!a.gate || !a.res)) return fail("gemm: gate/res pointers required");
   const GemmParams p = make_params(a);
   switch (a.epilogue) {
