@@ -16,6 +16,10 @@ import os
 import sys
 import time
 
+# MIOpen (VAE convolutions, torch ops this round): use the find-db / heuristic "fast" find mode instead of benchmarking
+# every solver (incl. the naive one) on first use -- that exhaustive search cost minutes of warm-up per process.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -148,6 +152,16 @@ def main():
         total_images = world * B * a.steps
         ips = total_images / elapsed
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic, traffic_note = None, None
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (bench.py cannot collect PMCs itself)
+            with open(os.path.join(REPO, "profiles", "r01_gemm_pmc_traffic.json")) as f:
+                pm = json.load(f)["shapes"][0]
+            traffic = pm["hbm_bytes_per_launch"]
+            traffic_note = (f"PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the most expensive shape "
+                            f"M={pm['M']} N={pm['N']} K={pm['K']} (algorithmic bytes {pm['algorithmic_bytes']}); "
+                            f"profiles/r01_gemm_pmc_traffic.json")
+        except Exception:
+            pass
         rec = {
             "metric": "images/sec (whole node), 1024x1024 30-step FLUX-Fill" if (H, W, n) == (1024, 1024, 30) else
                       f"images/sec (whole node), {H}x{W} {n}-step FLUX-Fill",
@@ -163,7 +177,7 @@ def main():
             "dit_algorithmic_tflops_per_gpu": dit_flops(S) * n * B * a.steps / elapsed / 1e12 if full else None,
             "roofline": {"bound": "mfma", "kernel": "tfx::gemm8p_kernel (all epilogues)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                         "traffic": None, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                         "traffic": traffic, "traffic_note": traffic_note, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "flops_per_launch": gemm_fl / max(gemm_n, 1),
                          "attention": {"achieved": att_fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0,
                                        "launches": att_n, "avg_launch_ms": att_ms / max(att_n, 1)}},

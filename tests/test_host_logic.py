@@ -1,0 +1,159 @@
+"""CPU tests of the host-side logic of the product package (no GPU, no kernels): scheduler tables vs the reference
+goldens, coefficient tables, pipeline helpers, input validation, image processor, driver geometry / prompts."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from textflux_amd import glyph
+from textflux_amd.image_processor import VaeImageProcessor
+from textflux_amd.pipeline import FluxFillPipeline, calculate_shift, randn_tensor, retrieve_timesteps
+from textflux_amd.schedulers import FlowMatchEulerDiscreteScheduler, StochasticRFOvershotDiscreteScheduler
+from textflux_amd.transformer import FluxTransformer2DModel, rope_tables
+
+SCHED = dict(use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15, base_image_seq_len=256, max_image_seq_len=4096,
+             shift=3.0)
+
+
+@pytest.mark.parametrize("n", [4, 30, 50])
+@pytest.mark.parametrize("S", [1152, 4096, 4736, 8192])
+def test_scheduler_tables_match_reference(golden, n, S):
+    g = golden("g4_sched")
+    mu = calculate_shift(S, 256, 4096, 0.5, 1.15)
+    assert mu == g[f"mu.S{S}"].item()
+    e = FlowMatchEulerDiscreteScheduler(**SCHED)
+    ts, k = retrieve_timesteps(e, n, "cpu", sigmas=np.linspace(1.0, 1 / n, n), mu=mu)
+    assert k == n and torch.equal(e.sigmas, g[f"euler.n{n}.S{S}.sigmas"]) and torch.equal(ts, g[f"euler.n{n}.S{S}.timesteps"])
+    a = StochasticRFOvershotDiscreteScheduler.from_config(e.config)  # config hand-over as run_inference.py:81-82
+    a.set_timesteps(sigmas=np.linspace(1.0, 1 / n, n), mu=mu)
+    assert torch.equal(a.sigmas, g[f"amo.n{n}.S{S}.sigmas"]) and torch.equal(a.timesteps, g[f"amo.n{n}.S{S}.timesteps"])
+    assert e.order == 1 and a.order == 1 and len(e) == 1000
+
+
+def test_coefficient_tables():
+    n, S = 30, 4096
+    mu = calculate_shift(S, 256, 4096, 0.5, 1.15)
+    e = FlowMatchEulerDiscreteScheduler(**SCHED)
+    e.set_timesteps(sigmas=np.linspace(1.0, 1 / n, n), mu=mu)
+    c = e.coef_table("cpu")
+    assert c.shape == (n,) and (c < 0).all()
+    assert torch.equal(c, c.to(torch.bfloat16).float())           # bf16-rounded, as the reference's multiply sees it
+    assert abs(c.sum().item() + 1.0) < 2e-2                       # sigma goes 1 -> 0
+    a = StochasticRFOvershotDiscreteScheduler(**SCHED)
+    with pytest.raises(RuntimeError):
+        a.set_timesteps(sigmas=np.linspace(1.0, 1 / n, n), mu=mu) or a.coef_table("cpu")
+    a.set_c(2.0)
+    a.set_overshot_func(lambda t, dt: t + dt)
+    t = a.coef_table("cpu")
+    assert t.shape == (n, 3) and (t[:, 1] <= 1).all() and (t[:, 2] >= 0).all()
+    assert t[-1, 1].item() == 1.0 and t[-1, 2].item() == 0.0      # last step deterministic
+    with pytest.raises(ValueError):
+        FlowMatchEulerDiscreteScheduler(**SCHED).set_timesteps(num_inference_steps=4)   # dynamic shifting needs mu
+
+
+def test_layout_helpers_match_reference(golden):
+    g = golden("g6_layout")
+    P = FluxFillPipeline
+    assert torch.equal(P._pack_latents(g["pack.in"], 2, 16, 8, 12), g["pack.out"])
+    assert torch.equal(P._unpack_latents(g["pack.out"], 64, 96, 8), g["unpack.out"])
+    assert torch.equal(P._prepare_latent_image_ids(1, 4, 6, "cpu", torch.float32), g["ids.4x6"])
+    g1 = golden("g1_ops")
+    cos, sin = rope_tables(g1["rope.ids"])
+    assert torch.equal(cos, g1["rope.cos"]) and torch.equal(sin, g1["rope.sin"])
+
+
+class _FakeVae:
+    class config:
+        block_out_channels = (1, 1, 1, 1)
+        latent_channels = 16
+        scaling_factor = 0.3611
+        shift_factor = 0.1159
+
+
+def _pipe():
+    tr = FluxTransformer2DModel(in_channels=384, out_channels=64, num_layers=1, num_single_layers=1,
+                                num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32, guidance_embeds=True)
+    return FluxFillPipeline(scheduler=FlowMatchEulerDiscreteScheduler(**SCHED), vae=_FakeVae(), text_encoder=None,
+                            tokenizer=None, text_encoder_2=None, tokenizer_2=None, transformer=tr)
+
+
+def test_check_inputs_raises_like_the_reference():
+    p = _pipe()
+    pe, pooled = torch.zeros(1, 4, 64), torch.zeros(1, 32)
+    ok = dict(prompt=None, prompt_2=None, height=64, width=64, prompt_embeds=pe, pooled_prompt_embeds=pooled)
+    p.check_inputs(**ok)
+    for bad in (dict(prompt="x"), dict(prompt_2="x"), dict(prompt_embeds=None), dict(pooled_prompt_embeds=None),
+                dict(max_sequence_length=513), dict(callback_on_step_end_tensor_inputs=["nope"]),
+                dict(image=torch.zeros(1, 3, 8, 8)), dict(image=torch.zeros(1, 3, 8, 8), mask_image=1, masked_image_latents=1)):
+        with pytest.raises(ValueError):
+            p.check_inputs(**{**ok, **bad})
+    assert p.vae_scale_factor == 8 and p.tokenizer_max_length == 77 and p.default_sample_size == 128
+
+
+def test_mask_packing_matches_reference(golden):
+    g = golden("g6_layout")
+    p = _pipe()
+    mask, mil = p.prepare_mask_latents(g["mask.in"], torch.zeros(2, 16, 8, 12), 2, 16, 1, 64, 96, torch.float32, "cpu", None)
+    assert torch.equal(mask, g["mask.out"]) and mil.shape == (2, 24, 64)
+
+
+def test_randn_tensor_generator_semantics():
+    a = randn_tensor((2, 3), generator=torch.Generator().manual_seed(1))
+    b = randn_tensor((2, 3), generator=torch.Generator().manual_seed(1))
+    assert torch.equal(a, b)
+    gens = [torch.Generator().manual_seed(5), torch.Generator().manual_seed(6)]
+    c = randn_tensor((2, 3), generator=gens)
+    assert torch.equal(c[0:1], randn_tensor((1, 3), generator=torch.Generator().manual_seed(5)))
+
+
+def test_image_processor():
+    ip = VaeImageProcessor(vae_scale_factor=16)
+    img = Image.fromarray((np.arange(40 * 50 * 3) % 256).astype(np.uint8).reshape(40, 50, 3))
+    t = ip.preprocess(img, height=40, width=50)
+    assert t.shape == (1, 3, 32, 48) and t.min() >= -1 and t.max() <= 1
+    mp = VaeImageProcessor(vae_scale_factor=16, vae_latent_channels=16, do_normalize=False, do_binarize=True,
+                           do_convert_grayscale=True)
+    m = mp.preprocess(Image.fromarray(np.full((32, 32, 3), 200, np.uint8)), height=32, width=32)
+    assert m.shape == (1, 1, 32, 32) and set(m.unique().tolist()) == {1.0}
+    x = torch.linspace(-1.2, 1.2, 3 * 4 * 4).reshape(1, 3, 4, 4)
+    out = ip.postprocess(x, "np")
+    assert out.shape == (1, 4, 4, 3) and out.min() == 0 and out.max() == 1
+    assert ip.postprocess(x, "pil")[0].size == (4, 4) and ip.postprocess(x, "latent") is x
+
+
+@pytest.mark.parametrize("w,h,multi,pipe,crop", [
+    (512, 512, False, (512, 576), (0, 77, 512, 576)), (512, 512, True, (512, 1024), (0, 512, 512, 1024)),
+    (1024, 1024, False, (1024, 1184), (0, 160, 1024, 1184)), (1024, 512, False, (1024, 672), (0, 160, 1024, 672)),
+    (1000, 700, False, (992, 832), (0, 151, 992, 832)), (700, 1000, True, (1376, 992), (688, 0, 1376, 992)),
+    (1400, 900, False, (1376, 1088), (0, 212, 1376, 1088))])
+def test_driver_geometry_known_answers(w, h, multi, pipe, crop):
+    scene, mask, words = glyph.synthetic_case(w, h, multiline=multi)
+    combined, cmask, meta = glyph.compose(scene, mask, words)
+    assert combined.size == cmask.size
+    assert glyph.pipe_size(combined) == pipe
+    assert glyph.crop_box(pipe, meta) == crop
+    arr = np.array(cmask)
+    if meta["direction"] == "vertical":
+        assert arr[: arr.shape[0] - h].max() == 0     # the glyph half of the mask is black
+    else:
+        assert arr[:, : arr.shape[1] - w].max() == 0
+
+
+def test_prompts_verbatim():
+    assert glyph.generate_prompt(["陕西"]).endswith("[IMAGE2] shows the text content '陕西' naturally and correspondingly integrated into the image.")
+    assert "with the words 'a', 'b';" in glyph.generate_prompt(["a", "b"])
+    assert glyph.PROMPT_TEMPLATE2.startswith("The pair of images highlights some white words on a black background")
+    assert glyph.read_words_from_text(" x \n\n y ") == ["x", "y"]
+
+
+def test_state_dict_key_contract():
+    from oracle import flux_oracle as fo
+    cfg = fo.FluxConfig(num_layers=2, num_single_layers=3, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32)
+    m = FluxTransformer2DModel(in_channels=384, out_channels=64, num_layers=2, num_single_layers=3, num_attention_heads=2,
+                               joint_attention_dim=64, pooled_projection_dim=32, guidance_embeds=True)
+    assert sorted(m.expected_keys()) == sorted(fo.state_dict_shapes(cfg).keys())   # = the reference's key set (G-goldens)
+    assert m.mod_len == 12 * 256 * 2 + 3 * 256 * 3 + 2 * 256
+    full = FluxTransformer2DModel(in_channels=384, out_channels=64, guidance_embeds=True)
+    assert full.mod_len == 1056768 and len(full.expected_keys()) == 1160
+    with pytest.raises(ValueError):
+        FluxTransformer2DModel(attention_head_dim=64)
