@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+constexpr int GLDS_AUX = 0;        // default cache policy of the operand prefetch
 constexpr int LDS_X = 0;            // X_g set s at g*32768 + s*16384   (128 rows x 128 B)
 constexpr int LDS_W = 65536;        // W   set s at 65536 + s*32768     (256 rows x 128 B)
 constexpr int LDS_DUMMY = 131072;   // 8 x 1 KiB sink for out-of-range prefetches (keeps vmcnt counts uniform)
@@ -100,8 +101,10 @@ constexpr int LDS_TOTAL = 8 * EPI_WAVE_BYTES;        // 147456 >= 131072 + 8192 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+// AUX = cache-policy bits of the load (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
+template <int AUX>
 __device__ __forceinline__ void glds16(const bf16_t* g, char* smem, uint32_t lds_off) {
-  __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(smem + lds_off), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(smem + lds_off), 16, 0, AUX);
 }
 
 #define TFX_BARRIER()                          \
@@ -194,8 +197,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     const int kt = ok ? tile : nt - 1;
     const bf16_t* base = (isx[q] ? Xb : Wb) + (int64_t)kt * 64;
     const uint32_t setoff = (tile & 1) * (isx[q] ? 16384u : 32768u);
+    constexpr int kAux = ((ABL >> 5) & 3) == 1 ? 16 : ((ABL >> 5) & 3) == 2 ? 2 : ((ABL >> 5) & 3) == 3 ? 1 : GLDS_AUX;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(base + goff[q][j], smem, ok ? ldst[q][j] + setoff : dummy);
+    for (int j = 0; j < 2; ++j) glds16<kAux>(base + goff[q][j], smem, ok ? ldst[q][j] + setoff : dummy);
   };
 
   // ---- fragment read addresses (set 0); per-lane swizzle key is (lane>>1)&7 because fragment rows are
@@ -256,6 +260,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       wlo[kk] = LDS_FRAG(fw[kk]); whi[kk] = LDS_FRAG(fw[kk] + 4096);
     }
   }
+  // ABL bit 7: cycle accounting (s_memtime) of one tile's phases by every wave's lane 0 -> p.res reinterpreted as
+  // uint64 [block][wave][4] = {vmcnt wait, barrier after loads, MFMA section, barrier after MFMA}
+  unsigned long long tw = 0, tb1 = 0, tm = 0, tb2 = 0, tmark = 0;
+#define TMARK() do { if (ABL & 128) tmark = __builtin_readcyclecounter(); } while (0)
+#define TACC(acc_) do { if (ABL & 128) { unsigned long long n_ = __builtin_readcyclecounter(); acc_ += n_ - tmark; tmark = n_; } } while (0)
   auto tile_body = [&](int u, const uint32_t xs, const uint32_t ws) {
     // xs / ws: byte offset of this tile's set inside the X / W regions (0 or 16384 / 32768)
     // ---- q0: X_lo (rows 0..63 of the group's half), W_lo (cols 0..31 of the stripe)
@@ -268,20 +277,30 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       }
     }
     BODY_STAGE(0, u + 1);
+    TMARK();
     WAIT_PREFETCH();
+    TACC(tw);
     BODY_BARRIER();
+    TACC(tb1);
     MFMA8(wlo, 0, 0);
+    TACC(tm);
     BODY_BARRIER();
+    TACC(tb2);
     // ---- q1: W_hi (cols 32..63)
     if (!(ABL & 2)) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);
     }
     BODY_STAGE(1, u + 2);
+    TMARK();
     WAIT_PREFETCH();
+    TACC(tw);
     BODY_BARRIER();
+    TACC(tb1);
     MFMA8(whi, 0, 1);
+    TACC(tm);
     BODY_BARRIER();
+    TACC(tb2);
     // ---- q2: X_hi (rows 64..127)
     if (!(ABL & 2)) {
 #pragma unroll
@@ -291,16 +310,26 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       }
     }
     BODY_STAGE(2, u + 2);
+    TMARK();
     WAIT_PREFETCH();
+    TACC(tw);
     BODY_BARRIER();
+    TACC(tb1);
     MFMA8(whi, 2, 1);
+    TACC(tm);
     BODY_BARRIER();
+    TACC(tb2);
     // ---- q3: no reads
     BODY_STAGE(3, u + 2);
+    TMARK();
     WAIT_PREFETCH();
+    TACC(tw);
     BODY_BARRIER();
+    TACC(tb1);
     MFMA8(wlo, 2, 0);
+    TACC(tm);
     BODY_BARRIER();
+    TACC(tb2);
   };
 
   for (int u = 0; u < nt; u += 2) {
@@ -308,11 +337,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     if (u + 1 < nt) tile_body(u + 1, 16384u, 32768u);
   }
   if (g == 0) TFX_BARRIER();  // re-align the two groups
+  if ((ABL & 128) && lane == 0) {
+    unsigned long long* dbg = (unsigned long long*)p.res + ((size_t)blockIdx.x * 8 + wave) * 4;
+    dbg[0] = tw; dbg[1] = tb1; dbg[2] = tm; dbg[3] = tb2;
+  }
 #undef LDS_FRAG
 #undef MFMA8
 #undef WAIT_PREFETCH
 #undef BODY_STAGE
 #undef BODY_BARRIER
+#undef TMARK
+#undef TACC
 
   // ---- epilogue.  Lane holds, per (mi, nj, quad), 4 consecutive columns of one row:
   //   m = m0 + g*128 + mi*32 + (lane & 31),  n = n0 + wc*64 + nj*32 + quad*8 + hi*4 + (r & 3).
@@ -428,6 +463,13 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       case 7: return launch_ablation<7>(p, st);
       case 8: return launch_ablation<8>(p, st);
       case 16: return launch_ablation<16>(p, st);
+      case 32: return launch_ablation<32>(p, st);
+      case 128: return launch_ablation<128>(p, st);
+      case 129: return launch_ablation<129>(p, st);
+      case 135: return launch_ablation<135>(p, st);
+      case 144: return launch_ablation<144>(p, st);
+      case 64: return launch_ablation<64>(p, st);
+      case 96: return launch_ablation<96>(p, st);
       case 18: return launch_ablation<18>(p, st);
       case 17: return launch_ablation<17>(p, st);
     }
