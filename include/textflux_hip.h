@@ -141,6 +141,10 @@ typedef struct tfx_dit_desc {
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
 
+/* ---- tuning knobs (no reference counterpart).  "attention_waves": 8 = one 512-thread workgroup of 256 query rows per
+ *      CU, 4 = two independent 256-thread workgroups of 128 query rows per CU. */
+int tfx_set_option(const char* name, int value);
+
 /* ---- measurement hooks (no reference counterpart: the reference has no profiling) --------------------
  * When enabled, every MFMA-GEMM (kind 0) / attention (kind 1) launch is bracketed by hipEvents on its own stream and
  * its algorithmic FLOPs (2*M*N*K*batch, 4*B*H*N^2*128) are recorded; tfx_prof_collect waits for those launches and

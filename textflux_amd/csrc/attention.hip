@@ -16,14 +16,20 @@
 
 namespace tfx {
 
-constexpr int QBLK = 256, KVBLK = 64, HD = 128;
+constexpr int KVBLK = 64, HD = 128;
 constexpr int K_BYTES = KVBLK * HD * 2;          // 16 KiB
 constexpr int ATT_LDS = 2 * 2 * K_BYTES;         // K,V x 2 buffers = 64 KiB
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-// Q and O may alias (the single-stream blocks write O over Q; a block only touches its own 256 rows of one head).
-__global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
+// Q and O may alias (the single-stream blocks write O over Q; a block only touches its own QBLK rows of one head).
+// NW waves per workgroup (QBLK = 32 * NW query rows).  NW = 8: one workgroup per CU; NW = 4: two independent
+// workgroups per CU (64 KiB LDS each) whose waves share the SIMDs without a common barrier, so one's softmax (VALU)
+// overlaps the other's MFMA phases.
+// ABL: bench-only ablations (wrong results): bit0 no softmax math, bit1 K fragments read once, bit2 V fragments read
+// once, bit3 no K/V staging after the first tile.
+template <int NW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
                                                    const bf16_t* __restrict__ Vp, bf16_t* O,
                                                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs,
                                                    int64_t k_bs, int64_t v_bs, int64_t o_bs, int H, int N, int nqb,
@@ -51,6 +57,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t
   bf16_t* Ob = O + b * o_bs + h * HD;
 
   // ---- Q fragments: lane (q = l31, hi) holds d = s*16 + hi*8 + [0,8) for s = 0..7
+  constexpr int QBLK = NW * 32, NT = NW * 64, CPT = 1024 / NT;  // chunks of a 16 KiB tile per thread
   const int qrow = qb * QBLK + wave * 32 + l31;
   const int qrow_c = qrow < N ? qrow : N - 1;
   bf16x8 qf[8];
@@ -60,11 +67,11 @@ __global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t
 
   // ---- staging: thread t copies chunks c = t and t + 512 of the 1024 16-byte chunks of a K (and V) tile
   const int nkv = (N + KVBLK - 1) / KVBLK;
-  u32x4 kreg[2], vreg[2];
+  u32x4 kreg[CPT], vreg[CPT];
   auto load_tile = [&](int j) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 512;
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * NT;
       int key = j * KVBLK + (c >> 4);
       if (key > N - 1) key = N - 1;
       kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (int64_t)key * ldk + (c & 15) * 8);
@@ -75,8 +82,8 @@ __global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t
     char* kd = smem + buf * 2 * K_BYTES;
     char* vd = kd + K_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 512;
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * NT;
       const int key = c >> 4, ch = c & 15;
       *reinterpret_cast<u32x4*>(kd + key * 256 + ((ch ^ (key & 15)) << 4)) = kreg[i];
       *reinterpret_cast<u32x4*>(vd + key * 256 + ((((ch >> 2) ^ (key & 3)) << 6) | ((ch & 3) << 4))) = vreg[i];
@@ -107,9 +114,10 @@ __global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t
   write_tile(0);
   __syncthreads();
 
+  bf16x8 kab[8], vab;
   for (int j = 0; j < nkv; ++j) {
     const int buf = j & 1;
-    if (j + 1 < nkv) load_tile(j + 1);  // global loads in flight under this tile's math
+    if (j + 1 < nkv && !(ABL & 8)) load_tile(j + 1);  // global loads in flight under this tile's math
     const char* kt = smem + buf * 2 * K_BYTES;
     const char* vt = kt + K_BYTES;
 
@@ -119,8 +127,13 @@ __global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kt + koff[s]);
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kt + koff[s] + 32 * 256);
+      bf16x8 k0, k1;
+      if ((ABL & 2) && j > 0) { k0 = kab[s]; k1 = kab[s]; }
+      else {
+        k0 = *reinterpret_cast<const bf16x8*>(kt + koff[s]);
+        k1 = *reinterpret_cast<const bf16x8*>(kt + koff[s] + 32 * 256);
+        if (ABL & 2) kab[s] = k0;
+      }
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
     }
@@ -134,6 +147,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t
       }
     }
     // ---- online softmax (this lane: one query row, 32 keys; partner lane^32: the other 32)
+    if (!(ABL & 1)) {
     float mx = s0[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
@@ -156,6 +170,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t
     for (int db = 0; db < 4; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
     // P as MFMA B operands: step ks covers keys 16*ks + {0..3, 8..11} + 4*hi = accumulator regs 8*(ks&1)..+7
     bf16x8 pf[4];
 #pragma unroll
@@ -175,11 +190,12 @@ __global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t
         const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 8 * 256));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         const s16x8 both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+        bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+        if (ABL & 4) { if (j == 0 && ks == 0 && db == 0) vab = vf; else vf = vab; }
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[db], 0, 0, 0);
       }
     }
-    if (j + 1 < nkv) write_tile(buf ^ 1);
+    if (j + 1 < nkv && !(ABL & 8)) write_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -200,28 +216,51 @@ __global__ __launch_bounds__(512) void attn_kernel(const bf16_t* Q, const bf16_t
   }
 }
 
+static int g_attn_waves = 8;
+static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
+void set_attention_ablation(int a) { g_attn_abl = a; }
+void set_attention_waves(int nw) { g_attn_waves = (nw == 4) ? 4 : 8; }
+
 int joint_attention(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.H <= 0 || a.N <= 0) return 0;
   if ((a.ldq | a.ldk | a.ldv | a.q_bstride | a.k_bstride | a.v_bstride) % 8 || (a.ldo | a.o_bstride) % 4)
     return fail("attention: strides must be multiples of 8 elements (q,k,v) / 4 (o)");
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 || (uintptr_t)a.o % 8)
     return fail("attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
+  const int NW = g_attn_waves;
+  const int qblk = NW * 32;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel);
+    (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<8>);
+    (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<4>);
     (void)hipGetLastError();
-    const hipError_t e = hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e != hipSuccess) return fail("attention: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  const int nqb = (a.N + QBLK - 1) / QBLK;
+  const int nqb = (a.N + qblk - 1) / qblk;
   const unsigned grid = (unsigned)(a.B * a.H * nqb);
   const bool prof = prof_on();
   if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
-  attn_kernel<<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
-                                          a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
-                                          a.N, nqb, a.scale * 1.4426950408889634f);
+  if (g_attn_abl) {
+    (void)hipFuncSetAttribute((const void*)attn_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_kernel<8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+#define ATT_ABL(A) attn_kernel<8, A><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f)
+    switch (g_attn_abl) { case 1: ATT_ABL(1); break; case 2: ATT_ABL(2); break; case 4: ATT_ABL(4); break; case 8: ATT_ABL(8); break; default: ATT_ABL(15); }
+#undef ATT_ABL
+  } else if (NW == 8)
+    attn_kernel<8><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
+                                               a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
+                                               a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f);
+  else
+    attn_kernel<4><<<grid, 256, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
+                                               a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
+                                               a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f);
   if (prof) prof_end(1, st);
   return check_launch("joint_attention");
 }

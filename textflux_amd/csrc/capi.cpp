@@ -228,6 +228,17 @@ int tfx_advance_step(int32_t* step_ptr, tfx_stream stream) {
   return advance_step(step_ptr, S(stream));
 }
 
+int tfx_set_option(const char* name, int value) {
+  if (!name) return fail("tfx_set_option: null name");
+  if (!std::strcmp(name, "attention_waves")) {
+    if (value != 4 && value != 8) return fail("tfx_set_option: attention_waves must be 4 or 8");
+    set_attention_waves(value);
+    return 0;
+  }
+  if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only
+  return fail("tfx_set_option: unknown option '%s'", name);
+}
+
 int tfx_prof_enable(int on) { prof_enable(on); return 0; }
 int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches) {
   if (kind < 0 || kind > 1) return fail("tfx_prof_collect: kind must be 0 (gemm) or 1 (attention)");

@@ -198,3 +198,7 @@ def prof_collect(kind: int):
     ms, fl, n = C.c_double(), C.c_double(), C.c_int()
     L.check(L.lib().tfx_prof_collect(kind, C.byref(ms), C.byref(fl), C.byref(n)), "prof_collect")
     return ms.value, fl.value, n.value
+
+
+def set_option(name: str, value: int) -> None:
+    L.check(L.lib().tfx_set_option(name.encode(), int(value)), "set_option")

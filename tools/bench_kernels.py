@@ -40,10 +40,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--only", default="")
     a = ap.parse_args()
     dev = "cuda"
     D = 3072
     rows = [4608] if a.quick else [4608, 4608 * 8]
+    if a.only == 'attention':
+        rows = []
     shapes = [(3 * D, D), (D, D), (4 * D, D), (D, 4 * D), (7 * D, D), (D, 5 * D)]
     for M in rows:
         for N, K in shapes:
@@ -63,9 +66,17 @@ def main():
             y = torch.randn(B, N, 3 * D, device=dev).to(BF)
             o = torch.empty(B, N, D, dtype=BF, device=dev)
             q, k, v = y[:, :, 2 * D:], y[:, :, :D], y[:, :, D:2 * D]
-            t = timeit(lambda: ops.attention(q, k, v, out=o))
             fl = 4.0 * B * H * N * N * 128
-            emit(dict(tag=a.tag, kernel="attention", B=B, N=N, ms=t * 1e3, tflops=fl / t / 1e12))
+            for nw in (8, 4):
+                ops.set_option("attention_waves", nw)
+                t = timeit(lambda: ops.attention(q, k, v, out=o))
+                emit(dict(tag=a.tag, kernel=f"attention(nw={nw})", B=B, N=N, ms=t * 1e3, tflops=fl / t / 1e12))
+            ops.set_option("attention_waves", 8)
+            for abl, nm in ((1, "no-softmax"), (2, "K-frags-once"), (4, "V-frags-once"), (8, "no-staging"), (15, "mfma-only")):
+                ops.set_option("attention_ablation", abl)
+                t = timeit(lambda: ops.attention(q, k, v, out=o))
+                emit(dict(tag=a.tag, kernel=f"attention[{nm}]", B=B, N=N, ms=t * 1e3, tflops=fl / t / 1e12))
+            ops.set_option("attention_ablation", 0)
             qh, kh, vh = (z.reshape(B, N, H, 128).transpose(1, 2) for z in (q, k, v))
             t2 = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(qh, kh, vh), iters=5)
             emit(dict(tag=a.tag, kernel="torch.sdpa", B=B, N=N, ms=t2 * 1e3, tflops=fl / t2 / 1e12))
