@@ -21,6 +21,17 @@ constexpr int K_BYTES = KVBLK * HD * 2;          // 16 KiB
 constexpr int ATT_LDS = 2 * 2 * K_BYTES;         // K,V x 2 buffers = 64 KiB
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ unsigned long long* g_dbg_ptr = nullptr;  // bench-only (tools/attn_timing.py)
+
+// raw barrier (no vmcnt drain: the staged global loads stay in flight across it); LDS traffic of the issuing wave
+// is drained first so the partner group sees completed ds_writes.
+#define TFX_ATT_BARRIER()                                   \
+  do {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                           \
+    __builtin_amdgcn_sched_barrier(0);                      \
+  } while (0)
 
 // Q and O may alias (the single-stream blocks write O over Q; a block only touches its own QBLK rows of one head).
 // NW waves per workgroup (QBLK = 32 * NW query rows).  NW = 8: one workgroup per CU; NW = 4: two independent
@@ -112,12 +123,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
 
   load_tile(0);
   write_tile(0);
+  if (nkv > 1) load_tile(1);
   __syncthreads();
 
   bf16x8 kab[8], vab;
+  unsigned long long tq = 0, tsm = 0, tpv = 0, tst = 0, tmk = 0;
+#define LTM() do { if (ABL & 16) { __builtin_amdgcn_sched_barrier(0); tmk = __builtin_readcyclecounter(); } } while (0)
+#define LTA(x) do { if (ABL & 16) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = __builtin_readcyclecounter(); x += n_ - tmk; tmk = n_; } } while (0)
   for (int j = 0; j < nkv; ++j) {
     const int buf = j & 1;
-    if (j + 1 < nkv && !(ABL & 8)) load_tile(j + 1);  // global loads in flight under this tile's math
+    LTM();
+    // staging: tile j+1 (requested one whole tile ago) goes into the other buffer -- idle since the barrier that ended
+    // tile j-1 -- right away, and the registers are re-used for the request of tile j+2: the loads get a full tile
+    // of latency hiding and the barrier at the end of the tile no longer waits for memory.
+    if (j + 1 < nkv && !(ABL & 8)) {
+      write_tile(buf ^ 1);
+      if (j + 2 < nkv) load_tile(j + 2);
+    }
     const char* kt = smem + buf * 2 * K_BYTES;
     const char* vt = kt + K_BYTES;
 
@@ -137,6 +159,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
     }
+    LTA(tq);
     if (j == nkv - 1 && (N & (KVBLK - 1))) {  // ragged last tile: keys >= N get -inf
       const int kbase = j * KVBLK + 4 * hi;
 #pragma unroll
@@ -166,10 +189,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
       psum += s0[r] + s1[r];
     }
     l_run = l_run * alpha + psum;
+    if (!__all(alpha == 1.0f)) {  // exact: alpha is exactly 1 whenever the running max did not move
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
     }
     // P as MFMA B operands: step ks covers keys 16*ks + {0..3, 8..11} + 4*hi = accumulator regs 8*(ks&1)..+7
     bf16x8 pf[4];
@@ -180,6 +205,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
       pf[2][e] = (__bf16)s1[e];
       pf[3][e] = (__bf16)s1[8 + e];
     }
+    LTA(tsm);
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -195,9 +221,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[db], 0, 0, 0);
       }
     }
-    if (j + 1 < nkv && !(ABL & 8)) write_tile(buf ^ 1);
+    LTA(tpv);
     __syncthreads();
+    LTA(tst);
   }
+  if ((ABL & 16) && lane == 0 && g_dbg_ptr) {
+    unsigned long long* d = g_dbg_ptr + ((size_t)blockIdx.x * 8 + wave) * 4;
+    d[0] = tq; d[1] = tsm; d[2] = tpv; d[3] = tst;
+  }
+#undef LTM
+#undef LTA
 
   // ---- finish: combine the two half-row sums, normalise, store 4 consecutive d per (db, quad)
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -216,10 +249,259 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
   }
 }
 
-static int g_attn_waves = 8;
+
+// -------------------------------------------------------------------------------------------------------------
+// Ping-pong variant (default).  Same math and data layouts as attn_kernel<8>, different schedule: the tile loop is
+// split into a VALU phase PA(u) = online softmax of tile u (scores already in registers) and an MFMA phase
+// PB(u) = O *= alpha; O^T += V(u)^T P(u)^T; S(u+1) = K(u+1) Q^T, and the two wave groups (waves 0-3 / 4-7, one
+// wave of each per SIMD) run half an iteration apart, offset by one s_barrier -- while one group's waves are in
+// their softmax the partner waves on the same SIMDs issue 32 MFMAs, so the matrix pipe and the VALU overlap instead
+// of both waves of a SIMD queueing for the same pipe.  Slots: G0 PA(u)=2u, PB(u)=2u+1; G1 one slot later.
+// LDS: K(t) is read in slots 2t-1, 2t, V(t) in 2t+1, 2t+2 (two buffers each); in PB(u) every thread writes its
+// chunks of V(u+1) and K(u+2) (both regions idle since >= 1 barrier, first readers >= 1 barrier later), then
+// re-issues the global loads for V(u+2), K(u+3) that stay in flight for two slots.
+template <bool TIMING>
+__global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
+                                                         const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq,
+                                                         int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs,
+                                                         int64_t v_bs, int64_t o_bs, int H, int N, int nqb,
+                                                         float scale_log2e, unsigned long long* dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2;
+  unsigned long long t_pa = 0, t_b1 = 0, t_pb = 0, t_b2 = 0, tmark = 0;
+#define ATM() do { if (TIMING) tmark = __builtin_readcyclecounter(); } while (0)
+#define ATA(x) do { if (TIMING) { unsigned long long n_ = __builtin_readcyclecounter(); x += n_ - tmark; tmark = n_; } } while (0)
+  const int hi = lane >> 5, l31 = lane & 31;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int qb = bid % nqb;
+  bid /= nqb;
+  const int h = bid % H;
+  const int b = bid / H;
+  const bf16_t* Qb = Q + b * q_bs + h * HD;
+  const bf16_t* Kb = Kp + b * k_bs + h * HD;
+  const bf16_t* Vb = Vp + b * v_bs + h * HD;
+  bf16_t* Ob = O + b * o_bs + h * HD;
+
+  const int qrow = qb * 256 + wave * 32 + l31;
+  const int qrow_c = qrow < N ? qrow : N - 1;
+  bf16x8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qrow_c * ldq + s * 16 + hi * 8);
+
+  const int nkv = (N + KVBLK - 1) / KVBLK;
+  char* kbuf = smem;                 // K(t) at kbuf + (t&1)*16K
+  char* vbuf = smem + 2 * K_BYTES;   // V(t) at vbuf + (t&1)*16K
+  u32x4 kreg[2], vreg[2];
+  auto load_rows = [&](const bf16_t* base, int64_t ld, int t, u32x4* reg) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 512;
+      int key = t * KVBLK + (c >> 4);
+      if (key > N - 1) key = N - 1;
+      reg[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)key * ld + (c & 15) * 8);
+    }
+  };
+  auto write_k = [&](int t) {
+    char* kd = kbuf + (t & 1) * K_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 512, key = c >> 4, ch = c & 15;
+      *reinterpret_cast<u32x4*>(kd + key * 256 + ((ch ^ (key & 15)) << 4)) = kreg[i];
+    }
+  };
+  auto write_v = [&](int t) {
+    char* vd = vbuf + (t & 1) * K_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 512, key = c >> 4, ch = c & 15;
+      *reinterpret_cast<u32x4*>(vd + key * 256 + ((((ch >> 2) ^ (key & 3)) << 6) | ((ch & 3) << 4))) = vreg[i];
+    }
+  };
+
+  uint32_t koff[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) koff[s] = l31 * 256 + (((2 * s + hi) ^ (lane & 15)) << 4);
+  const int vi = lane & 15;
+  const uint32_t vrow = (4 * hi + (vi >> 2)) * 256 + 32 * ((lane >> 4) & 1) + (vi & 3) * 8;
+  uint32_t voff[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) voff[db] = vrow + ((db ^ ((vi >> 2) & 3)) << 6);
+
+  f32x16 o[4], s0, s1;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f, alpha = 1.f;
+  bf16x8 pf[4];
+
+  // S(t) = K(t) Q^T from LDS, software pipelined by hand: the fragment reads run two k-steps (4 MFMAs = 128 matrix
+  // cycles) ahead of their MFMAs in a 3-deep register ring -- in the ping-pong schedule only ONE wave per SIMD is in
+  // its MFMA phase, so LDS latency is not covered by a partner wave; sched_barriers keep hipcc from sinking the
+  // prefetches back next to their uses.
+  auto qk = [&](int t) {
+    const char* kt = kbuf + (t & 1) * K_BYTES;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    bf16x8 kf[3][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      kf[s][0] = *reinterpret_cast<const bf16x8*>(kt + koff[s]);
+      kf[s][1] = *reinterpret_cast<const bf16x8*>(kt + koff[s] + 32 * 256);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s + 2 < 8) {
+        kf[(s + 2) % 3][0] = *reinterpret_cast<const bf16x8*>(kt + koff[s + 2]);
+        kf[(s + 2) % 3][1] = *reinterpret_cast<const bf16x8*>(kt + koff[s + 2] + 32 * 256);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s % 3][0], qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s % 3][1], qf[s], s1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: K(0), V(0), K(1) into LDS; V(1) loaded (written in PB(0)); K(2) requested
+  load_rows(Kb, ldk, 0, kreg);
+  load_rows(Vb, ldv, 0, vreg);
+  write_k(0);
+  write_v(0);
+  if (nkv > 1) {
+    load_rows(Kb, ldk, 1, kreg);
+    load_rows(Vb, ldv, 1, vreg);
+    write_k(1);
+    if (nkv > 2) load_rows(Kb, ldk, 2, kreg);
+  }
+  __syncthreads();
+  qk(0);
+  TFX_ATT_BARRIER();
+  if (g == 1) TFX_ATT_BARRIER();  // stagger: group 1 runs one slot behind
+
+  for (int u = 0; u < nkv; ++u) {
+    ATM();
+    // ================= PA(u): online softmax of tile u (VALU) =================
+    if (u == nkv - 1 && (N & (KVBLK - 1))) {
+      const int kbase = u * KVBLK + 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        if (key >= N) s0[r] = -INFINITY;
+        if (key + 32 >= N) s1[r] = -INFINITY;
+      }
+    }
+    {
+      float mx = s0[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float mc = m_new * scale_log2e;
+      alpha = __builtin_amdgcn_exp2f(m_run * scale_log2e - mc);
+      m_run = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(s0[r] * scale_log2e - mc);
+        s1[r] = __builtin_amdgcn_exp2f(s1[r] * scale_log2e - mc);
+        psum += s0[r] + s1[r];
+      }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pf[0][e] = (__bf16)s0[e];
+        pf[1][e] = (__bf16)s0[8 + e];
+        pf[2][e] = (__bf16)s1[e];
+        pf[3][e] = (__bf16)s1[8 + e];
+      }
+    }
+    ATA(t_pa);
+    TFX_ATT_BARRIER();
+    ATA(t_b1);
+    // ================= PB(u): rescale, PV(u), QK(u+1), staging (MFMA) =================
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    {
+      // O^T += V(u)^T P(u)^T: 16 MFMAs over (ks, db), V fragments (2 transpose reads each) 4 MFMAs ahead in a 5-deep ring
+      const char* vt = vbuf + (u & 1) * K_BYTES;
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      auto ldv = [&](int i) -> bf16x8 {
+        const char* va = vt + voff[i & 3] + (i >> 2) * 16 * 256;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 8 * 256));
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+      bf16x8 vf[5];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vf[i] = ldv(i);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i + 4 < 16) vf[(i + 4) % 5] = ldv(i + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 5], pf[i >> 2], o[i & 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (u + 1 < nkv) {
+      qk(u + 1);
+      write_v(u + 1);
+      if (u + 2 < nkv) {
+        write_k(u + 2);
+        load_rows(Vb, ldv, u + 2, vreg);
+        if (u + 3 < nkv) load_rows(Kb, ldk, u + 3, kreg);
+      }
+    }
+    ATA(t_pb);
+    TFX_ATT_BARRIER();
+    ATA(t_b2);
+  }
+  if (g == 0) TFX_ATT_BARRIER();
+  if (TIMING && lane == 0 && dbg) {
+    unsigned long long* d = dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+    d[0] = t_pa; d[1] = t_b1; d[2] = t_pb; d[3] = t_b2;
+  }
+#undef ATM
+#undef ATA
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < N) {
+    bf16_t* orow = Ob + (int64_t)qrow * ldo + 4 * hi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        u32x2 w;
+        w[0] = pack_bf2(o[db][qd * 4 + 0] * inv, o[db][qd * 4 + 1] * inv);
+        w[1] = pack_bf2(o[db][qd * 4 + 2] * inv, o[db][qd * 4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(orow + db * 32 + qd * 8) = w;
+      }
+  }
+}
+
+static int g_attn_waves = 8;  // 8 (default) / 4 = lock-step kernel with 8 / 4 waves per workgroup; 16 = ping-pong kernel (slower: kept for A/B)
+static unsigned long long* g_attn_dbg = nullptr;  // bench-only phase timing buffer
+void set_attention_debug(void* p) {
+  g_attn_dbg = (unsigned long long*)p;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_ptr), &p, sizeof(p));
+}
 static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
-void set_attention_waves(int nw) { g_attn_waves = (nw == 4) ? 4 : 8; }
+void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8) ? nw : 16; }
 
 int joint_attention(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.H <= 0 || a.N <= 0) return 0;
@@ -227,16 +509,19 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     return fail("attention: strides must be multiples of 8 elements (q,k,v) / 4 (o)");
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 || (uintptr_t)a.o % 8)
     return fail("attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
-  const int NW = g_attn_waves;
+  const int NW = g_attn_waves == 16 ? 8 : g_attn_waves;
+  const bool pp = g_attn_waves == 16;
   const int qblk = NW * 32;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncAttributes fa;
     (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<8>);
     (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<4>);
+    (void)hipFuncGetAttributes(&fa, (const void*)attn_pp_kernel<false>);
     (void)hipGetLastError();
     hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e != hipSuccess) return fail("attention: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
@@ -250,10 +535,21 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)attn_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     (void)hipFuncSetAttribute((const void*)attn_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     (void)hipFuncSetAttribute((const void*)attn_kernel<8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_kernel<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
 #define ATT_ABL(A) attn_kernel<8, A><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f)
-    switch (g_attn_abl) { case 1: ATT_ABL(1); break; case 2: ATT_ABL(2); break; case 4: ATT_ABL(4); break; case 8: ATT_ABL(8); break; default: ATT_ABL(15); }
+    switch (g_attn_abl) { case 1: ATT_ABL(1); break; case 2: ATT_ABL(2); break; case 4: ATT_ABL(4); break; case 8: ATT_ABL(8); break; case 16: ATT_ABL(16); break; default: ATT_ABL(15); }
 #undef ATT_ABL
-  } else if (NW == 8)
+  } else if (pp)
+    if (g_attn_dbg) {
+      (void)hipFuncSetAttribute((const void*)attn_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+      attn_pp_kernel<true><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
+                                                       a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
+                                                       a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f, g_attn_dbg);
+    } else
+      attn_pp_kernel<false><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
+                                                        a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
+                                                        a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f, nullptr);
+  else if (NW == 8)
     attn_kernel<8><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
                                                a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
                                                a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f);

@@ -231,13 +231,15 @@ int tfx_advance_step(int32_t* step_ptr, tfx_stream stream) {
 int tfx_set_option(const char* name, int value) {
   if (!name) return fail("tfx_set_option: null name");
   if (!std::strcmp(name, "attention_waves")) {
-    if (value != 4 && value != 8) return fail("tfx_set_option: attention_waves must be 4 or 8");
+    if (value != 4 && value != 8 && value != 16) return fail("tfx_set_option: attention_waves must be 4, 8 or 16 (ping-pong)");
     set_attention_waves(value);
     return 0;
   }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only
   return fail("tfx_set_option: unknown option '%s'", name);
 }
+
+int tfx_debug_attention_timing(void* buf) { set_attention_debug(buf); return 0; }  // bench-only, not in the header
 
 int tfx_prof_enable(int on) { prof_enable(on); return 0; }
 int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches) {

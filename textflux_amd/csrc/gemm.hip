@@ -242,12 +242,15 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
         asm volatile("" ::"v"(WF[kk]), "v"(xf[0][kk]), "v"(xf[1][kk]));  /* keep the fragment reads live */ \
       break;                                                                                              \
     }                                                                                                     \
-    __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    if (!(ABL & 256)) __builtin_amdgcn_s_setprio(1);                                                                        \
+    /* same-accumulator MFMAs back to back: D -> C forwarding of an accumulate chain costs no wait states, while an */ \
+    /* interleaved second accumulator exposes the write-back latency of the first on every other issue            */ \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
       acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
+    __builtin_amdgcn_sched_barrier(0); /* keep hipcc from re-interleaving the two chains */              \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
       acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
-    }                                                                                                     \
-    __builtin_amdgcn_s_setprio(0);                                                                        \
+    if (!(ABL & 256)) __builtin_amdgcn_s_setprio(0);                                                      \
   } while (0)
 #define WAIT_PREFETCH() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")  // all but the 5 newest sections landed
 
@@ -465,6 +468,8 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       case 16: return launch_ablation<16>(p, st);
       case 32: return launch_ablation<32>(p, st);
       case 128: return launch_ablation<128>(p, st);
+      case 256: return launch_ablation<256>(p, st);
+      case 263: return launch_ablation<263>(p, st);
       case 129: return launch_ablation<129>(p, st);
       case 135: return launch_ablation<135>(p, st);
       case 144: return launch_ablation<144>(p, st);

@@ -51,6 +51,7 @@ struct AttnArgs {
 };
 int joint_attention(const AttnArgs& a, hipStream_t st);
 void set_attention_ablation(int a);
+void set_attention_debug(void* p);
 void set_attention_waves(int nw);  // 8 (one 512-thread workgroup per CU) or 4 (two independent 256-thread workgroups)
 
 int ln_modulate(const void* x, void* out, const void* shift, const void* scale, int64_t mod_bstride,

@@ -67,7 +67,7 @@ def main():
             o = torch.empty(B, N, D, dtype=BF, device=dev)
             q, k, v = y[:, :, 2 * D:], y[:, :, :D], y[:, :, D:2 * D]
             fl = 4.0 * B * H * N * N * 128
-            for nw in (8, 4):
+            for nw in (16, 8):
                 ops.set_option("attention_waves", nw)
                 t = timeit(lambda: ops.attention(q, k, v, out=o))
                 emit(dict(tag=a.tag, kernel=f"attention(nw={nw})", B=B, N=N, ms=t * 1e3, tflops=fl / t / 1e12))
@@ -77,6 +77,7 @@ def main():
                 t = timeit(lambda: ops.attention(q, k, v, out=o))
                 emit(dict(tag=a.tag, kernel=f"attention[{nm}]", B=B, N=N, ms=t * 1e3, tflops=fl / t / 1e12))
             ops.set_option("attention_ablation", 0)
+            ops.set_option("attention_waves", 8)
             qh, kh, vh = (z.reshape(B, N, H, 128).transpose(1, 2) for z in (q, k, v))
             t2 = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(qh, kh, vh), iters=5)
             emit(dict(tag=a.tag, kernel="torch.sdpa", B=B, N=N, ms=t2 * 1e3, tflops=fl / t2 / 1e12))
