@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--sampler", choices=["euler", "amo"], default="euler")
     ap.add_argument("--layers", type=int, nargs=2, default=[19, 38], help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of per-step hipGraph replay")
     a = ap.parse_args()
 
     from textflux_amd import distributed as tdist
@@ -111,6 +112,7 @@ def main():
     pipe = FluxFillPipeline(scheduler=sch, vae=vae, text_encoder=None, tokenizer=None, text_encoder_2=None,
                             tokenizer_2=None, transformer=tr)
     pipe.set_progress_bar_config(disable=True)
+    pipe.enable_hip_graph(not a.no_graph)
 
     # ---- synthetic inputs, resident in HBM.  Conditioning is produced on rank 0 and broadcast over RCCL/xGMI
     g = torch.Generator().manual_seed(42)
@@ -169,7 +171,7 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init FLUX.1-Fill-architecture weights, random image, box mask, "
                                      "injected random prompt embeddings; text encoders bypassed)",
-            "config": {"workload": f"P1024: FluxFillPipeline.__call__ {H}x{W}, {n} {a.sampler} steps, guidance 30, "
+            "config": {"workload": f"{'P1024' if (H, W) == (1024, 1024) else f'{H}x{W}'}: FluxFillPipeline.__call__ {H}x{W}, {n} {a.sampler} steps, guidance 30, "
                                    f"batch {B}/GPU (S={S} image + 512 text tokens), VAE encode+decode included"
                                    + ("" if full else f" [REDUCED MODEL {a.layers} - not a valid headline]"),
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, conditioning broadcast over RCCL)"},

@@ -177,3 +177,31 @@ def test_lora_merge_matches_oracle_with_premerged_weights(tmp_path):
     e_m, e_0, delta = mae(got, ref_m), mae(got, ref_0), mae(ref_m, ref_0)
     print(f"LoRA: |got-merged| {e_m:.2e}  |got-unmerged| {e_0:.2e}  |merged-unmerged| {delta:.2e}")
     assert delta > 5 * e_m and e_0 > 3 * e_m and e_m < 2e-2 * ref_m.float().abs().mean().item()  # the merge is visible and lands on the merged oracle
+
+
+@pytest.mark.parametrize("sname", ["euler", "amo"])
+def test_hip_graph_replay_is_bit_identical_to_eager_loop(golden, sname):
+    """One captured step graph (device-side step cursor) replayed for steps 1..n-1 == the eager launch sequence."""
+    g = golden("g5_pipeline")
+    eps = [g[f"amo.eps{i}"] for i in range(4)] if sname == "amo" else None
+    kw = dict(prompt_embeds=g["prompt_embeds"].to(BF).cuda(), pooled_prompt_embeds=g["pooled"].to(BF).cuda(),
+              latents=g["latents"].to(BF).cuda(), masked_image_latents=g["masked_image_latents"].to(BF).cuda(),
+              height=128, width=128, num_inference_steps=4, guidance_scale=30.0, output_type="latent", amo_noise=eps)
+    pipe = make_pipe(sname)
+    eager = pipe(**kw).images
+    pipe.enable_hip_graph(True)
+    graphed = pipe(**kw).images          # captures
+    again = pipe(**kw).images            # re-uses the cached graph
+    assert torch.equal(eager, graphed) and torch.equal(eager, again)
+    assert mae(graphed, g[f"{sname}.bf16.final"]) < 1e-3
+
+
+def test_hip_graph_amo_internal_noise_runs():
+    pipe = make_pipe("amo").enable_hip_graph(True)
+    gi = torch.Generator().manual_seed(1)
+    out = pipe(prompt_embeds=torch.randn(1, 16, 64, generator=gi).to(BF).cuda(),
+               pooled_prompt_embeds=torch.randn(1, 32, generator=gi).to(BF).cuda(),
+               latents=torch.randn(1, 64, 64, generator=gi).to(BF).cuda(),
+               masked_image_latents=torch.randn(1, 64, 320, generator=gi).to(BF).cuda(), height=128, width=128,
+               num_inference_steps=5, guidance_scale=30.0, output_type="latent").images
+    assert torch.isfinite(out.float()).all() and out.float().std().item() > 0.1

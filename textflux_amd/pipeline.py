@@ -111,6 +111,7 @@ class FluxFillPipeline:
         self._progress_bar_config: Dict[str, Any] = {}
         self._device = transformer.device if transformer is not None else torch.device("cpu")
         self._guidance_scale, self._joint_attention_kwargs, self._num_timesteps, self._interrupt = None, None, 0, False
+        self._use_hip_graph = False
 
     # ------------------------------------------------------------------ loading / placement
     @classmethod
@@ -388,6 +389,8 @@ class FluxFillPipeline:
         is_amo = isinstance(sch, StochasticRFOvershotDiscreteScheduler)
         coef = sch.coef_table(dev, BF16)
         sch._step_index = 0 if sch.begin_index is None else sch.begin_index
+        if self._use_hip_graph and callback_on_step_end is None and n > 1 and sch._step_index == 0:
+            return self._graph_loop(ses, mod, latents, coef, is_amo, amo_noise, n, progress_bar)
         for i, t in enumerate(timesteps):
             if self._interrupt:
                 continue
@@ -411,6 +414,57 @@ class FluxFillPipeline:
                     ses.set_conditioning(prompt_embeds.to(dev, BF16), text_ids, latent_image_ids)
             progress_bar.update()
         return latents
+
+    def enable_hip_graph(self, on: bool = True):
+        """Replay ONE captured hipGraph per denoising step (device-side step cursor: modulation rows and scheduler
+        coefficients are selected by an int32 on the device, so the same graph serves every step).  Used when no
+        `callback_on_step_end` is given; results are bit-identical to the eager loop."""
+        self._use_hip_graph = bool(on)
+        return self
+
+    def _graph_loop(self, ses, mod, latents, coef, is_amo, amo_noise, n, progress_bar):
+        dev = latents.device
+        B = latents.shape[0]
+        gb = ses.graph_buffers(n, coef.numel(), latents.shape)
+        gb["mod_table"][:n].copy_(mod)
+        gb["coef"][:coef.numel()].copy_(coef.reshape(-1))
+        gb["lat"].copy_(latents)
+        gb["step"].zero_()
+        internal_noise = is_amo and amo_noise is None
+
+        def one_step():
+            ops.select_step_(gb["mod_table"], gb["mod_cur"], gb["step"])
+            v = ses.run(gb["mod_cur"])
+            if is_amo:
+                if internal_noise:
+                    gb["noise"].normal_()   # global device RNG, as the reference's randn_tensor(generator=None)
+                ops.amo_step_(v, gb["lat"], gb["coef"], gb["noise"], step_ptr=gb["step"], xin=ses.xin)
+            else:
+                ops.euler_step_(v, gb["lat"], gb["coef"], step_ptr=gb["step"], xin=ses.xin)
+            ops.advance_step_(gb["step"])
+
+        if is_amo and not internal_noise:
+            gb["noise"].copy_(amo_noise[0].to(dev, torch.float32))
+        one_step()                                   # eager step 0: also warms every kernel before capture
+        progress_bar.update()
+        key = (is_amo, internal_noise)
+        g = ses.graphs.get(key)
+        if g is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            saved = [gb[k].clone() for k in ("lat", "step")] + [ses.xin.clone()]
+            with torch.cuda.graph(g):
+                one_step()
+            # capture does not execute, but keep the state explicit in case a backend replays during instantiate
+            gb["lat"].copy_(saved[0]); gb["step"].copy_(saved[1]); ses.xin.copy_(saved[2])
+            ses.graphs[key] = g
+        for i in range(1, n):
+            if is_amo and not internal_noise:
+                gb["noise"].copy_(amo_noise[i].to(dev, torch.float32))
+            g.replay()
+            progress_bar.update()
+        self.scheduler._step_index = n
+        return gb["lat"].clone()
 
     def _generic_loop(self, latents, masked_image_latents, prompt_embeds, pooled, text_ids, latent_image_ids, timesteps,
                       guidance, callback_on_step_end, callback_tensor_inputs, progress_bar):

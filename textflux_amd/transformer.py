@@ -347,6 +347,8 @@ class DitSession:
         d.xin, d.ctx0 = self.xin.data_ptr(), self.ctx0.data_ptr()
         d.hid, d.xn, d.y, d.out = self.hid.data_ptr(), self.xn.data_ptr(), self.y.data_ptr(), self.out.data_ptr()
         d.first_block, d.last_block, d.flags = 0, -1, 0
+        self.graphs = {}
+        self._gb = None
 
     def set_conditioning(self, prompt_embeds: torch.Tensor, txt_ids: torch.Tensor, img_ids: torch.Tensor) -> None:
         """context_embedder(prompt_embeds) -> ctx0; RoPE tables for cat(txt_ids, img_ids)."""
@@ -360,6 +362,22 @@ class DitSession:
             self.cos, self.sin = cos.to(m.device), sin.to(m.device)
             self._ids_key = key
             self.desc.cos_tab, self.desc.sin_tab = self.cos.data_ptr(), self.sin.data_ptr()
+
+    def graph_buffers(self, n_steps: int, n_coef: int, lat_shape):
+        """Persistent device buffers a captured step graph points at (modulation table of all steps, the current
+        step's rows, scheduler coefficients, latent state, AMO noise, the int32 step cursor)."""
+        gb = self._gb
+        if gb is None or gb["mod_table"].shape[0] < n_steps or gb["coef"].numel() < n_coef:
+            dev = self.model.device
+            self.graphs = {}
+            gb = self._gb = dict(
+                mod_table=torch.empty(n_steps, self.B, self.model.mod_len, dtype=BF16, device=dev),
+                mod_cur=torch.empty(self.B, self.model.mod_len, dtype=BF16, device=dev),
+                coef=torch.zeros(max(n_coef, 3 * n_steps), dtype=torch.float32, device=dev),
+                lat=torch.empty(lat_shape, dtype=BF16, device=dev),
+                noise=torch.zeros(lat_shape, dtype=torch.float32, device=dev),
+                step=torch.zeros(1, dtype=torch.int32, device=dev))
+        return gb
 
     def run(self, mod: torch.Tensor, first_block: int = 0, last_block: int = -1, flags: int = 0) -> torch.Tensor:
         """One transformer forward with modulation rows `mod` [B, mod_len] (a view into a table is fine).
