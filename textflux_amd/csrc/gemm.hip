@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   bf16x8 xf[2][4], wlo[4], whi[4];
 
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
-#define MFMA8(WF, ROWBASE, NJ)                                                                            \
+#define MFMA8(WF, ROWBASE, NJ, MID)                                                                          \
   do {                                                                                                    \
     if (ABL & 16) {                                                                                       \
       _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
@@ -248,13 +248,20 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
       acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
     __builtin_amdgcn_sched_barrier(0); /* keep hipcc from re-interleaving the two chains */              \
+    MID;                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
       acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
     if (!(ABL & 256)) __builtin_amdgcn_s_setprio(0);                                                      \
   } while (0)
-#define WAIT_PREFETCH() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")  // all but the 5 newest sections landed
+// waits sit in the loads section: the 4 newest sections (8 loads; 10 with the old placement) may still be in flight
+#define WAIT_PREFETCH() do { if (ABL & 512) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
 
-#define BODY_STAGE(q, t) do { if (!(ABL & 1)) stage(q, t); } while (0)
+// The prefetch of a phase is issued BETWEEN the two accumulate chains of the wave's own MFMA section (ABL bit 9
+// = old placement, in the loads section): the texture path then works while the matrix pipe is busy and the loads
+// section -- the critical path of the partner group's MFMA slot -- carries only the fragment reads (+3 %).
+#define BODY_STAGE(q, t) do { if (!(ABL & 1) && (ABL & 512)) stage(q, t); } while (0)
+#define MID_STAGE(q, t) do { if (!(ABL & 1) && !(ABL & 512)) stage(q, t); } while (0)
 #define BODY_BARRIER() do { if (!(ABL & 4)) TFX_BARRIER(); } while (0)
   if (ABL & 2) {
 #pragma unroll
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     TACC(tw);
     BODY_BARRIER();
     TACC(tb1);
-    MFMA8(wlo, 0, 0);
+    MFMA8(wlo, 0, 0, MID_STAGE(0, u + 1));
     TACC(tm);
     BODY_BARRIER();
     TACC(tb2);
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     TACC(tw);
     BODY_BARRIER();
     TACC(tb1);
-    MFMA8(whi, 0, 1);
+    MFMA8(whi, 0, 1, MID_STAGE(1, u + 2));
     TACC(tm);
     BODY_BARRIER();
     TACC(tb2);
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     TACC(tw);
     BODY_BARRIER();
     TACC(tb1);
-    MFMA8(whi, 2, 1);
+    MFMA8(whi, 2, 1, MID_STAGE(2, u + 2));
     TACC(tm);
     BODY_BARRIER();
     TACC(tb2);
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     TACC(tw);
     BODY_BARRIER();
     TACC(tb1);
-    MFMA8(wlo, 2, 0);
+    MFMA8(wlo, 2, 0, MID_STAGE(3, u + 2));
     TACC(tm);
     BODY_BARRIER();
     TACC(tb2);
@@ -348,6 +355,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 #undef MFMA8
 #undef WAIT_PREFETCH
 #undef BODY_STAGE
+#undef MID_STAGE
 #undef BODY_BARRIER
 #undef TMARK
 #undef TACC
@@ -469,6 +477,7 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       case 32: return launch_ablation<32>(p, st);
       case 128: return launch_ablation<128>(p, st);
       case 256: return launch_ablation<256>(p, st);
+      case 512: return launch_ablation<512>(p, st);
       case 263: return launch_ablation<263>(p, st);
       case 129: return launch_ablation<129>(p, st);
       case 135: return launch_ablation<135>(p, st);

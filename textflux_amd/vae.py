@@ -52,7 +52,19 @@ class AutoencoderKL:
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], device="cuda", dtype=torch.bfloat16):
         self.sd = {k: v.to(device=device, dtype=dtype) for k, v in sd.items()}
+        if getattr(self, "_channels_last", False):
+            self.set_channels_last(True)
         self.dtype, self.device = dtype, torch.device(device)
+        return self
+
+    def set_channels_last(self, on: bool = True):
+        """NHWC activations + KRSC conv weights: MIOpen's bf16 implicit-GEMM kernels are NHWC-native; in NCHW it wraps
+        every convolution in layout transposes (visible as batched_transpose / Im2d2Col in profiles/r01_*)."""
+        self._channels_last = bool(on)
+        fmt = torch.channels_last if on else torch.contiguous_format
+        for k, v in self.sd.items():
+            if v.dim() == 4:
+                self.sd[k] = v.contiguous(memory_format=fmt)
         return self
 
     def init_random_(self, seed: int = 0, device="cuda", dtype=torch.bfloat16):
@@ -137,12 +149,18 @@ class AutoencoderKL:
 
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
-        post = DiagonalGaussianDistribution(self._encoder(x.to(self.device, self.dtype)))
+        x = x.to(self.device, self.dtype)
+        if getattr(self, "_channels_last", False):
+            x = x.contiguous(memory_format=torch.channels_last)
+        post = DiagonalGaussianDistribution(self._encoder(x))
         return SimpleNamespace(latent_dist=post) if return_dict else (post,)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None):
-        out = self._decoder(z.to(self.device, self.dtype))
+        z = z.to(self.device, self.dtype)
+        if getattr(self, "_channels_last", False):
+            z = z.contiguous(memory_format=torch.channels_last)
+        out = self._decoder(z)
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
     def _shapes(self):

@@ -42,6 +42,8 @@ probe("gemm8p no-prefetch", lambda: ops.gemm(x, w, b, out=out, variant=11))
 probe("gemm8p mfma-only", lambda: ops.gemm(x, w, b, out=out, variant=17))
 probe("gemm8p mfma-only no-setprio", lambda: ops.gemm(x, w, b, out=out, variant=273))
 probe("gemm8p full no-setprio", lambda: ops.gemm(x, w, b, out=out, variant=266))
+probe("gemm8p mfma-only, zero operands", lambda: ops.gemm(xz, wz, b, out=out, variant=17))
+probe("gemm8p no-prefetch, zero operands", lambda: ops.gemm(xz, wz, b, out=out, variant=11))
 probe("gemm8p full, zero operands", lambda: ops.gemm(xz, wz, b, out=out, variant=1))
 probe("hipBLASLt linear", lambda: torch.nn.functional.linear(x, w, b))
 probe("attention", lambda: ops.attention(y[:, :, 2 * D:], y[:, :, :D], y[:, :, D:2 * D], out=o))
