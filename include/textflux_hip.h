@@ -35,7 +35,7 @@ int tfx_query_arch(char* buf, int buflen);
  *      D/models/normalization.py:168, 200, 364; D/models/embeddings.py:1008-1021, 1926-1931).
  *      A [batch][M,K] (lda, a_bstride), W [N,K] nn.Linear layout (ldw), bias [N] or NULL, C [batch][M,N].
  *      epilogue: 0 bias | 1 bias, then tanh-GELU on columns >= gelu_from_col (activations.py:83; the split form is the
- *      fused [k|v|q|mlp] projection of FluxSingleTransformerBlock) | 2 C = res + gate[b,:] * (A@W^T + bias)
+ *      fused [k|v|q|mlp] projection of FluxSingleTransformerBlock) | 3 C = res + (A@W^T + bias) | 2 C = res + gate[b,:] * (A@W^T + bias)
  *      (gated residual, transformer_flux.py:733-735, 817-818, 824-826, 830-831, 837; res may alias C).
  *      variant: -1 auto, 0 generic FMA kernel (any shape), 1 MFMA kernel (K % 64 == 0, N % 8 == 0, 16-byte aligned). */
 typedef struct tfx_gemm_args {
@@ -140,6 +140,20 @@ typedef struct tfx_dit_desc {
   int32_t first_block, last_block, flags;
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
+
+/* ---- VAE ends (AutoencoderKL, D/models/autoencoders/autoencoder_kl.py:263-332) on NHWC bf16 activations -------------
+ * 3x3 convolution as an implicit GEMM on the MFMA kernel (ResnetBlock2D convs D/models/resnet.py:327-366, Upsample2D
+ * nearest-2x + conv D/models/upsampling.py:142-192 with up = 2, Downsample2D pad (0,1,0,1) stride 2
+ * D/models/downsampling.py:132-150 with stride = 2, pad_lo = 0).  x [B, inH, inW, Cin] (Cin % 64 == 0),
+ * w [Cout, 3, 3, Cin] (KRSC), out [B, H, W, Cout] = conv(x) + bias (+ res when res != NULL; may alias out),
+ * zero_page: >= 128 bytes of zeros (source of out-of-image taps).  variant: -1 auto, 0 generic, 1 MFMA. */
+int tfx_conv3x3_nhwc(const void* x, int32_t B, int32_t inH, int32_t inW, int32_t Cin, const void* w, const void* bias,
+                     void* out, int32_t H, int32_t W, int32_t Cout, int32_t stride, int32_t up, int32_t pad_lo,
+                     const void* res, const void* zero_page, int variant, tfx_stream stream);
+/* GroupNorm(groups, eps, affine) followed by SiLU when silu != 0, x/out [B, HW, C] NHWC.  workspace: fp32
+ * [B * (ceil(HW/1024) + 1) * groups * 2]. */
+int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* workspace, int32_t B,
+                       int64_t HW, int32_t C, int32_t groups, float eps, int32_t silu, tfx_stream stream);
 
 /* ---- tuning knobs (no reference counterpart).  "attention_waves": 8 = one 512-thread workgroup of 256 query rows per
  *      CU, 4 = two independent 256-thread workgroups of 128 query rows per CU. */

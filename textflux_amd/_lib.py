@@ -92,6 +92,10 @@ SIGNATURES = {
     "tfx_select_step": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "tfx_advance_step": (c_int, [c_void_p, c_void_p]),
     "tfx_dit_forward": (c_int, [C.POINTER(DitDesc), c_void_p]),
+    "tfx_conv3x3_nhwc": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                 c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int, c_void_p]),
+    "tfx_groupnorm_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
+                                   c_float, c_int32, c_void_p]),
     "tfx_set_option": (c_int, [c_char_p, c_int]),
     "tfx_prof_enable": (c_int, [c_int]),
     "tfx_prof_collect": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),

@@ -228,6 +228,28 @@ int tfx_advance_step(int32_t* step_ptr, tfx_stream stream) {
   return advance_step(step_ptr, S(stream));
 }
 
+int tfx_conv3x3_nhwc(const void* x, int32_t B, int32_t inH, int32_t inW, int32_t Cin, const void* w, const void* bias,
+                     void* out, int32_t H, int32_t W, int32_t Cout, int32_t stride, int32_t up, int32_t pad_lo,
+                     const void* res, const void* zero_page, int variant, tfx_stream stream) {
+  if (!x || !w || !out || !zero_page) return fail("tfx_conv3x3_nhwc: null pointer");
+  if (up != 1 && up != 2) return fail("tfx_conv3x3_nhwc: up must be 1 or 2");
+  GemmArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.A = x; a.lda = Cin; a.W = w; a.ldw = 9 * (int64_t)Cin; a.bias = bias;
+  a.C = out; a.ldc = Cout; a.M = B * H * W; a.N = Cout; a.K = 9 * Cin; a.batch = 1;
+  a.epilogue = res ? EPI_BIAS_RES : EPI_BIAS;
+  a.res = res; a.ldr = Cout;
+  a.conv_cin = Cin; a.conv_inH = inH; a.conv_inW = inW; a.conv_H = H; a.conv_W = W;
+  a.conv_stride = stride; a.conv_up_shift = up == 2 ? 1 : 0; a.conv_pad_lo = pad_lo; a.zero_page = zero_page;
+  return variant < 0 ? gemm_bf16(a, S(stream)) : gemm_bf16_variant(a, variant, S(stream));
+}
+
+int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* workspace, int32_t B,
+                       int64_t HW, int32_t C, int32_t groups, float eps, int32_t silu, tfx_stream stream) {
+  if (!x || !out || !gamma || !beta || !workspace) return fail("tfx_groupnorm_nhwc: null pointer");
+  return groupnorm_silu_nhwc(x, out, gamma, beta, workspace, B, HW, C, groups, eps, silu != 0, S(stream));
+}
+
 int tfx_set_option(const char* name, int value) {
   if (!name) return fail("tfx_set_option: null name");
   if (!std::strcmp(name, "attention_waves")) {

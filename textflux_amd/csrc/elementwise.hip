@@ -215,6 +215,78 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
       *reinterpret_cast<const u32x4*>(src + b * sbs + (int64_t)r * sld + c * 8);
 }
 
+// ---------------------------------------------------------------------------------------------
+// GroupNorm(groups, eps, affine) [+ SiLU] on NHWC activations x [B, HW, C] (VAE blocks: ResnetBlock2D norm1/norm2,
+// D/models/resnet.py:327-366; conv_norm_out, D/models/autoencoders/vae.py:191-193, 352-354; mid-block attention
+// group_norm, D/models/attention_processor.py:2824).  Three kernels: per-chunk partial sums (deterministic, no
+// atomics across blocks) -> per-(batch, group) mean / rstd -> normalise (+SiLU), 16 B per lane.
+constexpr int GN_CHUNK_PIX = 1024;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
+                                                         int64_t HW, int C, int groups, int nchunk) {
+  __shared__ float acc[64][2];
+  const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  if (tid < 128) acc[tid >> 1][tid & 1] = 0.f;
+  __syncthreads();
+  const int cpr = C >> 3;                       // 16-byte chunks per pixel
+  const int cpg = C / groups;                   // channels per group: 4, 8 or 16
+  const int64_t p0 = (int64_t)ch * GN_CHUNK_PIX;
+  const int64_t p1 = min(HW, p0 + GN_CHUNK_PIX);
+  const int c8 = tid % cpr;
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;  // two 4-channel halves of this lane's chunk
+  for (int64_t p = p0 + tid / cpr; p < p1; p += 256 / cpr) {
+    float v[8];
+    unpack8(*reinterpret_cast<const u32x4*>(x + ((int64_t)b * HW + p) * C + c8 * 8), v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s0 += v[i]; q0 += v[i] * v[i]; s1 += v[4 + i]; q1 += v[4 + i] * v[4 + i]; }
+  }
+  const int g0 = (c8 * 8) / cpg, g1 = (c8 * 8 + 4) / cpg;
+  atomicAdd(&acc[g0][0], s0); atomicAdd(&acc[g0][1], q0);
+  atomicAdd(&acc[g1][0], s1); atomicAdd(&acc[g1][1], q1);
+  __syncthreads();
+  if (tid < 2 * groups) part[(((int64_t)b * nchunk + ch) * groups + (tid >> 1)) * 2 + (tid & 1)] = acc[tid >> 1][tid & 1];
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, int nchunk, int groups,
+                                   float inv_count, float eps) {
+  const int b = blockIdx.x, g = threadIdx.x;
+  if (g >= groups) return;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    s += part[(((int64_t)b * nchunk + c) * groups + g) * 2];
+    q += part[(((int64_t)b * nchunk + c) * groups + g) * 2 + 1];
+  }
+  const double mean = s * inv_count, var = q * inv_count - mean * mean;
+  stat[(b * groups + g) * 2] = (float)mean;
+  stat[(b * groups + g) * 2 + 1] = rsqrtf((float)(var > 0 ? var : 0) + eps);
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                       const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                       const float* __restrict__ stat, int64_t HW, int C, int groups,
+                                                       int64_t total_chunks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total_chunks) return;
+  const int cpr = C >> 3, cpg = C / groups;
+  const int c8 = (int)(i % cpr);
+  const int64_t pix = i / cpr;
+  const int b = (int)(pix / HW);
+  float v[8], ga[8], be[8], o[8];
+  unpack8(*reinterpret_cast<const u32x4*>(x + i * 8), v);
+  unpack8(*reinterpret_cast<const u32x4*>(gamma + c8 * 8), ga);
+  unpack8(*reinterpret_cast<const u32x4*>(beta + c8 * 8), be);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = (c8 * 8 + e) / cpg;
+    const float mean = stat[(b * groups + g) * 2], rstd = stat[(b * groups + g) * 2 + 1];
+    float y = round_bf((v[e] - mean) * rstd * ga[e] + be[e]);   // F.group_norm output in bf16
+    if (SILU) y = y / (1.0f + __expf(-y));
+    o[e] = y;
+  }
+  *reinterpret_cast<u32x4*>(out + i * 8) = pack8(o);
+}
+
 // Device-side step cursor for graph replay: cur_mod[b, :] = mod_table[*step, b, :]; optionally ++*step.
 __global__ __launch_bounds__(256) void select_step_kernel(const bf16_t* __restrict__ table, bf16_t* __restrict__ cur,
                                                           int64_t per_step_chunks, int* step_ptr, int advance) {
@@ -301,6 +373,24 @@ int copy_rows(const void* src, int64_t sld, int64_t sbs, void* dst, int64_t dld,
   copy_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>((const bf16_t*)src, sld, sbs, (bf16_t*)dst, dld,
                                                                           dbs, rows, cols / 8, total);
   return check_launch("copy_rows");
+}
+int groupnorm_silu_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* ws, int B, int64_t HW,
+                        int C, int groups, float eps, bool silu, hipStream_t st) {
+  if (C % 8 || groups > 64 || C % groups || (C / groups) % 4 || 256 % (C / 8)) return fail("groupnorm: unsupported C / groups");
+  const int nchunk = (int)((HW + GN_CHUNK_PIX - 1) / GN_CHUNK_PIX);
+  float* part = ws;                                   // [B, nchunk, groups, 2]
+  float* stat = ws + (int64_t)B * nchunk * groups * 2; // [B, groups, 2]
+  gn_partial_kernel<<<dim3(nchunk, B), 256, 0, st>>>((const bf16_t*)x, part, HW, C, groups, nchunk);
+  gn_finalize_kernel<<<B, 64, 0, st>>>(part, stat, nchunk, groups, 1.0f / ((float)HW * (C / groups)), eps);
+  const int64_t total = (int64_t)B * HW * (C / 8);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (silu)
+    gn_apply_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)out, (const bf16_t*)gamma, (const bf16_t*)beta,
+                                                stat, HW, C, groups, total);
+  else
+    gn_apply_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)out, (const bf16_t*)gamma, (const bf16_t*)beta,
+                                                 stat, HW, C, groups, total);
+  return check_launch("groupnorm_silu_nhwc");
 }
 int select_step(const void* table, void* cur, int64_t per_step_elems, int* step_ptr, hipStream_t st) {
   if (per_step_elems % 8) return fail("select_step: per-step size must be a multiple of 8 elements");

@@ -34,6 +34,8 @@ struct GemmParams {
   int gelu_from;
   const bf16_t* gate; int64_t gate_bs;
   const bf16_t* res; int64_t ldr, r_bs;
+  int cin, inH, inW, oH, oW, cstride, cup, cpad;   // implicit 3x3 convolution (cin > 0), see GemmArgs
+  const bf16_t* zero;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -53,7 +55,19 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
       const int r = i >> 4, c = i & 15;
       const int m = m0 + r, n = n0 + r, k = k0 + c;
-      As[c][r] = (m < p.M && k < p.K) ? bf2f(A[(int64_t)m * p.lda + k]) : 0.f;
+      float av = 0.f;
+      if (m < p.M && k < p.K) {
+        if (p.cin > 0) {
+          const int tap = k / p.cin, ci = k - tap * p.cin, dy = tap / 3, dx = tap - 3 * dy;
+          const int pix = m % (p.oH * p.oW), bb = m / (p.oH * p.oW), y = pix / p.oW, x = pix - y * p.oW;
+          const int yy = y * p.cstride - p.cpad + dy, xx = x * p.cstride - p.cpad + dx;
+          if (yy >= 0 && xx >= 0 && yy < (p.inH << p.cup) && xx < (p.inW << p.cup))
+            av = bf2f(A[((int64_t)(bb * p.inH + (yy >> p.cup)) * p.inW + (xx >> p.cup)) * p.cin + ci]);
+        } else {
+          av = bf2f(A[(int64_t)m * p.lda + k]);
+        }
+      }
+      As[c][r] = av;
       Ws[c][r] = (n < p.N && k < p.K) ? bf2f(p.W[(int64_t)n * p.ldw + k]) : 0.f;
     }
     __syncthreads();
@@ -84,6 +98,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
         const float r = bf2f(p.res[b * p.r_bs + (int64_t)m * p.ldr + n]);
         v = r + round_bf(g * round_bf(v));
       }
+      if (EPI == EPI_BIAS_RES) v = bf2f(p.res[b * p.r_bs + (int64_t)m * p.ldr + n]) + round_bf(v);
       p.C[b * p.c_bs + (int64_t)m * p.ldc + n] = f2bf(v);
     }
   }
@@ -116,7 +131,7 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* smem, uint32_t lds
 
 // ABL (bench-only ablations, never dispatched by the product path): bit0 no prefetch in the main loop, bit1 no LDS
 // fragment reads, bit2 no barriers.  ABL = 0 is the real kernel.
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -156,7 +171,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   // rate) before its first reader.  Every lane issues 2 x 16-byte loads per item; piece = 8 consecutive LDS rows
   // written by one wave instruction.
   const int lr = lane >> 3, cphys = lane & 7;
-  int goff[4][2];        // per-lane element offset from Xb / Wb (without the k offset)
+  int goff[4][2];        // per-lane element offset from Xb / Wb (without the k offset); CONV X items: chunk offset
+  int cpix[4][2], cyx[4][2];  // CONV X items: first pixel of the row's image, packed (iy0 + 1) << 16 | (ix0 + 1)
   uint32_t ldst[4][2];   // wave-uniform LDS byte offset inside set 0 of the destination tile
   bool isx[4];
 #pragma unroll
@@ -177,10 +193,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       const int row = row0 + lr;
       const int key = (row >> 1) & 7;
       const int clog = cphys ^ key;
+      cpix[q][j] = 0; cyx[q][j] = 0;
       if (x_item) {
         int grow = g * 128 + row;  // each group stages its own half of the X tile
         if (m0 + grow > p.M - 1) grow = p.M - 1 - m0;
-        goff[q][j] = grow * (int)p.lda + clog * 8;
+        if (CONV) {
+          const int m = m0 + grow, hw = p.oH * p.oW;
+          const int bb = m / hw, pix = m - bb * hw, y = pix / p.oW, x = pix - y * p.oW;
+          cpix[q][j] = bb * p.inH * p.inW;
+          cyx[q][j] = ((y * p.cstride - p.cpad + 1) << 16) | (x * p.cstride - p.cpad + 1);
+          goff[q][j] = clog * 8;
+        } else {
+          goff[q][j] = grow * (int)p.lda + clog * 8;
+        }
         ldst[q][j] = LDS_X + g * 32768 + row0 * 128;
       } else {
         int grow = row;
@@ -198,6 +223,20 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     const bf16_t* base = (isx[q] ? Xb : Wb) + (int64_t)kt * 64;
     const uint32_t setoff = (tile & 1) * (isx[q] ? 16384u : 32768u);
     constexpr int kAux = ((ABL >> 5) & 3) == 1 ? 16 : ((ABL >> 5) & 3) == 2 ? 2 : ((ABL >> 5) & 3) == 3 ? 1 : GLDS_AUX;
+    if (CONV && isx[q]) {
+      // K index -> (tap, channel block): a 64-wide K-tile never straddles a tap because Cin % 64 == 0
+      const int k0 = kt * 64, tap = k0 / p.cin, ci0 = k0 - tap * p.cin, dy = tap / 3, dx = tap - 3 * dy;
+      const int vh = p.inH << p.cup, vw = p.inW << p.cup;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int yy = (cyx[q][j] >> 16) - 1 + dy, xx = (cyx[q][j] & 0xffff) - 1 + dx;
+        const bool inside = (unsigned)yy < (unsigned)vh && (unsigned)xx < (unsigned)vw;
+        const bf16_t* src = inside ? p.A + ((int64_t)(cpix[q][j] + (yy >> p.cup) * p.inW + (xx >> p.cup)) * p.cin + ci0 + goff[q][j])
+                                   : p.zero + goff[q][j];
+        glds16<kAux>(src, smem, ok ? ldst[q][j] + setoff : dummy);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) glds16<kAux>(base + goff[q][j], smem, ok ? ldst[q][j] + setoff : dummy);
   };
@@ -416,7 +455,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       const int m = m0 + g * 128 + row;
       if (m >= p.M) continue;
       u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * EPI_ROW_BYTES + cchunk * 16);
-      if (EPI == EPI_BIAS_GATE_RES) {
+      if (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES) {
         const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + nst);
         float fv[8], fr[8];
         unpack8(val, fv);
@@ -442,16 +481,25 @@ static GemmParams make_params(const GemmArgs& a) {
   p.gelu_from = a.gelu_from_col;
   p.gate = (const bf16_t*)a.gate; p.gate_bs = a.gate_bstride;
   p.res = (const bf16_t*)a.res; p.ldr = a.ldr; p.r_bs = a.r_bstride;
+  p.cin = a.conv_cin; p.inH = a.conv_inH; p.inW = a.conv_inW; p.oH = a.conv_H; p.oW = a.conv_W;
+  p.cstride = a.conv_stride; p.cup = a.conv_up_shift; p.cpad = a.conv_pad_lo; p.zero = (const bf16_t*)a.zero_page;
   return p;
 }
 
+static bool conv_ok(const GemmArgs& a) {
+  return a.conv_cin % 64 == 0 && a.K == 9 * a.conv_cin && a.batch == 1 && a.zero_page && (uintptr_t)a.zero_page % 16 == 0 &&
+         a.conv_H > 0 && a.conv_W > 0 && (a.conv_inH << a.conv_up_shift) < 32768 && (a.conv_inW << a.conv_up_shift) < 32768 &&
+         (int64_t)a.M * 1 == (int64_t)a.conv_H * a.conv_W * (a.M / (a.conv_H * a.conv_W)) && a.M % (a.conv_H * a.conv_W) == 0;
+}
+
 static bool fast_ok(const GemmArgs& a) {
+  if (a.conv_cin > 0 && !conv_ok(a)) return false;
   const bool al16 = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.C % 16 == 0) &&
                     ((uintptr_t)a.bias % 8 == 0);
   return a.K % 64 == 0 && a.K >= 64 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0 &&
          a.a_bstride % 8 == 0 && a.c_bstride % 8 == 0 && al16 && (int64_t)255 * a.lda < (1ll << 31) &&
          (int64_t)255 * a.ldw < (1ll << 31) &&
-         (a.epilogue != EPI_BIAS_GATE_RES || (a.ldr % 8 == 0 && a.r_bstride % 8 == 0 && a.gate_bstride % 4 == 0 &&
+         ((a.epilogue != EPI_BIAS_GATE_RES && a.epilogue != EPI_BIAS_RES) || (a.ldr % 8 == 0 && a.r_bstride % 8 == 0 && a.gate_bstride % 4 == 0 &&
                                               (uintptr_t)a.res % 16 == 0 && (uintptr_t)a.gate % 8 == 0)) &&
          (a.epilogue != EPI_BIAS_GELU || a.gelu_from_col % 256 == 0);
 }
@@ -490,21 +538,25 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
     return fail("gemm: unknown ablation");
   }
   if (variant == 1) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    const bool conv = p.cin > 0;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[conv]) {
+      const void* fn = conv ? (const void*)gemm8p_kernel<EPI, 0, true> : (const void*)gemm8p_kernel<EPI, 0, false>;
       hipFuncAttributes fa;  // forces the (lazily loaded) code object in before the attribute is set
-      (void)hipFuncGetAttributes(&fa, (const void*)gemm8p_kernel<EPI>);
+      (void)hipFuncGetAttributes(&fa, fn);
       (void)hipGetLastError();
-      const hipError_t e = hipFuncSetAttribute((const void*)gemm8p_kernel<EPI>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
       if (e != hipSuccess)
         return fail("gemm: cannot raise dynamic LDS limit to %d bytes: %s", LDS_TOTAL, hipGetErrorString(e));
-      attr_set = true;
+      attr_set[conv] = true;
     }
     const unsigned grid = (unsigned)(p.batch * p.tm * p.tn);
-    const bool prof = prof_on();
+    const bool prof = prof_on() && !conv;
     if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
-    gemm8p_kernel<EPI><<<grid, 512, LDS_TOTAL, st>>>(p);
+    if (conv)
+      gemm8p_kernel<EPI, 0, true><<<grid, 512, LDS_TOTAL, st>>>(p);
+    else
+      gemm8p_kernel<EPI, 0, false><<<grid, 512, LDS_TOTAL, st>>>(p);
     if (prof) prof_end(0, st);
   } else {
     dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch);
@@ -518,11 +570,13 @@ int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
   if (a.K <= 0) return fail("gemm: K must be positive");
   if (variant >= 1 && !fast_ok(a)) return fail("gemm: shape/alignment not supported by the MFMA kernel");
   if (a.epilogue == EPI_BIAS_GATE_RES && (!a.gate || !a.res)) return fail("gemm: gate/res pointers required");
+  if (a.epilogue == EPI_BIAS_RES && !a.res) return fail("gemm: res pointer required");
   const GemmParams p = make_params(a);
   switch (a.epilogue) {
     case EPI_BIAS: return launch_variant<EPI_BIAS>(p, variant, st);
     case EPI_BIAS_GELU: return launch_variant<EPI_BIAS_GELU>(p, variant, st);
     case EPI_BIAS_GATE_RES: return launch_variant<EPI_BIAS_GATE_RES>(p, variant, st);
+    case EPI_BIAS_RES: return launch_variant<EPI_BIAS_RES>(p, variant, st);
   }
   return fail("gemm: unknown epilogue %d", a.epilogue);
 }

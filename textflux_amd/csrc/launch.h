@@ -25,6 +25,7 @@ enum Epilogue : int {
   EPI_BIAS = 0,           // C = acc + bias
   EPI_BIAS_GELU = 1,      // C = gelu_tanh(acc + bias) for columns >= gelu_from_col, plain bias below it
   EPI_BIAS_GATE_RES = 2,  // C = res + gate[b, col] * (acc + bias)
+  EPI_BIAS_RES = 3,       // C = res + (acc + bias)   (VAE residual blocks)
 };
 
 struct GemmArgs {
@@ -38,6 +39,12 @@ struct GemmArgs {
   int gelu_from_col;                                  // EPI_BIAS_GELU: first column that gets GELU
   const void* gate; int64_t gate_bstride;             // EPI_BIAS_GATE_RES: gate [batch][N] bf16
   const void* res; int64_t ldr; int64_t r_bstride;    // residual [batch][M, N] bf16 (may alias C)
+  // implicit-GEMM 3x3 convolution on NHWC activations (conv_cin > 0): A = input [B, inH, inW, Cin], row m = output pixel
+  // (b, y, x) of an H x W grid, K = 9 * Cin ordered (tap, ci); the input is read at ((y*stride - pad_lo + dy) >> up_shift,
+  // (x*stride - pad_lo + dx) >> up_shift) -- up_shift = 1 folds a nearest 2x upsample into the gather -- and taps that
+  // fall outside the (upsampled) input read `zero_page` (>= 128 B of zeros) instead.
+  int conv_cin = 0, conv_inH = 0, conv_inW = 0, conv_H = 0, conv_W = 0, conv_stride = 1, conv_up_shift = 0, conv_pad_lo = 1;
+  const void* zero_page = nullptr;
 };
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
@@ -54,6 +61,8 @@ void set_attention_ablation(int a);
 void set_attention_debug(void* p);
 void set_attention_waves(int nw);  // 8 (one 512-thread workgroup per CU) or 4 (two independent 256-thread workgroups)
 
+int groupnorm_silu_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* stats_ws, int B,
+                        int64_t HW, int C, int groups, float eps, bool silu, hipStream_t st);
 int ln_modulate(const void* x, void* out, const void* shift, const void* scale, int64_t mod_bstride,
                 int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldo,
                 int64_t o_bstride, float eps, hipStream_t st);

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib as L
 
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES = 0, 1, 2
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES, EPI_BIAS_RES = 0, 1, 2, 3
 BF16 = torch.bfloat16
 
 
@@ -58,10 +58,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     g.C, g.ldc, g.c_bstride = cp, ldc, cbs
     g.M, g.N, g.K, g.batch = M, N, K, batch
     g.epilogue, g.gelu_from_col = epilogue, gelu_from_col
-    if epilogue == EPI_BIAS_GATE_RES:
-        assert gate is not None and res is not None and gate.stride(-1) == 1
-        g.gate = gate.data_ptr()
-        g.gate_bstride = gate.stride(0) if gate.dim() == 2 else 0
+    if epilogue in (EPI_BIAS_GATE_RES, EPI_BIAS_RES):
+        assert res is not None
+        if epilogue == EPI_BIAS_GATE_RES:
+            assert gate is not None and gate.stride(-1) == 1
+            g.gate = gate.data_ptr()
+            g.gate_bstride = gate.stride(0) if gate.dim() == 2 else 0
         rp, ldr, rbs, _, _ = _rows_view(res)
         g.res, g.ldr, g.r_bstride = rp, ldr, rbs
     L.check(L.lib().tfx_gemm_bf16(C.byref(g), variant, _stream()), "gemm")
@@ -202,3 +204,49 @@ def prof_collect(kind: int):
 
 def set_option(name: str, value: int) -> None:
     L.check(L.lib().tfx_set_option(name.encode(), int(value)), "set_option")
+
+
+_ZERO_PAGE = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    z = _ZERO_PAGE.get(str(device))
+    if z is None:
+        z = _ZERO_PAGE[str(device)] = torch.zeros(256, dtype=BF16, device=device)
+    return z
+
+
+def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, up: int = 1,
+                 pad_lo: int = 1, res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 variant: int = -1) -> torch.Tensor:
+    """x [B, inH, inW, Cin] NHWC bf16, w [Cout, 3, 3, Cin] (KRSC) -> [B, H, W, Cout].  up = 2 folds a nearest 2x upsample
+    into the gather; stride = 2, pad_lo = 0 is the VAE downsample (pad (0,1,0,1))."""
+    _chk_dev(x, w, bias, res, out)
+    assert x.is_contiguous() and w.is_contiguous() and x.dtype == BF16
+    B, inH, inW, Cin = x.shape
+    Cout = w.shape[0]
+    if stride == 1:
+        H, W = inH * up, inW * up
+    else:
+        H, W = (inH * up + pad_lo + 1 - 3) // stride + 1, (inW * up + pad_lo + 1 - 3) // stride + 1
+    if out is None:
+        out = torch.empty(B, H, W, Cout, dtype=BF16, device=x.device)
+    L.check(L.lib().tfx_conv3x3_nhwc(x.data_ptr(), B, inH, inW, Cin, w.data_ptr(), _p(bias), out.data_ptr(), H, W, Cout,
+                                     stride, up, pad_lo, _p(res), zero_page(x.device).data_ptr(), variant, _stream()),
+            "conv3x3_nhwc")
+    return out
+
+
+def groupnorm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, silu: bool = True,
+                   eps: float = 1e-6, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B, ..., C] NHWC bf16 -> GroupNorm(+SiLU)."""
+    _chk_dev(x, gamma, beta, out)
+    assert x.is_contiguous() and x.dtype == BF16
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    if out is None:
+        out = torch.empty_like(x)
+    ws = torch.empty(B * ((HW + 1023) // 1024 + 1) * groups * 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tfx_groupnorm_nhwc(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), B,
+                                       HW, C, groups, eps, 1 if silu else 0, _stream()), "groupnorm_nhwc")
+    return out

@@ -1,10 +1,14 @@
 """FLUX AutoencoderKL for the two ends of the path (masked-image encode, final decode).
 
 Reference: AutoencoderKL.encode/decode D/models/autoencoders/autoencoder_kl.py:263-332 and the blocks cited in
-oracle/vae_oracle.py.  STATUS (DESIGN.md "what comes next"): < 1 % of the image's FLOPs; in this
-round the convolutions / GroupNorms run through PyTorch-ROCm (MIOpen) on the device -- they are NOT hand-written HIP
-kernels yet, and no performance claim is made for them.  Weights use the reference's state-dict keys, so the HF
-`vae/diffusion_pytorch_model.safetensors` loads as is.
+oracle/vae_oracle.py.  Two execution paths over the same weights (reference state-dict keys, so the HF
+`vae/diffusion_pytorch_model.safetensors` loads as is):
+* HIP / NHWC (default whenever every block width is a multiple of 64, i.e. the FLUX VAE 128/256/512): activations stay
+  NHWC bf16; every 3x3 convolution is an implicit GEMM on the MFMA kernel (`tfx_conv3x3_nhwc`: nearest-2x upsample and
+  the (0,1,0,1)-padded stride-2 downsample are folded into its gather, the residual add into its epilogue), GroupNorm+SiLU
+  is `tfx_groupnorm_nhwc`, 1x1 shortcuts and the mid-block attention projections are plain `tfx_gemm_bf16` calls.  Still
+  through torch: conv_in (3 or 16 input channels), the single-head dim-512 mid-block softmax (F.scaled_dot_product_attention).
+* torch / NCHW (tiny test configurations whose widths are not multiples of 64): F.conv2d / F.group_norm via MIOpen.
 """
 from __future__ import annotations
 
@@ -49,22 +53,12 @@ class AutoencoderKL:
                               scaling_factor=scaling_factor, shift_factor=shift_factor)
         self.sd: Dict[str, torch.Tensor] = {}
         self.dtype, self.device = torch.bfloat16, torch.device("cpu")
+        self.use_hip, self.hw = False, {}
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], device="cuda", dtype=torch.bfloat16):
         self.sd = {k: v.to(device=device, dtype=dtype) for k, v in sd.items()}
-        if getattr(self, "_channels_last", False):
-            self.set_channels_last(True)
         self.dtype, self.device = dtype, torch.device(device)
-        return self
-
-    def set_channels_last(self, on: bool = True):
-        """NHWC activations + KRSC conv weights: MIOpen's bf16 implicit-GEMM kernels are NHWC-native; in NCHW it wraps
-        every convolution in layout transposes (visible as batched_transpose / Im2d2Col in profiles/r01_*)."""
-        self._channels_last = bool(on)
-        fmt = torch.channels_last if on else torch.contiguous_format
-        for k, v in self.sd.items():
-            if v.dim() == 4:
-                self.sd[k] = v.contiguous(memory_format=fmt)
+        self._prep_hip()
         return self
 
     def init_random_(self, seed: int = 0, device="cuda", dtype=torch.bfloat16):
@@ -97,6 +91,86 @@ class AutoencoderKL:
         if self.sd and (device is not None or dtype is not None):
             self.load_state_dict(self.sd, device or self.device, dtype or self.dtype)
         return self
+
+    # ---- HIP / NHWC path ---------------------------------------------------------------------------------------
+    def _prep_hip(self):
+        c = self.config
+        cpg_ok = all((ch // c.norm_num_groups) % 4 == 0 and 256 % (ch // 8) == 0 for ch in c.block_out_channels)
+        self.use_hip = (self.device.type == "cuda" and self.dtype == torch.bfloat16 and cpg_ok
+                        and all(ch % 64 == 0 for ch in c.block_out_channels))
+        self.hw: Dict[str, torch.Tensor] = {}
+        if not self.use_hip:
+            return
+        for k, v in self.sd.items():
+            if k.endswith(".weight") and v.dim() == 4:
+                if v.shape[2] == 3 and v.shape[1] % 64 == 0:
+                    w = v.permute(0, 2, 3, 1).contiguous()                   # [Cout, 3, 3, Cin]  (KRSC)
+                    if w.shape[0] % 8:                                       # conv_out: pad Cout 3 -> 8 (zero filters)
+                        pad = 8 - w.shape[0] % 8
+                        w = torch.cat([w, torch.zeros(pad, *w.shape[1:], dtype=w.dtype, device=w.device)], 0)
+                        b = self.sd[k[:-7] + ".bias"]
+                        self.hw[k[:-7] + ".bias"] = torch.cat([b, torch.zeros(pad, dtype=b.dtype, device=b.device)], 0)
+                    self.hw[k] = w
+                elif v.shape[2] == 1:
+                    self.hw[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()   # 1x1 shortcut as a matrix
+
+    def _hconv(self, x, name, **kw):
+        from . import ops
+        return ops.conv3x3_nhwc(x, self.hw[name + ".weight"], self.hw.get(name + ".bias", self.sd[name + ".bias"]), **kw)
+
+    def _hgn(self, x, name, silu=True):
+        from . import ops
+        return ops.groupnorm_nhwc(x, self.sd[name + ".weight"], self.sd[name + ".bias"], self.config.norm_num_groups, silu=silu)
+
+    def _hres(self, x, p):
+        from . import ops
+        h = self._hconv(self._hgn(x, p + ".norm1"), p + ".conv1")
+        h = self._hgn(h, p + ".norm2")
+        if p + ".conv_shortcut.weight" in self.sd:
+            B, H, W, C = x.shape
+            x = ops.gemm(x.view(B * H * W, C), self.hw[p + ".conv_shortcut.weight"], self.sd[p + ".conv_shortcut.bias"]).view(B, H, W, -1)
+        return self._hconv(h, p + ".conv2", res=x)
+
+    def _hmid(self, x, p):
+        from . import ops
+        x = self._hres(x, p + ".resnets.0")
+        B, H, W, C = x.shape
+        a = p + ".attentions.0"
+        tok = x.view(B, H * W, C)
+        h = self._hgn(tok, a + ".group_norm", silu=False)
+        q, k, v = (ops.gemm(h, self.sd[f"{a}.{n}.weight"], self.sd[f"{a}.{n}.bias"]) for n in ("to_q", "to_k", "to_v"))
+        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0].contiguous()   # one head of dim C
+        x = ops.gemm(o, self.sd[a + ".to_out.0.weight"], self.sd[a + ".to_out.0.bias"], epilogue=ops.EPI_BIAS_RES,
+                     res=tok).view(B, H, W, C)
+        return self._hres(x, p + ".resnets.1")
+
+    def _encoder_hip(self, x):
+        c = self.config
+        h = F.conv2d(x, self.sd["encoder.conv_in.weight"], self.sd["encoder.conv_in.bias"], padding=1)
+        h = h.permute(0, 2, 3, 1).contiguous()
+        n = len(c.block_out_channels)
+        for i in range(n):
+            for j in range(c.layers_per_block):
+                h = self._hres(h, f"encoder.down_blocks.{i}.resnets.{j}")
+            if i != n - 1:
+                h = self._hconv(h, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, pad_lo=0)
+        h = self._hmid(h, "encoder.mid_block")
+        h = self._hconv(self._hgn(h, "encoder.conv_norm_out"), "encoder.conv_out")
+        return h.permute(0, 3, 1, 2).contiguous()
+
+    def _decoder_hip(self, z):
+        c = self.config
+        h = F.conv2d(z, self.sd["decoder.conv_in.weight"], self.sd["decoder.conv_in.bias"], padding=1)
+        h = h.permute(0, 2, 3, 1).contiguous()
+        h = self._hmid(h, "decoder.mid_block")
+        n = len(c.block_out_channels)
+        for i in range(n):
+            for j in range(c.layers_per_block + 1):
+                h = self._hres(h, f"decoder.up_blocks.{i}.resnets.{j}")
+            if i != n - 1:
+                h = self._hconv(h, f"decoder.up_blocks.{i}.upsamplers.0.conv", up=2)
+        h = self._hconv(self._hgn(h, "decoder.conv_norm_out"), "decoder.conv_out")
+        return h[..., : c.out_channels].permute(0, 3, 1, 2).contiguous()
 
     # ---- building blocks (torch ops on the ROCm device) ------------------------------------------------------
     def _conv(self, x, name, stride=1, padding=1):
@@ -150,17 +224,13 @@ class AutoencoderKL:
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         x = x.to(self.device, self.dtype)
-        if getattr(self, "_channels_last", False):
-            x = x.contiguous(memory_format=torch.channels_last)
-        post = DiagonalGaussianDistribution(self._encoder(x))
+        post = DiagonalGaussianDistribution(self._encoder_hip(x) if self.use_hip else self._encoder(x))
         return SimpleNamespace(latent_dist=post) if return_dict else (post,)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None):
         z = z.to(self.device, self.dtype)
-        if getattr(self, "_channels_last", False):
-            z = z.contiguous(memory_format=torch.channels_last)
-        out = self._decoder(z)
+        out = self._decoder_hip(z) if self.use_hip else self._decoder(z)
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
     def _shapes(self):

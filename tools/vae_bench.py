@@ -13,6 +13,5 @@ def t(fn, n=3):
     torch.cuda.synchronize()
     return (time.time() - t0) / n
 print(f"B={B} encode {t(lambda: vae.encode(x))*1e3:.1f} ms  decode {t(lambda: vae.decode(z))*1e3:.1f} ms", flush=True)
-if hasattr(vae, "set_channels_last"):
-    vae.set_channels_last(True)
-    print(f"channels_last: encode {t(lambda: vae.encode(x))*1e3:.1f} ms  decode {t(lambda: vae.decode(z))*1e3:.1f} ms", flush=True)
+vae.use_hip = False
+print(f"torch/MIOpen NCHW path: encode {t(lambda: vae.encode(x))*1e3:.1f} ms  decode {t(lambda: vae.decode(z))*1e3:.1f} ms", flush=True)
