@@ -30,7 +30,7 @@ struct GemmParams {
   const bf16_t* W; int64_t ldw;
   const bf16_t* bias;
   bf16_t* C; int64_t ldc, c_bs;
-  int M, N, K, batch, tm, tn;
+  int M, N, K, batch, tm, tn, gm;
   int gelu_from;
   const bf16_t* gate; int64_t gate_bs;
   const bf16_t* res; int64_t ldr, r_bs;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   const int per_batch = p.tm * p.tn;
   const int b = bid / per_batch;
   int idx = bid - b * per_batch;
-  constexpr int GM = 8;
+  const int GM = p.gm;
   const int grp = idx / (GM * p.tn);
   const int first_m = grp * GM;
   const int gsz = min(GM, p.tm - first_m);
@@ -276,12 +276,22 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
 #define MFMA8(WF, ROWBASE, NJ, MID)                                                                          \
   do {                                                                                                    \
+    if ((ABL & 1024) && g == 1) break; /* bench-only: one MFMA stream per SIMD */                          \
     if (ABL & 16) {                                                                                       \
       _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
         asm volatile("" ::"v"(WF[kk]), "v"(xf[0][kk]), "v"(xf[1][kk]));  /* keep the fragment reads live */ \
       break;                                                                                              \
     }                                                                                                     \
     if (!(ABL & 256)) __builtin_amdgcn_s_setprio(1);                                                                        \
+    if (ABL & 2048) { /* bench-only: the two accumulators interleaved */                                  \
+      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
+        acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+      }                                                                                                   \
+      MID;                                                                                                \
+    } else {                                                                                              \
     /* same-accumulator MFMAs back to back: D -> C forwarding of an accumulate chain costs no wait states, while an */ \
     /* interleaved second accumulator exposes the write-back latency of the first on every other issue            */ \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
@@ -291,6 +301,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
       acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
+    }                                                                                                     \
     if (!(ABL & 256)) __builtin_amdgcn_s_setprio(0);                                                      \
   } while (0)
 // waits sit in the loads section: the 4 newest sections (8 loads; 10 with the old placement) may still be in flight
@@ -470,6 +481,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+static int g_gemm_group_m = 4;  // row tiles per group of the tile order (L2 locality knob)
+void set_gemm_group_m(int gm) { g_gemm_group_m = gm < 1 ? 1 : gm; }
+
 static GemmParams make_params(const GemmArgs& a) {
   GemmParams p;
   p.A = (const bf16_t*)a.A; p.lda = a.lda; p.a_bs = a.a_bstride;
@@ -477,7 +491,7 @@ static GemmParams make_params(const GemmArgs& a) {
   p.bias = (const bf16_t*)a.bias;
   p.C = (bf16_t*)a.C; p.ldc = a.ldc; p.c_bs = a.c_bstride;
   p.M = a.M; p.N = a.N; p.K = a.K; p.batch = a.batch;
-  p.tm = (a.M + 255) / 256; p.tn = (a.N + 255) / 256;
+  p.tm = (a.M + 255) / 256; p.tn = (a.N + 255) / 256; p.gm = g_gemm_group_m;
   p.gelu_from = a.gelu_from_col;
   p.gate = (const bf16_t*)a.gate; p.gate_bs = a.gate_bstride;
   p.res = (const bf16_t*)a.res; p.ldr = a.ldr; p.r_bs = a.r_bstride;
@@ -526,6 +540,10 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       case 128: return launch_ablation<128>(p, st);
       case 256: return launch_ablation<256>(p, st);
       case 512: return launch_ablation<512>(p, st);
+      case 1031: return launch_ablation<1031>(p, st);
+      case 3079: return launch_ablation<3079>(p, st);
+      case 2055: return launch_ablation<2055>(p, st);
+      case 2048: return launch_ablation<2048>(p, st);
       case 263: return launch_ablation<263>(p, st);
       case 129: return launch_ablation<129>(p, st);
       case 135: return launch_ablation<135>(p, st);

@@ -46,6 +46,7 @@ struct GemmArgs {
   int conv_cin = 0, conv_inH = 0, conv_inW = 0, conv_H = 0, conv_W = 0, conv_stride = 1, conv_up_shift = 0, conv_pad_lo = 1;
   const void* zero_page = nullptr;
 };
+void set_gemm_group_m(int gm);
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
 

@@ -16,7 +16,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from the torchrun environment; initialises the default process group."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # torchrun: also exercise the group at world 1
+    if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
