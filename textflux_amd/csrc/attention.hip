@@ -527,7 +527,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
   }
   const int nqb = (a.N + qblk - 1) / qblk;
   const unsigned grid = (unsigned)(a.B * a.H * nqb);
-  const bool prof = prof_on();
+  const bool prof = prof_on(st);
   if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
   if (g_attn_abl) {
     (void)hipFuncSetAttribute((const void*)attn_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);

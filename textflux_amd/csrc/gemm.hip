@@ -569,7 +569,7 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       attr_set[conv] = true;
     }
     const unsigned grid = (unsigned)(p.batch * p.tm * p.tn);
-    const bool prof = prof_on() && !conv;
+    const bool prof = prof_on(st) && !conv;
     if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
     if (conv)
       gemm8p_kernel<EPI, 0, true><<<grid, 512, LDS_TOTAL, st>>>(p);

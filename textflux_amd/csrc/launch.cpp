@@ -43,6 +43,12 @@ struct Prof {
 
 void prof_enable(int on) { g_prof.on = on != 0; }
 bool prof_on() { return g_prof.on; }
+bool prof_on(hipStream_t st) {
+  if (!g_prof.on) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // events recorded while capturing cannot be timed
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return true; }
+  return cs == hipStreamCaptureStatusNone;
+}
 void prof_begin(int kind, double flops, hipStream_t st) {
   Rec r{g_prof.get(), g_prof.get(), flops};
   hipEventRecord(r.a, st);

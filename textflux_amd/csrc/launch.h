@@ -16,6 +16,7 @@ const char* last_error();
 // FLOPs.  kind: 0 = gemm8p, 1 = attention.
 void prof_enable(int on);
 bool prof_on();
+bool prof_on(hipStream_t st);  // false while `st` is being captured into a graph
 void prof_begin(int kind, double flops, hipStream_t st);
 void prof_end(int kind, hipStream_t st);
 int prof_collect(int kind, double* total_ms, double* total_flops, int* launches);
