@@ -157,3 +157,39 @@ def test_state_dict_key_contract():
     assert full.mod_len == 1056768 and len(full.expected_keys()) == 1160
     with pytest.raises(ValueError):
         FluxTransformer2DModel(attention_head_dim=64)
+
+
+def test_encode_prompt_with_tiny_text_encoders():
+    """encode_prompt / _get_clip_prompt_embeds / _get_t5_prompt_embeds (pipeline_flux_fill.py:1411-1503, 1586-1663) against
+    tiny random CLIP / T5 encoders from `transformers` configs (no hub) and stub tokenizers: CLIP pooled output of
+    `prompt`, T5 sequence of `prompt_2`, repeat semantics of num_images_per_prompt, zero text ids."""
+    from types import SimpleNamespace
+    from transformers import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
+
+    class Tok:
+        def __init__(self, n):
+            self.model_max_length = n
+
+        def __call__(self, prompts, padding=None, max_length=None, truncation=None, return_tensors=None, **kw):
+            ids = torch.stack([torch.tensor([(hash(p) + i) % 90 + 1 for i in range(max_length)]) for p in prompts])
+            return SimpleNamespace(input_ids=ids)
+
+    torch.manual_seed(0)
+    clip = CLIPTextModel(CLIPTextConfig(vocab_size=100, hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                                        num_attention_heads=2, max_position_embeddings=77, projection_dim=32)).eval()
+    t5 = T5EncoderModel(T5Config(vocab_size=100, d_model=64, d_kv=16, d_ff=64, num_layers=1, num_heads=2)).eval()
+    p = _pipe()
+    p.text_encoder, p.tokenizer, p.text_encoder_2, p.tokenizer_2 = clip, Tok(77), t5, Tok(512)
+    p.tokenizer_max_length = 77
+    pe, pooled, ids = p.encode_prompt(prompt=["a", "b"], prompt_2=["c d", "e"], device="cpu", num_images_per_prompt=2,
+                                      max_sequence_length=24)
+    assert pe.shape == (4, 24, 64) and pooled.shape == (4, 32) and ids.shape == (24, 3) and ids.abs().sum() == 0
+    assert torch.equal(pe[0], pe[1]) and not torch.equal(pe[0], pe[2])          # repeated per prompt, distinct across prompts
+    assert torch.equal(pooled[2], pooled[3]) and not torch.equal(pooled[0], pooled[2])
+    ref_pooled = clip(p.tokenizer(["a"], max_length=77).input_ids, output_hidden_states=False).pooler_output
+    assert torch.allclose(pooled[0], ref_pooled[0])
+    pe2, pooled2, _ = p.encode_prompt(prompt=None, prompt_2=None, prompt_embeds=pe, pooled_prompt_embeds=pooled, device="cpu")
+    assert pe2 is pe and pooled2 is pooled
+    p.text_encoder = None
+    with pytest.raises(ValueError):
+        p.encode_prompt(prompt="a", prompt_2=None, device="cpu")

@@ -124,6 +124,12 @@ def lib() -> C.CDLL:
         # ONE HIP runtime (loading ours first pulls /opt/rocm's copy and its kernels then see "no device").
         import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
+            try:                      # same HIP sources, just not compiled yet (fresh checkout): compile, never substitute
+                build()
+            except Exception as e:
+                raise RuntimeError(f"{LIB_PATH} is missing and could not be built ({e}); textflux_amd has no CPU / eager "
+                                   "fallback") from e
+        if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  textflux_amd has no CPU / eager fallback.")

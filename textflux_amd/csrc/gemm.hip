@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   }
   const uint32_t dummy = LDS_DUMMY + wave * 1024;
 
-  auto stage = [&](int q, int tile) {
+  auto stage = [&](int q, int tile, int jsel = -1) {
     const bool ok = tile < nt;
     const int kt = ok ? tile : nt - 1;
     const bf16_t* base = (isx[q] ? Xb : Wb) + (int64_t)kt * 64;
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       const int vh = p.inH << p.cup, vw = p.inW << p.cup;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        if (jsel >= 0 && j != jsel) continue;
         const int yy = (cyx[q][j] >> 16) - 1 + dy, xx = (cyx[q][j] & 0xffff) - 1 + dx;
         const bool inside = (unsigned)yy < (unsigned)vh && (unsigned)xx < (unsigned)vw;
         const bf16_t* src = inside ? p.A + ((int64_t)(cpix[q][j] + (yy >> p.cup) * p.inW + (xx >> p.cup)) * p.cin + ci0 + goff[q][j])
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       return;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) glds16<kAux>(base + goff[q][j], smem, ok ? ldst[q][j] + setoff : dummy);
+    for (int j = 0; j < 2; ++j)
+      if (jsel < 0 || j == jsel) glds16<kAux>(base + goff[q][j], smem, ok ? ldst[q][j] + setoff : dummy);
   };
 
   // ---- fragment read addresses (set 0); per-lane swizzle key is (lane>>1)&7 because fragment rows are
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   bf16x8 xf[2][4], wlo[4], whi[4];
 
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
-#define MFMA8(WF, ROWBASE, NJ, MID)                                                                          \
+#define MFMA8(WF, ROWBASE, NJ, MID, END)                                                                          \
   do {                                                                                                    \
     if ((ABL & 1024) && g == 1) break; /* bench-only: one MFMA stream per SIMD */                          \
     if (ABL & 16) {                                                                                       \
@@ -302,6 +304,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
       acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
     }                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    END;                                                                                                  \
     if (!(ABL & 256)) __builtin_amdgcn_s_setprio(0);                                                      \
   } while (0)
 // waits sit in the loads section: the 4 newest sections (8 loads; 10 with the old placement) may still be in flight
@@ -311,7 +315,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 // = old placement, in the loads section): the texture path then works while the matrix pipe is busy and the loads
 // section -- the critical path of the partner group's MFMA slot -- carries only the fragment reads (+3 %).
 #define BODY_STAGE(q, t) do { if (!(ABL & 1) && (ABL & 512)) stage(q, t); } while (0)
-#define MID_STAGE(q, t) do { if (!(ABL & 1) && !(ABL & 512)) stage(q, t); } while (0)
+#define MID_STAGE(q, t) do { if (!(ABL & 1) && !(ABL & 512)) { if (ABL & 8192) stage(q, t, 0); else stage(q, t); } } while (0)
+#define END_STAGE(q, t) do { if (!(ABL & 1) && !(ABL & 512) && (ABL & 8192)) stage(q, t, 1); } while (0)
 #define BODY_BARRIER() do { if (!(ABL & 4)) TFX_BARRIER(); } while (0)
   if (ABL & 2) {
 #pragma unroll
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     TACC(tw);
     BODY_BARRIER();
     TACC(tb1);
-    MFMA8(wlo, 0, 0, MID_STAGE(0, u + 1));
+    MFMA8(wlo, 0, 0, MID_STAGE(0, u + 1), END_STAGE(0, u + 1));
     TACC(tm);
     BODY_BARRIER();
     TACC(tb2);
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     TACC(tw);
     BODY_BARRIER();
     TACC(tb1);
-    MFMA8(whi, 0, 1, MID_STAGE(1, u + 2));
+    MFMA8(whi, 0, 1, MID_STAGE(1, u + 2), END_STAGE(1, u + 2));
     TACC(tm);
     BODY_BARRIER();
     TACC(tb2);
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     TACC(tw);
     BODY_BARRIER();
     TACC(tb1);
-    MFMA8(whi, 2, 1, MID_STAGE(2, u + 2));
+    MFMA8(whi, 2, 1, MID_STAGE(2, u + 2), END_STAGE(2, u + 2));
     TACC(tm);
     BODY_BARRIER();
     TACC(tb2);
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     TACC(tw);
     BODY_BARRIER();
     TACC(tb1);
-    MFMA8(wlo, 2, 0, MID_STAGE(3, u + 2));
+    MFMA8(wlo, 2, 0, MID_STAGE(3, u + 2), END_STAGE(3, u + 2));
     TACC(tm);
     BODY_BARRIER();
     TACC(tb2);
@@ -406,6 +411,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 #undef WAIT_PREFETCH
 #undef BODY_STAGE
 #undef MID_STAGE
+#undef END_STAGE
 #undef BODY_BARRIER
 #undef TMARK
 #undef TACC
@@ -541,6 +547,7 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       case 256: return launch_ablation<256>(p, st);
       case 512: return launch_ablation<512>(p, st);
       case 1031: return launch_ablation<1031>(p, st);
+      case 8192: return launch_ablation<8192>(p, st);
       case 3079: return launch_ablation<3079>(p, st);
       case 2055: return launch_ablation<2055>(p, st);
       case 2048: return launch_ablation<2048>(p, st);
