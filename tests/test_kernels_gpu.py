@@ -99,6 +99,21 @@ def test_attention(ops, B, H, N):
     close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
+@pytest.mark.parametrize("nw", [4, 9, 16])
+def test_attention_waves_variants(ops, nw):
+    """The alternative schedules kept for A/B (4-wave workgroups, 128 keys per barrier, ping-pong) compute the same thing."""
+    B, H, N = 2, 2, 712
+    q, k, v = (rnd((B, N, H * 128), s).to(BF) for s in (27, 28, 29))
+    qh, kh, vh = (t.float().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, N, H * 128)
+    ops.set_option("attention_waves", nw)
+    try:
+        got = ops.attention(q.cuda(), k.cuda(), v.cuda())
+    finally:
+        ops.set_option("attention_waves", 8)
+    close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+
+
 def test_attention_online_softmax_rescale_branch(ops):
     """A key far above the rest in a LATE tile forces the running-max rescale of the accumulated output."""
     B, H, N = 1, 1, 256

@@ -19,6 +19,7 @@ namespace tfx {
 constexpr int KVBLK = 64, HD = 128;
 constexpr int K_BYTES = KVBLK * HD * 2;          // 16 KiB
 constexpr int ATT_LDS = 2 * 2 * K_BYTES;         // K,V x 2 buffers = 64 KiB
+constexpr int ATT_LDS2 = 2 * ATT_LDS;            // two 64-key sub-tiles per buffer = 128 KiB
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ unsigned long long* g_dbg_ptr = nullptr;  // bench-only (tools/attn_timing.py)
@@ -34,12 +35,13 @@ __device__ unsigned long long* g_dbg_ptr = nullptr;  // bench-only (tools/attn_t
   } while (0)
 
 // Q and O may alias (the single-stream blocks write O over Q; a block only touches its own QBLK rows of one head).
+// SUB = 64-key sub-tiles staged per barrier (SUB = 2: 128 keys per barrier, 128 KiB LDS, half the barriers).
 // NW waves per workgroup (QBLK = 32 * NW query rows).  NW = 8: one workgroup per CU; NW = 4: two independent
 // workgroups per CU (64 KiB LDS each) whose waves share the SIMDs without a common barrier, so one's softmax (VALU)
 // overlaps the other's MFMA phases.
 // ABL: bench-only ablations (wrong results): bit0 no softmax math, bit1 K fragments read once, bit2 V fragments read
 // once, bit3 no K/V staging after the first tile.
-template <int NW, int ABL = 0>
+template <int NW, int ABL = 0, int SUB = 1>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
                                                    const bf16_t* __restrict__ Vp, bf16_t* O,
                                                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs,
@@ -78,26 +80,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
 
   // ---- staging: thread t copies chunks c = t and t + 512 of the 1024 16-byte chunks of a K (and V) tile
   const int nkv = (N + KVBLK - 1) / KVBLK;
-  u32x4 kreg[CPT], vreg[CPT];
-  auto load_tile = [&](int j) {
+  u32x4 kreg[SUB][CPT], vreg[SUB][CPT];
+  auto load_tile = [&](int jg) {   // group jg = sub-tiles jg*SUB .. jg*SUB+SUB-1
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int c = tid + i * NT;
-      int key = j * KVBLK + (c >> 4);
-      if (key > N - 1) key = N - 1;
-      kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (int64_t)key * ldk + (c & 15) * 8);
-      vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (int64_t)key * ldv + (c & 15) * 8);
-    }
+    for (int sb = 0; sb < SUB; ++sb)
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * NT;
+        int key = (jg * SUB + sb) * KVBLK + (c >> 4);
+        if (key > N - 1) key = N - 1;
+        kreg[sb][i] = *reinterpret_cast<const u32x4*>(Kb + (int64_t)key * ldk + (c & 15) * 8);
+        vreg[sb][i] = *reinterpret_cast<const u32x4*>(Vb + (int64_t)key * ldv + (c & 15) * 8);
+      }
   };
   auto write_tile = [&](int buf) {
-    char* kd = smem + buf * 2 * K_BYTES;
-    char* vd = kd + K_BYTES;
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int c = tid + i * NT;
-      const int key = c >> 4, ch = c & 15;
-      *reinterpret_cast<u32x4*>(kd + key * 256 + ((ch ^ (key & 15)) << 4)) = kreg[i];
-      *reinterpret_cast<u32x4*>(vd + key * 256 + ((((ch >> 2) ^ (key & 3)) << 6) | ((ch & 3) << 4))) = vreg[i];
+    for (int sb = 0; sb < SUB; ++sb) {
+      char* kd = smem + (buf * SUB + sb) * 2 * K_BYTES;
+      char* vd = kd + K_BYTES;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * NT;
+        const int key = c >> 4, ch = c & 15;
+        *reinterpret_cast<u32x4*>(kd + key * 256 + ((ch ^ (key & 15)) << 4)) = kreg[sb][i];
+        *reinterpret_cast<u32x4*>(vd + key * 256 + ((((ch >> 2) ^ (key & 3)) << 6) | ((ch & 3) << 4))) = vreg[sb][i];
+      }
     }
   };
 
@@ -121,26 +128,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  const int ngrp = (nkv + SUB - 1) / SUB;
   load_tile(0);
   write_tile(0);
-  if (nkv > 1) load_tile(1);
+  if (ngrp > 1) load_tile(1);
   __syncthreads();
 
   bf16x8 kab[8], vab;
   unsigned long long tq = 0, tsm = 0, tpv = 0, tst = 0, tmk = 0;
 #define LTM() do { if (ABL & 16) { __builtin_amdgcn_sched_barrier(0); tmk = __builtin_readcyclecounter(); } } while (0)
 #define LTA(x) do { if (ABL & 16) { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = __builtin_readcyclecounter(); x += n_ - tmk; tmk = n_; } } while (0)
-  for (int j = 0; j < nkv; ++j) {
-    const int buf = j & 1;
-    LTM();
-    // staging: tile j+1 (requested one whole tile ago) goes into the other buffer -- idle since the barrier that ended
-    // tile j-1 -- right away, and the registers are re-used for the request of tile j+2: the loads get a full tile
-    // of latency hiding and the barrier at the end of the tile no longer waits for memory.
-    if (j + 1 < nkv && !(ABL & 8)) {
+  for (int jg = 0; jg < ngrp; ++jg) {
+    const int buf = jg & 1;
+    // staging: group jg+1 (requested one whole group ago) goes into the other buffer -- idle since the barrier that
+    // ended group jg-1 -- right away, and the registers are re-used for the request of group jg+2: the loads get a full
+    // group of latency hiding and the barrier at the end of the group no longer waits for memory.
+    if (jg + 1 < ngrp && !(ABL & 8)) {
       write_tile(buf ^ 1);
-      if (j + 2 < nkv) load_tile(j + 2);
+      if (jg + 2 < ngrp) load_tile(jg + 2);
     }
-    const char* kt = smem + buf * 2 * K_BYTES;
+#pragma unroll
+   for (int sb = 0; sb < SUB; ++sb) {
+    const int j = jg * SUB + sb;
+    if (j >= nkv) break;
+    LTM();
+    const char* kt = smem + (buf * SUB + sb) * 2 * K_BYTES;
     const char* vt = kt + K_BYTES;
 
     // ---- S^T = K Q^T : two 32-key blocks
@@ -222,6 +234,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
       }
     }
     LTA(tpv);
+   }
+    LTM();
     __syncthreads();
     LTA(tst);
   }
@@ -501,7 +515,7 @@ void set_attention_debug(void* p) {
 }
 static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
-void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8) ? nw : 16; }
+void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 9) ? nw : 16; }
 
 int joint_attention(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.H <= 0 || a.N <= 0) return 0;
@@ -509,7 +523,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     return fail("attention: strides must be multiples of 8 elements (q,k,v) / 4 (o)");
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 || (uintptr_t)a.o % 8)
     return fail("attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
-  const int NW = g_attn_waves == 16 ? 8 : g_attn_waves;
+  const int NW = (g_attn_waves == 16 || g_attn_waves == 9) ? 8 : g_attn_waves;
   const bool pp = g_attn_waves == 16;
   const int qblk = NW * 32;
   static bool attr_set = false;
@@ -517,10 +531,12 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     hipFuncAttributes fa;
     (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<8>);
     (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<4>);
+    (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<8, 0, 2>);
     (void)hipFuncGetAttributes(&fa, (const void*)attn_pp_kernel<false>);
     (void)hipGetLastError();
     hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<8, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS2);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e != hipSuccess) return fail("attention: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
@@ -549,6 +565,10 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
       attn_pp_kernel<false><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
                                                         a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
                                                         a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f, nullptr);
+  else if (g_attn_waves == 9)   // 8 waves, two 64-key sub-tiles per barrier
+    attn_kernel<8, 0, 2><<<grid, 512, ATT_LDS2, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
+                                                      a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
+                                                      a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f);
   else if (NW == 8)
     attn_kernel<8><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
                                                a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,

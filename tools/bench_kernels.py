@@ -67,7 +67,7 @@ def main():
             o = torch.empty(B, N, D, dtype=BF, device=dev)
             q, k, v = y[:, :, 2 * D:], y[:, :, :D], y[:, :, D:2 * D]
             fl = 4.0 * B * H * N * N * 128
-            for nw in (16, 8):
+            for nw in (9, 8):
                 ops.set_option("attention_waves", nw)
                 t = timeit(lambda: ops.attention(q, k, v, out=o))
                 emit(dict(tag=a.tag, kernel=f"attention(nw={nw})", B=B, N=N, ms=t * 1e3, tflops=fl / t / 1e12))
