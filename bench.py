@@ -198,7 +198,7 @@ def main():
                          "attention": {"achieved": att_fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0,
                                        "launches": att_n, "avg_launch_ms": att_ms / max(att_n, 1)}},
         }
-        rec["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline(H, W, n)
+        rec["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(H, W, n)   # rank 0 at N = 1 only
         print(json.dumps(rec), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -216,6 +216,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     }
   }
   const uint32_t dummy = LDS_DUMMY + wave * 1024;
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)Xb, 0, 0x7fffffff, 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
 
   auto stage = [&](int q, int tile, int jsel = -1) {
     const bool ok = tile < nt;
@@ -236,6 +238,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
                                    : p.zero + goff[q][j];
         glds16<kAux>(src, smem, ok ? ldst[q][j] + setoff : dummy);
       }
+      return;
+    }
+    if (!CONV && !(ABL & 16384)) {
+      // buffer form of the LDS DMA: per-lane 32-bit byte offset + scalar K offset against a per-tile descriptor -- no
+      // 64-bit per-lane address arithmetic in the issue path
+      const auto rs = isx[q] ? rsrcX : rsrcW;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (jsel < 0 || j == jsel)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (ok ? ldst[q][j] + setoff : dummy)), 16,
+                                                   goff[q][j] * 2, kt * 128, 0, kAux);
       return;
     }
 #pragma unroll
@@ -548,6 +561,7 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       case 512: return launch_ablation<512>(p, st);
       case 1031: return launch_ablation<1031>(p, st);
       case 8192: return launch_ablation<8192>(p, st);
+      case 16384: return launch_ablation<16384>(p, st);
       case 3079: return launch_ablation<3079>(p, st);
       case 2055: return launch_ablation<2055>(p, st);
       case 2048: return launch_ablation<2048>(p, st);
