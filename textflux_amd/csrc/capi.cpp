@@ -259,6 +259,7 @@ int tfx_set_option(const char* name, int value) {
     return 0;
   }
   if (!std::strcmp(name, "gemm_group_m")) { set_gemm_group_m(value); return 0; }
+  if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only
   return fail("tfx_set_option: unknown option '%s'", name);
 }

@@ -246,9 +246,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       const auto rs = isx[q] ? rsrcX : rsrcW;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        if (jsel < 0 || j == jsel)
+        if ((jsel < 0 || j == jsel) && !((ABL & 32768) && j == 1))   // bench-only bit 15: half the prefetch bytes
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (ok ? ldst[q][j] + setoff : dummy)), 16,
-                                                   goff[q][j] * 2, kt * 128, 0, kAux);
+                                                   (ABL & 65536) ? lane * 16 : goff[q][j] * 2,  // bit 16: L1-hot source
+                                                   (ABL & 65536) ? 0 : kt * 128, 0, kAux);
       return;
     }
 #pragma unroll
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     if (!(ABL & 256)) __builtin_amdgcn_s_setprio(0);                                                      \
   } while (0)
 // waits sit in the loads section: the 4 newest sections (8 loads; 10 with the old placement) may still be in flight
-#define WAIT_PREFETCH() do { if (ABL & 512) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
+#define WAIT_PREFETCH() do { if (ABL & 512) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else if (ABL & 32768) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
 
 // The prefetch of a phase is issued BETWEEN the two accumulate chains of the wave's own MFMA section (ABL bit 9
 // = old placement, in the loads section): the texture path then works while the matrix pipe is busy and the loads
@@ -500,6 +501,344 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent form of gemm8p_kernel for the DiT shapes (M, N multiples of 256, K multiple of 128, > 256 tiles): one
+// block per CU walks the XCD's contiguous range of the tile order.  The K-loop schedule is the one above; what
+// changes is the boundary between tiles:
+//   * the prefetch slots of a tile's last two K-tiles (which the one-tile kernel points at a sink) request the first
+//     two K-tiles of the block's NEXT tile into the regular buffer sets, so a tile starts with its operands already
+//     in LDS -- no per-tile prologue latency, no sink traffic (2/nt of the L2->LDS bytes);
+//   * the epilogue stages through its own 32 KiB (8 waves x 32 rows x 128 B, XOR-swizzled 16-byte chunks) behind
+//     the two sets instead of reusing them, one 32-row block of the accumulators at a time;
+//   * the two row groups stay one barrier apart across tiles, so one group's epilogue overlaps the other's MFMAs.
+// Operands are addressed through ONE buffer descriptor per matrix with the tile origin folded into the scalar
+// offset (fits 32 bits: checked by persist_ok), so switching to the next tile's addresses is a scalar move.
+constexpr int PP_STG = 131072;
+constexpr int PP_STG_WAVE = 4096;
+constexpr int PP_LDS_TOTAL = PP_STG + 8 * PP_STG_WAVE;  // 163840 = all of the CU's LDS
+
+template <int EPI, int PLACE = 1>
+__global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2;
+  const int wc = wave & 3;
+  const int nt = p.K >> 6;
+
+  // ---- this block's tiles: XCD x owns a contiguous range of the (grouped) tile order; its blocks stride through it
+  const int per_batch = p.tm * p.tn;
+  const int T = p.batch * per_batch;
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const int q8 = T >> 3, r8 = T & 7;
+  const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int xcnt = q8 + (xcd < r8 ? 1 : 0);
+  int it = blockIdx.x >> 3;
+  if (it >= xcnt) return;
+
+  struct Tile { int b, m0, n0; uint32_t xoff, woff; };
+  auto coords = [&](int id) {
+    Tile t;
+    t.b = id / per_batch;
+    int idx = id - t.b * per_batch;
+    const int GM = p.gm;
+    const int grp = idx / (GM * p.tn);
+    const int first_m = grp * GM;
+    const int gsz = min(GM, p.tm - first_m);
+    idx -= grp * GM * p.tn;
+    t.m0 = (first_m + idx % gsz) * 256;
+    t.n0 = (idx / gsz) * 256;
+    t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * 2);
+    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * 2);
+    return t;
+  };
+
+  // ---- prefetch items; no edge clamps: M, N are multiples of 256.
+  // PLACE 0: the table and slots of gemm8p_kernel (requests issued between the two accumulate chains of an MFMA
+  //          section).
+  // PLACE >= 1: every request is issued from a LOADS section -- the partner group owns the matrix pipe there, so the
+  //          ~60 issue cycles an LDS-DMA instruction costs its wave no longer open a hole in the MFMA stream.  Each
+  //          group stages its own X half and W stripes {2g, 2g+1}, all for K-tile u+2 (same buffer set as u):
+  //            item 0 X_lo  free after slot L0   item 1 W_lo  free after L0 (+1 for the partner's read)
+  //            item 2 W_hi  free after L1 (+1)   item 3 X_hi  free after L2
+  //          PLACE 1: L1 {0,1}  L3 {2,3} | PLACE 2: L1 {0}  L2 {1}  L3 {2,3} | PLACE 3: L1 {0}  L3 {1,2,3}
+  //          Deadlines (issuer's wait, one barrier before the first reader): items 0,1 at L3 of tile u+1, item 2 at
+  //          L0 of u+2, item 3 at L1 of u+2 -> vmcnt 12 / 10 / 12 (PLACE 1) or 12 / 10 / 10 (PLACE 2, 3).
+  const int lr = lane >> 3, cphys = lane & 7;
+  int goff[4][2];
+  uint32_t ldst[4][2];
+  bool isx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bool x_item;
+    if (PLACE == 0) x_item = g == 0 ? (q == 0 || q == 1) : (q == 0 || q == 2);
+    else x_item = (q == 0 || q == 3);
+    isx[q] = x_item;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pc = wc * 2 + j;
+      int row0;
+      if (PLACE == 0) {
+        if (x_item) {
+          row0 = (q == 0 ? 64 : 0) + pc * 8;
+        } else {
+          const int whi_item = (q == 3);
+          const int half = g == 0 ? (q == 2 ? 128 : 0) : (q == 1 ? 0 : 128);
+          row0 = half + (pc >> 2) * 64 + whi_item * 32 + (pc & 3) * 8;
+        }
+      } else {
+        if (x_item) row0 = (q == 3 ? 64 : 0) + pc * 8;
+        else row0 = g * 128 + (pc >> 2) * 64 + (q == 2 ? 32 : 0) + (pc & 3) * 8;
+      }
+      const int row = row0 + lr;
+      const int clog = cphys ^ ((row >> 1) & 7);
+      if (x_item) {
+        goff[q][j] = ((g * 128 + row) * (int)p.lda + clog * 8) * 2;
+        ldst[q][j] = LDS_X + g * 32768 + row0 * 128;
+      } else {
+        goff[q][j] = (row * (int)p.ldw + clog * 8) * 2;
+        ldst[q][j] = LDS_W + row0 * 128;
+      }
+    }
+  }
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+
+  // request item q of K-tile kt of the tile whose origins are (xo, wo) into buffer set `set`
+  auto stage = [&](int q, uint32_t xo, uint32_t wo, int kt, int set) {
+    const auto rs = isx[q] ? rsrcX : rsrcW;
+    const uint32_t so = (isx[q] ? xo : wo) + (uint32_t)kt * 128u;
+    const uint32_t setoff = set * (isx[q] ? 16384u : 32768u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + ldst[q][j] + setoff), 16, goff[q][j], so, 0, GLDS_AUX);
+  };
+
+  const int hi = lane >> 5;
+  const int key = (lane >> 1) & 7;
+  uint32_t fx[4], fw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const uint32_t o = (lane & 31) * 128 + (((kk * 2 + hi) ^ key) << 4);
+    fx[kk] = LDS_X + g * 32768 + o;
+    fw[kk] = LDS_W + wc * 64 * 128 + o;
+  }
+
+  Tile cur = coords(xstart + it);
+  // ---- prologue (first tile of the block only)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) stage(q, cur.xoff, cur.woff, 0, 0);
+#pragma unroll
+  for (int q = (PLACE == 0 ? 1 : 0); q < 4; ++q) stage(q, cur.xoff, cur.woff, 1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TFX_BARRIER();
+  if (g == 1) TFX_BARRIER();  // stagger: G1 runs one barrier behind G0, for the whole life of the block
+
+  f32x16 acc[4][2];
+  bf16x8 xf[2][4], wlo[4], whi[4];
+#define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
+#define PP_WAIT() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define PP_MFMA8(WF, ROWBASE, NJ, MID)                                                                       \
+  do {                                                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                         \
+      acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
+    asm volatile("" : "+v"(acc[ROWBASE][NJ]));  /* pins the chain in front of the prefetch issue */           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    MID;                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                         \
+      acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
+    asm volatile("" : "+v"(acc[ROWBASE + 1][NJ]));  /* ... and this one in front of the closing barrier */    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  } while (0)
+  // one K-tile: SET = its buffer set; S0..S3 = the prefetch issued in the MFMA section of phase q0..q3
+#define PP_TILE(SET, S0, S1, S2, S3)                                                                         \
+  do {                                                                                                       \
+    constexpr uint32_t xs = (SET) * 16384u, ws = (SET) * 32768u;                                             \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                       \
+      xf[0][kk] = LDS_FRAG(fx[kk] + xs);                                                                     \
+      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);                                                              \
+      wlo[kk] = LDS_FRAG(fw[kk] + ws);                                                                       \
+    }                                                                                                        \
+    PP_WAIT(); TFX_BARRIER();                                                                                \
+    PP_MFMA8(wlo, 0, 0, S0);                                                                                 \
+    TFX_BARRIER();                                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);                 \
+    PP_WAIT(); TFX_BARRIER();                                                                                \
+    PP_MFMA8(whi, 0, 1, S1);                                                                                 \
+    TFX_BARRIER();                                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                       \
+      xf[0][kk] = LDS_FRAG(fx[kk] + xs + 8192);                                                              \
+      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);                                                             \
+    }                                                                                                        \
+    PP_WAIT(); TFX_BARRIER();                                                                                \
+    PP_MFMA8(whi, 2, 1, S2);                                                                                 \
+    TFX_BARRIER();                                                                                           \
+    PP_WAIT(); TFX_BARRIER();                                                                                \
+    PP_MFMA8(wlo, 2, 0, S3);                                                                                 \
+    TFX_BARRIER();                                                                                           \
+  } while (0)
+
+  // PLACE >= 1: XO, WO, KT = origin and K-tile of the operands requested during this K-tile (two K-tiles ahead)
+#define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define PP_TILE_L(SET, XO, WO, KT)                                                                           \
+  do {                                                                                                       \
+    constexpr uint32_t xs = (SET) * 16384u, ws = (SET) * 32768u;                                             \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                       \
+      xf[0][kk] = LDS_FRAG(fx[kk] + xs);                                                                     \
+      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);                                                              \
+      wlo[kk] = LDS_FRAG(fw[kk] + ws);                                                                       \
+    }                                                                                                        \
+    PP_VMCNT(10); TFX_BARRIER();                                                                             \
+    PP_MFMA8(wlo, 0, 0, (void)0);                                                                            \
+    TFX_BARRIER();                                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);                 \
+    stage(0, XO, WO, KT, SET);                                                                               \
+    if (PLACE == 1) { stage(1, XO, WO, KT, SET); PP_VMCNT(12); } else { PP_VMCNT(10); }                      \
+    TFX_BARRIER();                                                                                           \
+    PP_MFMA8(whi, 0, 1, (void)0);                                                                            \
+    TFX_BARRIER();                                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                       \
+      xf[0][kk] = LDS_FRAG(fx[kk] + xs + 8192);                                                              \
+      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);                                                             \
+    }                                                                                                        \
+    if (PLACE == 2) stage(1, XO, WO, KT, SET);                                                               \
+    TFX_BARRIER();                                                                                           \
+    PP_MFMA8(whi, 2, 1, (void)0);                                                                            \
+    TFX_BARRIER();                                                                                           \
+    if (PLACE == 3) stage(1, XO, WO, KT, SET);                                                               \
+    stage(2, XO, WO, KT, SET);                                                                               \
+    stage(3, XO, WO, KT, SET);                                                                               \
+    PP_VMCNT(12); TFX_BARRIER();                                                                             \
+    PP_MFMA8(wlo, 2, 0, (void)0);                                                                            \
+    TFX_BARRIER();                                                                                           \
+  } while (0)
+
+  char* stg = smem + PP_STG + wave * PP_STG_WAVE;
+  for (;;) {
+    const int nit = it + per_xcd;
+    const bool has_next = nit < xcnt;
+    // the last tile of the block re-requests its own first K-tiles: harmless (nobody reads them) and keeps the
+    // load counts of the waits uniform
+    const Tile nxt = coords(xstart + (has_next ? nit : it));
+    const uint32_t cx = cur.xoff, cw = cur.woff, nx = nxt.xoff, nw = nxt.woff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (PLACE == 0) {
+      for (int u = 0; u < nt - 2; u += 2) {
+        PP_TILE(0, stage(0, cx, cw, u + 1, 1), stage(1, cx, cw, u + 2, 0), stage(2, cx, cw, u + 2, 0), stage(3, cx, cw, u + 2, 0));
+        PP_TILE(1, stage(0, cx, cw, u + 2, 0), stage(1, cx, cw, u + 3, 1), stage(2, cx, cw, u + 3, 1), stage(3, cx, cw, u + 3, 1));
+      }
+      // K-tiles nt-2 and nt-1: their "two ahead" slots carry the next tile's K-tiles 0 and 1
+      PP_TILE(0, stage(0, cx, cw, nt - 1, 1), stage(1, nx, nw, 0, 0), stage(2, nx, nw, 0, 0), stage(3, nx, nw, 0, 0));
+      PP_TILE(1, stage(0, nx, nw, 0, 0), stage(1, nx, nw, 1, 1), stage(2, nx, nw, 1, 1), stage(3, nx, nw, 1, 1));
+    } else {
+      for (int u = 0; u < nt - 2; u += 2) {
+        PP_TILE_L(0, cx, cw, u + 2);
+        PP_TILE_L(1, cx, cw, u + 3);
+      }
+      PP_TILE_L(0, nx, nw, 0);
+      PP_TILE_L(1, nx, nw, 1);
+    }
+
+    // ---- epilogue (see gemm8p_kernel for the lane -> element map), one 32-row accumulator block at a time
+    const int m0 = cur.m0, n0 = cur.n0, b = cur.b;
+    const int ncol = n0 + wc * 64 + hi * 4;
+    const bool do_gelu = (EPI == EPI_BIAS_GELU) && (n0 >= p.gelu_from);
+    const int r32 = lane & 31;
+    const int crow = lane >> 3, cchunk = lane & 7;
+    const int nst = n0 + wc * 64 + cchunk * 8;
+    float bs[2][4][4], gt[2][4][4];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int n = ncol + nj * 32 + qd * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bs[nj][qd][e] = 0.f; gt[nj][qd][e] = 0.f; }
+        if (p.bias) {
+          const u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n);
+          bs[nj][qd][0] = __uint_as_float(raw[0] << 16); bs[nj][qd][1] = __uint_as_float(raw[0] & 0xffff0000u);
+          bs[nj][qd][2] = __uint_as_float(raw[1] << 16); bs[nj][qd][3] = __uint_as_float(raw[1] & 0xffff0000u);
+        }
+        if (EPI == EPI_BIAS_GATE_RES) {
+          const u32x2 raw = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + n);
+          gt[nj][qd][0] = __uint_as_float(raw[0] << 16); gt[nj][qd][1] = __uint_as_float(raw[0] & 0xffff0000u);
+          gt[nj][qd][2] = __uint_as_float(raw[1] << 16); gt[nj][qd][3] = __uint_as_float(raw[1] & 0xffff0000u);
+        }
+      }
+    // every request of this tile's K loop (incl. the next tile's first K-tiles) is older than the stores below;
+    // loads and stores retire out of order with respect to each other, so the counted waits of the next K loop are
+    // only meaningful once these have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][qd * 4 + e] + bs[nj][qd][e];
+          if (do_gelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+          }
+          if (EPI == EPI_BIAS_GATE_RES) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gt[nj][qd][e] * round_bf(v[e]);
+          }
+          u32x2 o;
+          o[0] = pack_bf2(v[0], v[1]);
+          o[1] = pack_bf2(v[2], v[3]);
+          // row r32, 16-byte chunk c = nj*4 + qd stored at chunk c ^ (r32 & 7); the 8-byte half is flipped for rows
+          // 8..15 / 24..31 so the 16 lanes of a ds_write_b64 group touch 16 different bank pairs
+          const int c = nj * 4 + qd;
+          *reinterpret_cast<u32x2*>(stg + r32 * 128 + ((c ^ (r32 & 7)) << 4) + ((hi ^ ((r32 >> 3) & 1)) << 3)) = o;
+        }
+      // wave-private region + in-order LDS pipe: no barrier between the writes above and the reads below
+#pragma unroll
+      for (int itr = 0; itr < 4; ++itr) {
+        const int row = itr * 8 + crow;
+        const int m = m0 + g * 128 + mi * 32 + row;
+        u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((cchunk ^ (row & 7)) << 4));
+        if (itr & 1) { const uint32_t t0 = val[0], t1 = val[1]; val[0] = val[2]; val[1] = val[3]; val[2] = t0; val[3] = t1; }
+        if (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES) {
+          const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + nst);
+          float fv[8], fr[8];
+          unpack8(val, fv);
+          unpack8(rr, fr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+          val = pack8(fv);
+        }
+        *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
+      }
+    }
+    if (!has_next) break;
+    cur = nxt;
+    it = nit;
+  }
+  if (g == 0) TFX_BARRIER();  // pairs with G1's extra barrier of the prologue
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the closing requests must not land in a successor's LDS
+#undef LDS_FRAG
+#undef PP_WAIT
+#undef PP_MFMA8
+#undef PP_TILE
+#undef PP_TILE_L
+#undef PP_VMCNT
+}
+
+// ------------------------------------------------------------------------------------------------
+static int g_gemm_place = 1;      // request placement of the persistent kernel (bench knob, see gemm8pp_kernel)
+void set_gemm_place(int v) { g_gemm_place = v; }
 static int g_gemm_group_m = 4;  // row tiles per group of the tile order (L2 locality knob)
 void set_gemm_group_m(int gm) { g_gemm_group_m = gm < 1 ? 1 : gm; }
 
@@ -535,6 +874,13 @@ static bool fast_ok(const GemmArgs& a) {
          ((a.epilogue != EPI_BIAS_GATE_RES && a.epilogue != EPI_BIAS_RES) || (a.ldr % 8 == 0 && a.r_bstride % 8 == 0 && a.gate_bstride % 4 == 0 &&
                                               (uintptr_t)a.res % 16 == 0 && (uintptr_t)a.gate % 8 == 0)) &&
          (a.epilogue != EPI_BIAS_GELU || a.gelu_from_col % 256 == 0);
+}
+
+// Shapes the persistent kernel takes: whole 256x256 tiles, an even number of K-tiles, every operand byte offset
+// inside 32 bits (the tile origin travels in the scalar offset of the buffer load).
+static bool persist_ok(const GemmParams& p) {
+  return p.cin == 0 && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 128 == 0 &&
+         ((int64_t)(p.batch - 1) * p.a_bs + (int64_t)p.M * p.lda) * 2 < (1ll << 32) && (int64_t)p.N * p.ldw * 2 < (1ll << 32);
 }
 
 template <int ABL>
@@ -573,10 +919,45 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       case 96: return launch_ablation<96>(p, st);
       case 18: return launch_ablation<18>(p, st);
       case 17: return launch_ablation<17>(p, st);
+      case 32768: return launch_ablation<32768>(p, st);
+      case 65536: return launch_ablation<65536>(p, st);
+      case 98304: return launch_ablation<98304>(p, st);
     }
     return fail("gemm: unknown ablation");
   }
-  if (variant == 1) {
+  if ((variant == 1 || variant == 3) && persist_ok(p)) {
+    static int grid = 0;
+    if (!grid) {
+      int dev = 0, cus = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+      const void* fns[4] = {(const void*)gemm8pp_kernel<EPI, 0>, (const void*)gemm8pp_kernel<EPI, 1>,
+                            (const void*)gemm8pp_kernel<EPI, 2>, (const void*)gemm8pp_kernel<EPI, 3>};
+      for (const void* fn : fns) {
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, fn);
+        (void)hipGetLastError();
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL);
+        if (e != hipSuccess)
+          return fail("gemm: cannot raise dynamic LDS limit to %d bytes: %s", PP_LDS_TOTAL, hipGetErrorString(e));
+      }
+      grid = cus & ~7;  // one block per CU (160 KiB of LDS each), a whole number per XCD
+    }
+    if (p.batch * p.tm * p.tn > grid) {
+      const bool prof = prof_on(st);
+      if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
+      switch (g_gemm_place) {
+        case 0: gemm8pp_kernel<EPI, 0><<<grid, 512, PP_LDS_TOTAL, st>>>(p); break;
+        case 2: gemm8pp_kernel<EPI, 2><<<grid, 512, PP_LDS_TOTAL, st>>>(p); break;
+        case 3: gemm8pp_kernel<EPI, 3><<<grid, 512, PP_LDS_TOTAL, st>>>(p); break;
+        default: gemm8pp_kernel<EPI, 1><<<grid, 512, PP_LDS_TOTAL, st>>>(p); break;
+      }
+      if (prof) prof_end(0, st);
+      return check_launch("gemm_bf16");
+    }
+  }
+  if (variant == 3) return fail("gemm: shape not eligible for the persistent kernel");
+  if (variant == 1 || variant == 2) {
     const bool conv = p.cin > 0;
     static bool attr_set[2] = {false, false};
     if (!attr_set[conv]) {

@@ -48,6 +48,7 @@ struct GemmArgs {
   const void* zero_page = nullptr;
 };
 void set_gemm_group_m(int gm);
+void set_gemm_place(int v);
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
 
