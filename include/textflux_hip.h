@@ -37,7 +37,9 @@ int tfx_query_arch(char* buf, int buflen);
  *      epilogue: 0 bias | 1 bias, then tanh-GELU on columns >= gelu_from_col (activations.py:83; the split form is the
  *      fused [k|v|q|mlp] projection of FluxSingleTransformerBlock) | 3 C = res + (A@W^T + bias) | 2 C = res + gate[b,:] * (A@W^T + bias)
  *      (gated residual, transformer_flux.py:733-735, 817-818, 824-826, 830-831, 837; res may alias C).
- *      variant: -1 auto, 0 generic FMA kernel (any shape), 1 MFMA kernel (K % 64 == 0, N % 8 == 0, 16-byte aligned). */
+ *      variant: -1 auto, 0 generic FMA kernel (any shape), 1 MFMA path (K % 64 == 0, N % 8 == 0, 16-byte aligned;
+ *      the persistent kernel when K % 128 == 0, else the one-tile kernel), 2 / 3 force the one-tile / persistent MFMA
+ *      kernel (tests: the two agree bit for bit). */
 typedef struct tfx_gemm_args {
   const void* A; int64_t lda; int64_t a_bstride;
   const void* W; int64_t ldw;
@@ -156,7 +158,9 @@ int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* 
                        int64_t HW, int32_t C, int32_t groups, float eps, int32_t silu, tfx_stream stream);
 
 /* ---- tuning knobs (no reference counterpart).  "attention_waves": 8 = one 512-thread workgroup of 256 query rows per
- *      CU, 4 = two independent 256-thread workgroups of 128 query rows per CU. */
+ *      CU (default), 4 = two independent 256-thread workgroups of 128 query rows per CU, 9 = 8 waves with 128 keys per
+ *      barrier, 16 = ping-pong variant.  "gemm_group_m": row tiles per group of the GEMM tile order (default 4).
+ *      "gemm_place": slot assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip). */
 int tfx_set_option(const char* name, int value);
 
 /* ---- measurement hooks (no reference counterpart: the reference has no profiling) --------------------

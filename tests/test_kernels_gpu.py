@@ -39,7 +39,7 @@ def close(got, ref, max_rel=1e-2, mae_rel=2e-3):
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K,batch", [(256, 256, 64, 1), (300, 264, 128, 2), (37, 72, 192, 3), (1024, 768, 3072, 1),
                                          (520, 3072, 384, 2), (8, 3072, 256, 1), (4, 64, 64, 1)])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])   # 0 generic FMA, 1 MFMA (persistent kernel when K % 128 == 0), 2 one-tile MFMA
 def test_gemm_bias(ops, M, N, K, batch, variant):
     a, w, b = rnd((batch, M, K), 1).to(BF), rnd((N, K), 2, 0.05).to(BF), rnd((N,), 3).to(BF)
     ref = a.float() @ w.float().T + b.float()
@@ -52,7 +52,7 @@ def test_gemm_generic_odd_k(ops):
     close(ops.gemm(a.cuda(), w.cuda(), b.cuda()), (a.float() @ w.float().T + b.float()).to(BF))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_gemm_gelu_split_and_strided(ops, variant):
     """The single-block fused projection: plain bias below column 256, tanh-GELU from column 256 on; A and C are
     column slices of wider buffers (lda/ldc > row length)."""
@@ -69,7 +69,7 @@ def test_gemm_gelu_split_and_strided(ops, variant):
     assert cbuf[:, :, :128].abs().max().item() == 0  # nothing written outside the slice
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_gemm_gate_residual_inplace(ops, variant):
     B, M, K, N = 2, 200, 256, 256
     a, w, b = rnd((B, M, K), 7).to(BF), rnd((N, K), 8, 0.05).to(BF), rnd((N,), 9).to(BF)
@@ -87,6 +87,35 @@ def test_gemm_fast_matches_generic_on_device(ops):
     w = (rnd((1032, 3072), 13, 0.03) - 0.01).to(BF).cuda()
     b = rnd((1032,), 14).to(BF).cuda()
     close(ops.gemm(a, w, b, variant=1), ops.gemm(a, w, b, variant=0), max_rel=5e-3, mae_rel=1e-3)
+
+
+@pytest.mark.parametrize("B,M,N,K", [(1, 36864, 3072, 256), (3, 5120, 9216, 384), (2, 5248, 3072, 384), (2, 1000, 3136, 128),
+                                     (1, 512, 3072, 3072), (1, 8, 64, 128), (3, 4736, 3328, 256)])
+def test_gemm_persistent_bit_identical_to_one_tile_kernel(ops, B, M, N, K):
+    """The persistent kernel (variant 3; many tiles per block, next-tile prefetch, chunked epilogue, both request
+    placements) accumulates in the same order as the one-tile kernel (variant 2): every epilogue must agree bit for bit,
+    including ragged M / N edges, batch strides and grids smaller and larger than the CU count."""
+    a, w = rnd((B, M, K), 21).to(BF).cuda(), rnd((N, K), 22, 0.05).to(BF).cuda()
+    bias, gate, res = rnd((N,), 23).to(BF).cuda(), rnd((B, N), 24).to(BF).cuda(), rnd((B, M, N), 25).to(BF).cuda()
+    cases = [(ops.EPI_BIAS, {}), (ops.EPI_BIAS_GELU, dict(gelu_from_col=max(0, (N // 256 - 1) * 256))),
+             (ops.EPI_BIAS_GATE_RES, dict(gate=gate, res=res)), (ops.EPI_BIAS_RES, dict(res=res))]
+    try:
+        for epi, kw in cases:
+            one = torch.full((B, M, N), 7.0, dtype=BF, device="cuda")
+            ops.gemm(a, w, bias, out=one, epilogue=epi, variant=2, **kw)
+            for place in (1, 2):
+                ops.set_option("gemm_place", place)
+                per = torch.full((B, M, N), 9.0, dtype=BF, device="cuda")
+                ops.gemm(a, w, bias, out=per, epilogue=epi, variant=3, **kw)
+                assert torch.equal(one, per), (epi, place, (one.float() - per.float()).abs().max().item())
+    finally:
+        ops.set_option("gemm_place", 2)
+
+
+def test_gemm_persistent_rejects_odd_k_tiles(ops):
+    a, w = rnd((512, 192), 1).to(BF).cuda(), rnd((256, 192), 2).to(BF).cuda()
+    with pytest.raises(RuntimeError, match="persistent"):
+        ops.gemm(a, w, None, variant=3)
 
 
 # ----------------------------------------------------------------------------- attention

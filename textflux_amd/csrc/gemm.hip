@@ -501,22 +501,31 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent form of gemm8p_kernel for the DiT shapes (M, N multiples of 256, K multiple of 128, > 256 tiles): one
-// block per CU walks the XCD's contiguous range of the tile order.  The K-loop schedule is the one above; what
-// changes is the boundary between tiles:
-//   * the prefetch slots of a tile's last two K-tiles (which the one-tile kernel points at a sink) request the first
-//     two K-tiles of the block's NEXT tile into the regular buffer sets, so a tile starts with its operands already
-//     in LDS -- no per-tile prologue latency, no sink traffic (2/nt of the L2->LDS bytes);
+// Persistent form of gemm8p_kernel -- the kernel the DiT runs on (any M, N; K a multiple of 128; no conv): one block
+// per CU walks its XCD's contiguous range of the tile order.  Same tile, fragments, MFMA order and barrier ping-pong
+// as above; what changes:
+//   * requests are issued from the LOADS sections.  An LDS-DMA instruction costs its wave ~60 issue cycles; issued
+//     between the MFMAs of a section (above) that is a hole in the matrix pipe, issued while the partner group owns
+//     the pipe it is free as long as the loads section stays under the 256 cycles of the partner's 8 MFMAs.  Each
+//     group stages its own X half and the W stripes {2g, 2g+1}, everything for K-tile u+2 (same buffer set as u):
+//         item 0  X_lo  reads done after L0            item 1  W_lo  after L0 (+1 slot: the partner's read)
+//         item 2  W_hi  after L1 (+1)                  item 3  X_hi  after L2
+//     PLACE 1:  L1 {0,1}  L3 {2,3}          PLACE 2 (default):  L1 {0}  L2 {1}  L3 {2,3}
+//     Deadlines (issuer's own counted wait, one barrier before the first reader): items 0,1 at L3 of K-tile u+1,
+//     item 2 at L0 of u+2, item 3 at L1 of u+2 -> vmcnt 12 / 10 / 12 (PLACE 1) or 12 / 10 / 10 (PLACE 2); every
+//     request has >= 10 slots (~2.5k cycles) in flight, the MFMA sections carry nothing but MFMAs;
+//   * the requests of a tile's last two K-tiles fetch K-tiles 0 and 1 of the block's NEXT tile, so a tile starts
+//     with its operands in LDS: no per-tile prologue latency, no sink traffic;
 //   * the epilogue stages through its own 32 KiB (8 waves x 32 rows x 128 B, XOR-swizzled 16-byte chunks) behind
-//     the two sets instead of reusing them, one 32-row block of the accumulators at a time;
-//   * the two row groups stay one barrier apart across tiles, so one group's epilogue overlaps the other's MFMAs.
-// Operands are addressed through ONE buffer descriptor per matrix with the tile origin folded into the scalar
-// offset (fits 32 bits: checked by persist_ok), so switching to the next tile's addresses is a scalar move.
+//     the two sets, one 32-row block of the accumulators at a time;
+//   * the two row groups stay one barrier apart across tiles: one group's epilogue overlaps the other's MFMAs.
+// Operands are addressed through ONE buffer descriptor per matrix, the tile origin folded into the scalar offset
+// (32 bits, checked by persist_ok); rows beyond M / N are clamped on the way in and never stored.
 constexpr int PP_STG = 131072;
 constexpr int PP_STG_WAVE = 4096;
 constexpr int PP_LDS_TOTAL = PP_STG + 8 * PP_STG_WAVE;  // 163840 = all of the CU's LDS
 
-template <int EPI, int PLACE = 1>
+template <int EPI, int PLACE = 2>
 __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -553,65 +562,45 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     return t;
   };
 
-  // ---- prefetch items; no edge clamps: M, N are multiples of 256.
-  // PLACE 0: the table and slots of gemm8p_kernel (requests issued between the two accumulate chains of an MFMA
-  //          section).
-  // PLACE >= 1: every request is issued from a LOADS section -- the partner group owns the matrix pipe there, so the
-  //          ~60 issue cycles an LDS-DMA instruction costs its wave no longer open a hole in the MFMA stream.  Each
-  //          group stages its own X half and W stripes {2g, 2g+1}, all for K-tile u+2 (same buffer set as u):
-  //            item 0 X_lo  free after slot L0   item 1 W_lo  free after L0 (+1 for the partner's read)
-  //            item 2 W_hi  free after L1 (+1)   item 3 X_hi  free after L2
-  //          PLACE 1: L1 {0,1}  L3 {2,3} | PLACE 2: L1 {0}  L2 {1}  L3 {2,3} | PLACE 3: L1 {0}  L3 {1,2,3}
-  //          Deadlines (issuer's wait, one barrier before the first reader): items 0,1 at L3 of tile u+1, item 2 at
-  //          L0 of u+2, item 3 at L1 of u+2 -> vmcnt 12 / 10 / 12 (PLACE 1) or 12 / 10 / 10 (PLACE 2, 3).
+  // ---- request items: piece = 8 consecutive LDS rows written by one wave instruction, 2 pieces per item and wave;
+  // 16-byte chunks XOR-swizzled with ((row >> 1) & 7) on the per-lane SOURCE address (LDS image stays lane-linear)
   const int lr = lane >> 3, cphys = lane & 7;
-  int goff[4][2];
   uint32_t ldst[4][2];
-  bool isx[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    bool x_item;
-    if (PLACE == 0) x_item = g == 0 ? (q == 0 || q == 1) : (q == 0 || q == 2);
-    else x_item = (q == 0 || q == 3);
-    isx[q] = x_item;
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int pc = wc * 2 + j;
-      int row0;
-      if (PLACE == 0) {
-        if (x_item) {
-          row0 = (q == 0 ? 64 : 0) + pc * 8;
-        } else {
-          const int whi_item = (q == 3);
-          const int half = g == 0 ? (q == 2 ? 128 : 0) : (q == 1 ? 0 : 128);
-          row0 = half + (pc >> 2) * 64 + whi_item * 32 + (pc & 3) * 8;
-        }
-      } else {
-        if (x_item) row0 = (q == 3 ? 64 : 0) + pc * 8;
-        else row0 = g * 128 + (pc >> 2) * 64 + (q == 2 ? 32 : 0) + (pc & 3) * 8;
-      }
-      const int row = row0 + lr;
-      const int clog = cphys ^ ((row >> 1) & 7);
-      if (x_item) {
-        goff[q][j] = ((g * 128 + row) * (int)p.lda + clog * 8) * 2;
-        ldst[q][j] = LDS_X + g * 32768 + row0 * 128;
-      } else {
-        goff[q][j] = (row * (int)p.ldw + clog * 8) * 2;
-        ldst[q][j] = LDS_W + row0 * 128;
-      }
+      if (q == 0 || q == 3) ldst[q][j] = LDS_X + g * 32768 + ((q == 3 ? 64 : 0) + pc * 8) * 128;
+      else ldst[q][j] = LDS_W + (g * 128 + (pc >> 2) * 64 + (q == 2 ? 32 : 0) + (pc & 3) * 8) * 128;
     }
-  }
+  // per-lane byte offsets from the tile origin (edge tiles: rows beyond M / N re-read the last valid row)
+  auto offsets = [&](const Tile& t, int (&go)[4][2]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int pc = wc * 2 + j;
+        const bool x_item = (q == 0 || q == 3);
+        const int row0 = x_item ? (q == 3 ? 64 : 0) + pc * 8 : g * 128 + (pc >> 2) * 64 + (q == 2 ? 32 : 0) + (pc & 3) * 8;
+        const int row = row0 + lr;
+        const int clog = cphys ^ ((row >> 1) & 7);
+        if (x_item) go[q][j] = (min(g * 128 + row, p.M - 1 - t.m0) * (int)p.lda + clog * 8) * 2;
+        else go[q][j] = (min(row, p.N - 1 - t.n0) * (int)p.ldw + clog * 8) * 2;
+      }
+  };
   const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
   const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
 
-  // request item q of K-tile kt of the tile whose origins are (xo, wo) into buffer set `set`
-  auto stage = [&](int q, uint32_t xo, uint32_t wo, int kt, int set) {
-    const auto rs = isx[q] ? rsrcX : rsrcW;
-    const uint32_t so = (isx[q] ? xo : wo) + (uint32_t)kt * 128u;
-    const uint32_t setoff = set * (isx[q] ? 16384u : 32768u);
+  // request item q of K-tile kt of the tile with origins (xo, wo) and lane offsets go into buffer set `set`
+  auto stage = [&](int q, const int (&go)[4][2], uint32_t xo, uint32_t wo, int kt, int set) {
+    const bool x_item = (q == 0 || q == 3);
+    const uint32_t so = (x_item ? xo : wo) + (uint32_t)kt * 128u;
+    const uint32_t setoff = set * (x_item ? 16384u : 32768u);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + ldst[q][j] + setoff), 16, goff[q][j], so, 0, GLDS_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_item ? rsrcX : rsrcW, (lds_void*)(smem + ldst[q][j] + setoff), 16, go[q][j], so,
+                                               0, GLDS_AUX);
   };
 
   const int hi = lane >> 5;
@@ -625,11 +614,13 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   }
 
   Tile cur = coords(xstart + it);
-  // ---- prologue (first tile of the block only)
+  int goc[4][2], gon[4][2];
+  offsets(cur, goc);
+  // ---- prologue (first tile of the block only): K-tiles 0 and 1 complete
 #pragma unroll
-  for (int q = 0; q < 4; ++q) stage(q, cur.xoff, cur.woff, 0, 0);
+  for (int q = 0; q < 4; ++q) stage(q, goc, cur.xoff, cur.woff, 0, 0);
 #pragma unroll
-  for (int q = (PLACE == 0 ? 1 : 0); q < 4; ++q) stage(q, cur.xoff, cur.woff, 1, 1);
+  for (int q = 0; q < 4; ++q) stage(q, goc, cur.xoff, cur.woff, 1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TFX_BARRIER();
   if (g == 1) TFX_BARRIER();  // stagger: G1 runs one barrier behind G0, for the whole life of the block
@@ -637,82 +628,52 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   f32x16 acc[4][2];
   bf16x8 xf[2][4], wlo[4], whi[4];
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
-#define PP_WAIT() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
-#define PP_MFMA8(WF, ROWBASE, NJ, MID)                                                                       \
+#define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+  // same-accumulator MFMAs back to back (D -> C forwarding costs no wait states); the empty asm statements pin each
+  // chain inside its section -- the intrinsics are pure, nothing else stops hipcc from moving them across a barrier
+#define PP_MFMA8(WF, ROWBASE, NJ)                                                                            \
   do {                                                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                         \
       acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
-    asm volatile("" : "+v"(acc[ROWBASE][NJ]));  /* pins the chain in front of the prefetch issue */           \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    MID;                                                                                                     \
+    asm volatile("" : "+v"(acc[ROWBASE][NJ]));                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                         \
       acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
-    asm volatile("" : "+v"(acc[ROWBASE + 1][NJ]));  /* ... and this one in front of the closing barrier */    \
+    asm volatile("" : "+v"(acc[ROWBASE + 1][NJ]));                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
-  // one K-tile: SET = its buffer set; S0..S3 = the prefetch issued in the MFMA section of phase q0..q3
-#define PP_TILE(SET, S0, S1, S2, S3)                                                                         \
+  // one K-tile out of buffer set SET; (GO, XO, WO, KT) = the operands requested meanwhile (two K-tiles ahead)
+#define PP_TILE(SET, GO, XO, WO, KT)                                                                         \
   do {                                                                                                       \
     constexpr uint32_t xs = (SET) * 16384u, ws = (SET) * 32768u;                                             \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                       \
-      xf[0][kk] = LDS_FRAG(fx[kk] + xs);                                                                     \
-      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);                                                              \
-      wlo[kk] = LDS_FRAG(fw[kk] + ws);                                                                       \
-    }                                                                                                        \
-    PP_WAIT(); TFX_BARRIER();                                                                                \
-    PP_MFMA8(wlo, 0, 0, S0);                                                                                 \
-    TFX_BARRIER();                                                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);                 \
-    PP_WAIT(); TFX_BARRIER();                                                                                \
-    PP_MFMA8(whi, 0, 1, S1);                                                                                 \
-    TFX_BARRIER();                                                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                       \
-      xf[0][kk] = LDS_FRAG(fx[kk] + xs + 8192);                                                              \
-      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);                                                             \
-    }                                                                                                        \
-    PP_WAIT(); TFX_BARRIER();                                                                                \
-    PP_MFMA8(whi, 2, 1, S2);                                                                                 \
-    TFX_BARRIER();                                                                                           \
-    PP_WAIT(); TFX_BARRIER();                                                                                \
-    PP_MFMA8(wlo, 2, 0, S3);                                                                                 \
-    TFX_BARRIER();                                                                                           \
-  } while (0)
-
-  // PLACE >= 1: XO, WO, KT = origin and K-tile of the operands requested during this K-tile (two K-tiles ahead)
-#define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define PP_TILE_L(SET, XO, WO, KT)                                                                           \
-  do {                                                                                                       \
-    constexpr uint32_t xs = (SET) * 16384u, ws = (SET) * 32768u;                                             \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {            /* L0: X_lo, W_lo */                       \
       xf[0][kk] = LDS_FRAG(fx[kk] + xs);                                                                     \
       xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);                                                              \
       wlo[kk] = LDS_FRAG(fw[kk] + ws);                                                                       \
     }                                                                                                        \
     PP_VMCNT(10); TFX_BARRIER();                                                                             \
-    PP_MFMA8(wlo, 0, 0, (void)0);                                                                            \
+    PP_MFMA8(wlo, 0, 0);                                                                                     \
     TFX_BARRIER();                                                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);                 \
-    stage(0, XO, WO, KT, SET);                                                                               \
-    if (PLACE == 1) { stage(1, XO, WO, KT, SET); PP_VMCNT(12); } else { PP_VMCNT(10); }                      \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);  /* L1: W_hi */ \
+    stage(0, GO, XO, WO, KT, SET);                                                                           \
+    if (PLACE == 1) { stage(1, GO, XO, WO, KT, SET); PP_VMCNT(12); } else { PP_VMCNT(10); }                  \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA8(whi, 0, 1, (void)0);                                                                            \
+    PP_MFMA8(whi, 0, 1);                                                                                     \
     TFX_BARRIER();                                                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {            /* L2: X_hi */                             \
       xf[0][kk] = LDS_FRAG(fx[kk] + xs + 8192);                                                              \
       xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);                                                             \
     }                                                                                                        \
-    if (PLACE == 2) stage(1, XO, WO, KT, SET);                                                               \
+    if (PLACE != 1) stage(1, GO, XO, WO, KT, SET);                                                           \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA8(whi, 2, 1, (void)0);                                                                            \
+    PP_MFMA8(whi, 2, 1);                                                                                     \
     TFX_BARRIER();                                                                                           \
-    if (PLACE == 3) stage(1, XO, WO, KT, SET);                                                               \
-    stage(2, XO, WO, KT, SET);                                                                               \
-    stage(3, XO, WO, KT, SET);                                                                               \
+    stage(2, GO, XO, WO, KT, SET);                                /* L3: no reads */                         \
+    stage(3, GO, XO, WO, KT, SET);                                                                           \
     PP_VMCNT(12); TFX_BARRIER();                                                                             \
-    PP_MFMA8(wlo, 2, 0, (void)0);                                                                            \
+    PP_MFMA8(wlo, 2, 0);                                                                                     \
     TFX_BARRIER();                                                                                           \
   } while (0)
 
@@ -723,6 +684,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     // the last tile of the block re-requests its own first K-tiles: harmless (nobody reads them) and keeps the
     // load counts of the waits uniform
     const Tile nxt = coords(xstart + (has_next ? nit : it));
+    offsets(nxt, gon);
     const uint32_t cx = cur.xoff, cw = cur.woff, nx = nxt.xoff, nw = nxt.woff;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -731,22 +693,12 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (PLACE == 0) {
-      for (int u = 0; u < nt - 2; u += 2) {
-        PP_TILE(0, stage(0, cx, cw, u + 1, 1), stage(1, cx, cw, u + 2, 0), stage(2, cx, cw, u + 2, 0), stage(3, cx, cw, u + 2, 0));
-        PP_TILE(1, stage(0, cx, cw, u + 2, 0), stage(1, cx, cw, u + 3, 1), stage(2, cx, cw, u + 3, 1), stage(3, cx, cw, u + 3, 1));
-      }
-      // K-tiles nt-2 and nt-1: their "two ahead" slots carry the next tile's K-tiles 0 and 1
-      PP_TILE(0, stage(0, cx, cw, nt - 1, 1), stage(1, nx, nw, 0, 0), stage(2, nx, nw, 0, 0), stage(3, nx, nw, 0, 0));
-      PP_TILE(1, stage(0, nx, nw, 0, 0), stage(1, nx, nw, 1, 1), stage(2, nx, nw, 1, 1), stage(3, nx, nw, 1, 1));
-    } else {
-      for (int u = 0; u < nt - 2; u += 2) {
-        PP_TILE_L(0, cx, cw, u + 2);
-        PP_TILE_L(1, cx, cw, u + 3);
-      }
-      PP_TILE_L(0, nx, nw, 0);
-      PP_TILE_L(1, nx, nw, 1);
+    for (int u = 0; u < nt - 2; u += 2) {
+      PP_TILE(0, goc, cx, cw, u + 2);
+      PP_TILE(1, goc, cx, cw, u + 3);
     }
+    PP_TILE(0, gon, nx, nw, 0);  // K-tiles nt-2, nt-1: their requests are the next tile's K-tiles 0 and 1
+    PP_TILE(1, gon, nx, nw, 1);
 
     // ---- epilogue (see gemm8p_kernel for the lane -> element map), one 32-row accumulator block at a time
     const int m0 = cur.m0, n0 = cur.n0, b = cur.b;
@@ -761,15 +713,16 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const int n = ncol + nj * 32 + qd * 8;
+        const int nc = n < p.N ? n : 0;  // columns beyond N are computed but never stored
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bs[nj][qd][e] = 0.f; gt[nj][qd][e] = 0.f; }
         if (p.bias) {
-          const u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n);
+          const u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + nc);
           bs[nj][qd][0] = __uint_as_float(raw[0] << 16); bs[nj][qd][1] = __uint_as_float(raw[0] & 0xffff0000u);
           bs[nj][qd][2] = __uint_as_float(raw[1] << 16); bs[nj][qd][3] = __uint_as_float(raw[1] & 0xffff0000u);
         }
         if (EPI == EPI_BIAS_GATE_RES) {
-          const u32x2 raw = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + n);
+          const u32x2 raw = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + nc);
           gt[nj][qd][0] = __uint_as_float(raw[0] << 16); gt[nj][qd][1] = __uint_as_float(raw[0] & 0xffff0000u);
           gt[nj][qd][2] = __uint_as_float(raw[1] << 16); gt[nj][qd][3] = __uint_as_float(raw[1] & 0xffff0000u);
         }
@@ -804,40 +757,45 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
           *reinterpret_cast<u32x2*>(stg + r32 * 128 + ((c ^ (r32 & 7)) << 4) + ((hi ^ ((r32 >> 3) & 1)) << 3)) = o;
         }
       // wave-private region + in-order LDS pipe: no barrier between the writes above and the reads below
+      if (nst < p.N) {
 #pragma unroll
-      for (int itr = 0; itr < 4; ++itr) {
-        const int row = itr * 8 + crow;
-        const int m = m0 + g * 128 + mi * 32 + row;
-        u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((cchunk ^ (row & 7)) << 4));
-        if (itr & 1) { const uint32_t t0 = val[0], t1 = val[1]; val[0] = val[2]; val[1] = val[3]; val[2] = t0; val[3] = t1; }
-        if (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES) {
-          const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + nst);
-          float fv[8], fr[8];
-          unpack8(val, fv);
-          unpack8(rr, fr);
+        for (int itr = 0; itr < 4; ++itr) {
+          const int row = itr * 8 + crow;
+          const int m = m0 + g * 128 + mi * 32 + row;
+          if (m >= p.M) continue;
+          u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((cchunk ^ (row & 7)) << 4));
+          if (itr & 1) { const uint32_t t0 = val[0], t1 = val[1]; val[0] = val[2]; val[1] = val[3]; val[2] = t0; val[3] = t1; }
+          if (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES) {
+            const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + nst);
+            float fv[8], fr[8];
+            unpack8(val, fv);
+            unpack8(rr, fr);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) fv[e] += fr[e];
-          val = pack8(fv);
+            for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+            val = pack8(fv);
+          }
+          *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
         }
-        *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
       }
     }
     if (!has_next) break;
     cur = nxt;
     it = nit;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) goc[q][j] = gon[q][j];
   }
   if (g == 0) TFX_BARRIER();  // pairs with G1's extra barrier of the prologue
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the closing requests must not land in a successor's LDS
 #undef LDS_FRAG
-#undef PP_WAIT
+#undef PP_VMCNT
 #undef PP_MFMA8
 #undef PP_TILE
-#undef PP_TILE_L
-#undef PP_VMCNT
 }
 
 // ------------------------------------------------------------------------------------------------
-static int g_gemm_place = 1;      // request placement of the persistent kernel (bench knob, see gemm8pp_kernel)
+static int g_gemm_place = 2;      // request placement of the persistent kernel (bench knob, see gemm8pp_kernel)
 void set_gemm_place(int v) { g_gemm_place = v; }
 static int g_gemm_group_m = 4;  // row tiles per group of the tile order (L2 locality knob)
 void set_gemm_group_m(int gm) { g_gemm_group_m = gm < 1 ? 1 : gm; }
@@ -876,11 +834,13 @@ static bool fast_ok(const GemmArgs& a) {
          (a.epilogue != EPI_BIAS_GELU || a.gelu_from_col % 256 == 0);
 }
 
-// Shapes the persistent kernel takes: whole 256x256 tiles, an even number of K-tiles, every operand byte offset
-// inside 32 bits (the tile origin travels in the scalar offset of the buffer load).
+// Shapes the persistent kernel takes: an even number of K-tiles and every operand byte offset inside 32 bits (the
+// tile origin travels in the scalar offset of the buffer load).  Everything else the MFMA path accepts goes to the
+// one-tile kernel.
 static bool persist_ok(const GemmParams& p) {
-  return p.cin == 0 && p.M % 256 == 0 && p.N % 256 == 0 && p.K % 128 == 0 &&
-         ((int64_t)(p.batch - 1) * p.a_bs + (int64_t)p.M * p.lda) * 2 < (1ll << 32) && (int64_t)p.N * p.ldw * 2 < (1ll << 32);
+  return p.cin == 0 && p.K % 128 == 0 &&
+         ((int64_t)(p.batch - 1) * p.a_bs + (int64_t)p.tm * 256 * p.lda) * 2 < (1ll << 32) &&
+         (int64_t)p.tn * 256 * p.ldw * 2 < (1ll << 32);
 }
 
 template <int ABL>
@@ -931,10 +891,9 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       int dev = 0, cus = 0;
       (void)hipGetDevice(&dev);
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-      const void* fns[4] = {(const void*)gemm8pp_kernel<EPI, 0>, (const void*)gemm8pp_kernel<EPI, 1>,
-                            (const void*)gemm8pp_kernel<EPI, 2>, (const void*)gemm8pp_kernel<EPI, 3>};
+      const void* fns[2] = {(const void*)gemm8pp_kernel<EPI, 1>, (const void*)gemm8pp_kernel<EPI, 2>};
       for (const void* fn : fns) {
-        hipFuncAttributes fa;
+        hipFuncAttributes fa;  // forces the (lazily loaded) code object in before the attribute is set
         (void)hipFuncGetAttributes(&fa, fn);
         (void)hipGetLastError();
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL);
@@ -943,18 +902,12 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       }
       grid = cus & ~7;  // one block per CU (160 KiB of LDS each), a whole number per XCD
     }
-    if (p.batch * p.tm * p.tn > grid) {
-      const bool prof = prof_on(st);
-      if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
-      switch (g_gemm_place) {
-        case 0: gemm8pp_kernel<EPI, 0><<<grid, 512, PP_LDS_TOTAL, st>>>(p); break;
-        case 2: gemm8pp_kernel<EPI, 2><<<grid, 512, PP_LDS_TOTAL, st>>>(p); break;
-        case 3: gemm8pp_kernel<EPI, 3><<<grid, 512, PP_LDS_TOTAL, st>>>(p); break;
-        default: gemm8pp_kernel<EPI, 1><<<grid, 512, PP_LDS_TOTAL, st>>>(p); break;
-      }
-      if (prof) prof_end(0, st);
-      return check_launch("gemm_bf16");
-    }
+    const bool prof = prof_on(st);
+    if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
+    if (g_gemm_place == 1) gemm8pp_kernel<EPI, 1><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+    else gemm8pp_kernel<EPI, 2><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+    if (prof) prof_end(0, st);
+    return check_launch("gemm_bf16");
   }
   if (variant == 3) return fail("gemm: shape not eligible for the persistent kernel");
   if (variant == 1 || variant == 2) {
