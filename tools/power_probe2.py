@@ -30,9 +30,11 @@ def probe(name, fn, secs=4.0):
     dt = time.time() - t0
     stop.set(); th.join(timeout=3)
     a = acc[3:] or acc
-    print(f"{name}: {dt / n * 1e3:.3f} ms/launch; sclk {sum(x[0] for x in a) / len(a):.0f} MHz, {sum(x[1] for x in a) / len(a):.0f} W ({len(a)} samples)", flush=True)
+    ms, w = dt / n * 1e3, sum(x[1] for x in a) / len(a)
+    print(f"{name}: {ms:.3f} ms/launch; sclk {sum(x[0] for x in a) / len(a):.0f} MHz, {w:.0f} W, {ms * w / 1e3:.3f} J/launch ({len(a)} samples)", flush=True)
+    return ms, w
 
-for (M, N, K) in [(36864, 9216, 3072), (36864, 3072, 12288)]:
+for (M, N, K) in ([(36864, 9216, 3072), (36864, 3072, 12288)] if __name__ == "__main__" else []):
     x = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * 0.02).to(BF)
     b = torch.randn(N, device="cuda").to(BF); out = torch.empty(M, N, dtype=BF, device="cuda")
     xs = (torch.randn(M, K, device="cuda") * 0.05).to(BF)
