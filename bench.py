@@ -178,6 +178,13 @@ def main():
                             f"profiles/r01_gemm_pmc_traffic.json")
         except Exception:
             pass
+        mfma_pmc = None
+        try:  # matrix-pipe busy fraction of the DiT kernels from the committed SQ_VALU_MFMA_BUSY_CYCLES pass over this bench
+            with open(os.path.join(REPO, "profiles", "r01_mfma_util.json")) as f:
+                mu = json.load(f)
+            mfma_pmc = {"dit_kernels": mu["dit_kernels_total"]["mfma_util"], "source": "profiles/r01_mfma_util.json (" + mu["formula"] + ")"}
+        except Exception:
+            pass
         rec = {
             "metric": "images/sec (whole node), 1024x1024 30-step FLUX-Fill" if (H, W, n) == (1024, 1024, 30) else
                       f"images/sec (whole node), {H}x{W} {n}-step FLUX-Fill",
@@ -191,16 +198,16 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, conditioning broadcast over RCCL)"},
             "sec_per_img_per_gpu": elapsed / (B * a.steps),
             "dit_algorithmic_tflops_per_gpu": dit_flops(S) * n * B * a.steps / elapsed / 1e12 if full else None,
-            "roofline": {"bound": "mfma", "kernel": "tfx::gemm8p_kernel (all epilogues)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "tfx::gemm8pp_kernel (persistent MFMA GEMM, all epilogues; + gemm8p_kernel for K % 128 != 0)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_note": traffic_note, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                         "traffic": traffic, "traffic_note": traffic_note, "mfma_busy_pmc": mfma_pmc, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "flops_per_launch": gemm_fl / max(gemm_n, 1),
                          "attention": {"achieved": att_fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0,
                                        "launches": att_n, "avg_launch_ms": att_ms / max(att_n, 1)}},
         }
         rec["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(H, W, n)   # rank 0 at N = 1 only
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
