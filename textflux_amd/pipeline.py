@@ -14,6 +14,7 @@ from __future__ import annotations
 import inspect
 import json
 import os
+import warnings
 from types import SimpleNamespace
 from typing import Any, Callable, Dict, List, Optional, Union
 
@@ -453,15 +454,24 @@ class FluxFillPipeline:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             saved = [gb[k].clone() for k in ("lat", "step")] + [ses.xin.clone()]
-            with torch.cuda.graph(g):
-                one_step()
+            try:
+                # thread_local: a collective watchdog thread (RCCL) touching the runtime must not invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    one_step()
+            except RuntimeError as e:   # capture refused (driver / runtime state): same kernels, launched eagerly
+                warnings.warn(f"hipGraph capture of the denoising step failed ({e}); running the step loop eagerly")
+                torch.cuda.synchronize()
+                g = False
             # capture does not execute, but keep the state explicit in case a backend replays during instantiate
             gb["lat"].copy_(saved[0]); gb["step"].copy_(saved[1]); ses.xin.copy_(saved[2])
             ses.graphs[key] = g
         for i in range(1, n):
             if is_amo and not internal_noise:
                 gb["noise"].copy_(amo_noise[i].to(dev, torch.float32))
-            g.replay()
+            if g is False:
+                one_step()
+            else:
+                g.replay()
             progress_bar.update()
         self.scheduler._step_index = n
         return gb["lat"].clone()
