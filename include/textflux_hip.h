@@ -53,6 +53,16 @@ typedef struct tfx_gemm_args {
 } tfx_gemm_args;
 int tfx_gemm_bf16(const tfx_gemm_args* args, int variant, tfx_stream stream);
 
+/* ---- fp8 (OCP e4m3) variant of the same Linear, BASELINE config 5 "fp8 weights (CDNA4 fp8 MFMA)"; no reference
+ *      counterpart (the reference computes in bf16).  A [batch][M, K] and W [N, K] hold one e4m3 byte per element
+ *      (lda / ldw / a_bstride count elements = bytes), C = (A . W^T) * a_scale[b][m] * w_scale[n] + bias with the same
+ *      epilogues, bf16 output.  K % 256 == 0, rows 16-byte aligned.  tfx_quantize_rows_fp8 produces both operands:
+ *      out = round_e4m3(x / scale), scale[b * s_bstride + row] = max|x[row]| / 448 (1.0 for an all-zero row). */
+int tfx_gemm_fp8(const tfx_gemm_args* args, const float* a_scale, int64_t a_scale_bstride, const float* w_scale,
+                 tfx_stream stream);
+int tfx_quantize_rows_fp8(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride,
+                          float* scale, int64_t s_bstride, int32_t rows, int32_t batch, int32_t K, tfx_stream stream);
+
 /* ---- LayerNorm(no affine, eps) * (1 + scale[b]) + shift[b]   (AdaLayerNormZero / ZeroSingle / Continuous,
  *      D/models/normalization.py:170, 202, 365; norm2 + modulation, transformer_flux.py:820-821, 833-834).
  *      x, out: [batch][rows_per_batch, D]; shift, scale: [batch][D] with stride mod_bstride.  D % 8 == 0, D <= 3072. */
@@ -166,7 +176,7 @@ int tfx_set_option(const char* name, int value);
 /* ---- measurement hooks (no reference counterpart: the reference has no profiling) --------------------
  * When enabled, every MFMA-GEMM (kind 0) / attention (kind 1) launch is bracketed by hipEvents on its own stream and
  * its algorithmic FLOPs (2*M*N*K*batch, 4*B*H*N^2*128) are recorded; tfx_prof_collect waits for those launches and
- * returns the summed kernel time, FLOPs and launch count, then clears the records.  Not capturable into a graph. */
+ * returns the summed kernel time, FLOPs and launch count (kind 2: fp8 GEMM launches), then clears the records.  Not capturable into a graph. */
 int tfx_prof_enable(int on);
 int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches);
 

@@ -160,6 +160,28 @@ int tfx_gemm_bf16(const tfx_gemm_args* g, int variant, tfx_stream stream) {
   return variant < 0 ? gemm_bf16(a, S(stream)) : gemm_bf16_variant(a, variant, S(stream));
 }
 
+int tfx_gemm_fp8(const tfx_gemm_args* g, const float* a_scale, int64_t a_scale_bstride, const float* w_scale,
+                 tfx_stream stream) {
+  if (!g) return fail("tfx_gemm_fp8: null args");
+  GemmArgs a;
+  a.A = g->A; a.lda = g->lda; a.a_bstride = g->a_bstride;
+  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias;
+  a.C = g->C; a.ldc = g->ldc; a.c_bstride = g->c_bstride;
+  a.M = g->M; a.N = g->N; a.K = g->K; a.batch = g->batch;
+  a.epilogue = g->epilogue; a.gelu_from_col = g->gelu_from_col;
+  a.gate = g->gate; a.gate_bstride = g->gate_bstride;
+  a.res = g->res; a.ldr = g->ldr; a.r_bstride = g->r_bstride;
+  a.a_scale = a_scale; a.a_scale_bstride = a_scale_bstride; a.w_scale = w_scale;
+  if (!a.A || !a.W || !a.C) return fail("tfx_gemm_fp8: null matrix pointer");
+  return gemm_fp8(a, S(stream));
+}
+
+int tfx_quantize_rows_fp8(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride,
+                          float* scale, int64_t s_bstride, int32_t rows, int32_t batch, int32_t K, tfx_stream stream) {
+  if (!x || !out || !scale) return fail("tfx_quantize_rows_fp8: null pointer");
+  return quantize_rows_fp8(x, ldx, x_bstride, out, ldo, o_bstride, scale, s_bstride, rows, batch, K, S(stream));
+}
+
 int tfx_ln_modulate(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride,
                     const void* shift, const void* scale, int64_t mod_bstride, int32_t rows_per_batch, int32_t batch,
                     int32_t D, float eps, tfx_stream stream) {
@@ -268,7 +290,7 @@ int tfx_debug_attention_timing(void* buf) { set_attention_debug(buf); return 0; 
 
 int tfx_prof_enable(int on) { prof_enable(on); return 0; }
 int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches) {
-  if (kind < 0 || kind > 1) return fail("tfx_prof_collect: kind must be 0 (gemm) or 1 (attention)");
+  if (kind < 0 || kind > 2) return fail("tfx_prof_collect: kind must be 0 (gemm), 1 (attention) or 2 (fp8 gemm)");
   return prof_collect(kind, total_ms, total_flops, launches);
 }
 

@@ -405,4 +405,66 @@ int advance_step(int* step_ptr, hipStream_t st) {
   return check_launch("advance_step");
 }
 
+// ---- per-row absmax quantisation bf16 -> fp8 e4m3 (OCP): one 256-thread block per row, row cached in registers.
+// scale = absmax / 448, out = round_to_e4m3(x / scale); v_cvt_pk_fp8_f32 does not saturate (NaN above 448), hence the clamp.
+template <int VPT>   // 16-byte vectors (8 elements) per thread; K <= 256 * 8 * VPT
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, int64_t x_bs, uint8_t* __restrict__ out,
+                                                            int64_t ldo, int64_t o_bs, float* __restrict__ scale, int64_t s_bs, int rows, int K) {
+  const int row = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const bf16_t* xr = x + b * x_bs + (int64_t)row * ldx;
+  u32x4 v[VPT];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = (tid + i * 256) * 8;
+    v[i] = u32x4{0, 0, 0, 0};
+    if (c < K) v[i] = *reinterpret_cast<const u32x4*>(xr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[i][e] << 16)));
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[i][e] & 0xffff0000u)));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  __shared__ float red[4];
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / sc;
+  if (tid == 0) scale[b * s_bs + row] = sc;
+  uint8_t* orow = out + b * o_bs + (int64_t)row * ldo;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = (tid + i * 256) * 8;
+    if (c >= K) continue;
+    float f[8];
+    unpack8(v[i], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e] * inv, -448.f), 448.f);
+    uint32_t w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+    *reinterpret_cast<u32x2*>(orow + c) = u32x2{w0, w1};
+  }
+}
+
+int quantize_rows_fp8(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride, float* scale,
+                      int64_t s_bstride, int rows, int batch, int K, hipStream_t st) {
+  if (rows <= 0 || batch <= 0) return 0;
+  if (K <= 0 || K % 8 || ldx % 8 || x_bstride % 8 || ldo % 8 || o_bstride % 8 || (uintptr_t)x % 16 || (uintptr_t)out % 8)
+    return fail("quantize_rows_fp8: K, strides must be multiples of 8 and pointers 16 / 8-byte aligned");
+  if (K > 256 * 8 * 8) return fail("quantize_rows_fp8: K = %d exceeds 16384", K);
+  const dim3 grid(rows, batch);
+  const bf16_t* xp = (const bf16_t*)x;
+  uint8_t* op = (uint8_t*)out;
+  if (K <= 256 * 8 * 2) quant_rows_fp8_kernel<2><<<grid, 256, 0, st>>>(xp, ldx, x_bstride, op, ldo, o_bstride, scale, s_bstride, rows, K);
+  else if (K <= 256 * 8 * 6) quant_rows_fp8_kernel<6><<<grid, 256, 0, st>>>(xp, ldx, x_bstride, op, ldo, o_bstride, scale, s_bstride, rows, K);
+  else quant_rows_fp8_kernel<8><<<grid, 256, 0, st>>>(xp, ldx, x_bstride, op, ldo, o_bstride, scale, s_bstride, rows, K);
+  return check_launch("quantize_rows_fp8");
+}
+
 }  // namespace tfx

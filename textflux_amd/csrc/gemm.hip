@@ -36,6 +36,7 @@ struct GemmParams {
   const bf16_t* res; int64_t ldr, r_bs;
   int cin, inH, inW, oH, oW, cstride, cup, cpad;   // implicit 3x3 convolution (cin > 0), see GemmArgs
   const bf16_t* zero;
+  const float* a_scale; int64_t as_bs; const float* w_scale;   // fp8 kernel only
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -525,7 +526,12 @@ constexpr int PP_STG = 131072;
 constexpr int PP_STG_WAVE = 4096;
 constexpr int PP_LDS_TOTAL = PP_STG + 8 * PP_STG_WAVE;  // 163840 = all of the CU's LDS
 
-template <int EPI, int PLACE = 2>
+// FP8: A and W hold e4m3 bytes.  The byte geometry is the bf16 kernel's -- a K-tile is 128 bytes per row, now 128 k --
+// so staging, swizzle, buffer sets, slots and waits are unchanged; a 32x32 block takes two
+// v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; 64 matrix cycles each) instead of four 32x32x16 bf16 (32 each),
+// i.e. the same 256 cycles per section for twice the k, and the epilogue applies the per-row / per-channel scales.
+// Lane l supplies row (l & 31), k bytes (l >> 5) * 32 .. +32 of a 64-k step (checked by tools/ubench/mfma_fp8_layout.hip).
+template <int EPI, int PLACE = 2, bool FP8 = false>
 __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -533,7 +539,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2;
   const int wc = wave & 3;
-  const int nt = p.K >> 6;
+  constexpr int ESZ = FP8 ? 1 : 2;       // bytes per operand element
+  const int nt = (p.K * ESZ) >> 7;        // K-tiles of 128 bytes per row
 
   // ---- this block's tiles: XCD x owns a contiguous range of the (grouped) tile order; its blocks stride through it
   const int per_batch = p.tm * p.tn;
@@ -557,8 +564,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     idx -= grp * GM * p.tn;
     t.m0 = (first_m + idx % gsz) * 256;
     t.n0 = (idx / gsz) * 256;
-    t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * 2);
-    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * 2);
+    t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * ESZ);
+    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * ESZ);
     return t;
   };
 
@@ -585,8 +592,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
         const int row0 = x_item ? (q == 3 ? 64 : 0) + pc * 8 : g * 128 + (pc >> 2) * 64 + (q == 2 ? 32 : 0) + (pc & 3) * 8;
         const int row = row0 + lr;
         const int clog = cphys ^ ((row >> 1) & 7);
-        if (x_item) go[q][j] = (min(g * 128 + row, p.M - 1 - t.m0) * (int)p.lda + clog * 8) * 2;
-        else go[q][j] = (min(row, p.N - 1 - t.n0) * (int)p.ldw + clog * 8) * 2;
+        if (x_item) go[q][j] = min(g * 128 + row, p.M - 1 - t.m0) * (int)p.lda * ESZ + clog * 16;
+        else go[q][j] = min(row, p.N - 1 - t.n0) * (int)p.ldw * ESZ + clog * 16;
       }
   };
   const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
@@ -608,7 +615,9 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   uint32_t fx[4], fw[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    const uint32_t o = (lane & 31) * 128 + (((kk * 2 + hi) ^ key) << 4);
+    // bf16: chunk 2*kk + hi = k-step kk's 8 elements of this lane half; fp8: chunks 4*ks + 2*hi + {0, 1} (kk = 2*ks + h)
+    const int chunk = FP8 ? (kk >> 1) * 4 + hi * 2 + (kk & 1) : kk * 2 + hi;
+    const uint32_t o = (lane & 31) * 128 + ((chunk ^ key) << 4);
     fx[kk] = LDS_X + g * 32768 + o;
     fw[kk] = LDS_W + wc * 64 * 128 + o;
   }
@@ -631,16 +640,26 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
   // same-accumulator MFMAs back to back (D -> C forwarding costs no wait states); the empty asm statements pin each
   // chain inside its section -- the intrinsics are pure, nothing else stops hipcc from moving them across a barrier
+#define PP_CAT(lo_, hi_) __builtin_shufflevector(__builtin_bit_cast(i32x4, lo_), __builtin_bit_cast(i32x4, hi_), 0, 1, 2, 3, 4, 5, 6, 7)
+#define PP_CHAIN(ACC, WF, XF)                                                                                \
+  do {                                                                                                       \
+    if (FP8) {                                                                                               \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+        ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(PP_CAT(WF[2 * ks], WF[2 * ks + 1]),            \
+                                                              PP_CAT(XF[2 * ks], XF[2 * ks + 1]), ACC, 0, 0, 0,  \
+                                                              0x7f7f7f7f, 0, 0x7f7f7f7f);                    \
+    } else {                                                                                                 \
+      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                       \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], XF[kk], ACC, 0, 0, 0);                         \
+    }                                                                                                        \
+    asm volatile("" : "+v"(ACC));                                                                            \
+  } while (0)
 #define PP_MFMA8(WF, ROWBASE, NJ)                                                                            \
   do {                                                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                         \
-      acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
-    asm volatile("" : "+v"(acc[ROWBASE][NJ]));                                                               \
+    PP_CHAIN(acc[ROWBASE][NJ], WF, xf[0]);                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                         \
-      acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
-    asm volatile("" : "+v"(acc[ROWBASE + 1][NJ]));                                                           \
+    PP_CHAIN(acc[ROWBASE + 1][NJ], WF, xf[1]);                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
@@ -707,6 +726,24 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     const int r32 = lane & 31;
     const int crow = lane >> 3, cchunk = lane & 7;
     const int nst = n0 + wc * 64 + cchunk * 8;
+    if (FP8) {
+      // dequantise in place first (row scale x channel scale), so the scale vectors are dead before bias / gate load
+      float sa[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) sa[mi] = p.a_scale[b * p.as_bs + min(m0 + g * 128 + mi * 32 + r32, p.M - 1)];
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int n = ncol + nj * 32 + qd * 8;
+          const f32x4 sw = *reinterpret_cast<const f32x4*>(p.w_scale + (n < p.N ? n : 0));
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mi][nj][qd * 4 + e] *= sa[mi] * sw[e];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     float bs[2][4][4], gt[2][4][4];
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj)
@@ -791,6 +828,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #undef LDS_FRAG
 #undef PP_VMCNT
 #undef PP_MFMA8
+#undef PP_CHAIN
+#undef PP_CAT
 #undef PP_TILE
 }
 
@@ -813,6 +852,7 @@ static GemmParams make_params(const GemmArgs& a) {
   p.res = (const bf16_t*)a.res; p.ldr = a.ldr; p.r_bs = a.r_bstride;
   p.cin = a.conv_cin; p.inH = a.conv_inH; p.inW = a.conv_inW; p.oH = a.conv_H; p.oW = a.conv_W;
   p.cstride = a.conv_stride; p.cup = a.conv_up_shift; p.cpad = a.conv_pad_lo; p.zero = (const bf16_t*)a.zero_page;
+  p.a_scale = a.a_scale; p.as_bs = a.a_scale_bstride; p.w_scale = a.w_scale;
   return p;
 }
 
@@ -955,5 +995,55 @@ int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
 }
 
 int gemm_bf16(const GemmArgs& a, hipStream_t st) { return gemm_bf16_variant(a, fast_ok(a) ? 1 : 0, st); }
+
+// ---- fp8 (e4m3 x e4m3 -> fp32) path: the persistent kernel only
+template <int EPI>
+static int launch_fp8(const GemmParams& p, hipStream_t st) {
+  static int grid = 0;
+  if (!grid) {
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    const void* fn = (const void*)gemm8pp_kernel<EPI, 2, true>;
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, fn);
+    (void)hipGetLastError();
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL);
+    if (e != hipSuccess) return fail("gemm_fp8: cannot raise dynamic LDS limit to %d bytes: %s", PP_LDS_TOTAL, hipGetErrorString(e));
+    grid = cus & ~7;
+  }
+  const bool prof = prof_on(st);
+  if (prof) prof_begin(2, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
+  gemm8pp_kernel<EPI, 2, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+  if (prof) prof_end(2, st);
+  return check_launch("gemm_fp8");
+}
+
+int gemm_fp8(const GemmArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return 0;
+  if (!a.a_scale || !a.w_scale) return fail("gemm_fp8: scale pointers required");
+  if (a.conv_cin > 0) return fail("gemm_fp8: no convolution mode");
+  const bool al = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.C % 16 == 0) &&
+                  ((uintptr_t)a.bias % 8 == 0) && ((uintptr_t)a.w_scale % 16 == 0);
+  const int tm = (a.M + 255) / 256, tn = (a.N + 255) / 256;
+  if (!(a.K > 0 && a.K % 256 == 0 && a.N % 8 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0 && a.a_bstride % 16 == 0 &&
+        a.ldc % 8 == 0 && a.c_bstride % 8 == 0 && al && (int64_t)(a.batch - 1) * a.a_bstride + (int64_t)tm * 256 * a.lda < (1ll << 32) &&
+        (int64_t)tn * 256 * a.ldw < (1ll << 32) && (int64_t)255 * a.lda < (1ll << 31) && (int64_t)255 * a.ldw < (1ll << 31)))
+    return fail("gemm_fp8: shape/alignment not supported (K %% 256 == 0, N %% 8 == 0, 16-byte aligned rows)");
+  if ((a.epilogue == EPI_BIAS_GATE_RES || a.epilogue == EPI_BIAS_RES) &&
+      !(a.res && a.ldr % 8 == 0 && a.r_bstride % 8 == 0 && (uintptr_t)a.res % 16 == 0))
+    return fail("gemm_fp8: residual pointer / alignment");
+  if (a.epilogue == EPI_BIAS_GATE_RES && !(a.gate && a.gate_bstride % 4 == 0 && (uintptr_t)a.gate % 8 == 0))
+    return fail("gemm_fp8: gate pointer / alignment");
+  if (a.epilogue == EPI_BIAS_GELU && a.gelu_from_col % 256) return fail("gemm_fp8: gelu_from_col must be a multiple of 256");
+  const GemmParams p = make_params(a);
+  switch (a.epilogue) {
+    case EPI_BIAS: return launch_fp8<EPI_BIAS>(p, st);
+    case EPI_BIAS_GELU: return launch_fp8<EPI_BIAS_GELU>(p, st);
+    case EPI_BIAS_GATE_RES: return launch_fp8<EPI_BIAS_GATE_RES>(p, st);
+    case EPI_BIAS_RES: return launch_fp8<EPI_BIAS_RES>(p, st);
+  }
+  return fail("gemm_fp8: unknown epilogue %d", a.epilogue);
+}
 
 }  // namespace tfx

@@ -30,7 +30,7 @@ namespace {
 struct Rec { hipEvent_t a, b; double flops; };
 struct Prof {
   bool on = false;
-  std::vector<Rec> recs[2];
+  std::vector<Rec> recs[3];   // 0 bf16 GEMM, 1 attention, 2 fp8 GEMM
   std::vector<hipEvent_t> pool;
   hipEvent_t get() {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }

@@ -46,11 +46,18 @@ struct GemmArgs {
   // fall outside the (upsampled) input read `zero_page` (>= 128 B of zeros) instead.
   int conv_cin = 0, conv_inH = 0, conv_inW = 0, conv_H = 0, conv_W = 0, conv_stride = 1, conv_up_shift = 0, conv_pad_lo = 1;
   const void* zero_page = nullptr;
+  // fp8 (e4m3) operands, gemm_fp8 only: A and W hold one byte per element, C = (A.W^T) * a_scale[b][m] * w_scale[n] + bias
+  const float* a_scale = nullptr; int64_t a_scale_bstride = 0;   // per activation row
+  const float* w_scale = nullptr;                                 // per output channel
 };
 void set_gemm_group_m(int gm);
 void set_gemm_place(int v);
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
+int gemm_fp8(const GemmArgs& a, hipStream_t st);             // persistent MFMA kernel on e4m3 operands (K % 256 == 0)
+// per-row absmax quantisation bf16 -> e4m3: out = x / scale, scale = absmax / 448 (1 for an all-zero row)
+int quantize_rows_fp8(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride, float* scale,
+                      int64_t s_bstride, int rows, int batch, int K, hipStream_t st);
 
 struct AttnArgs {
   const void* q; const void* k; const void* v; void* o;   // bf16, element (b, n, h, d) at base + b*bstride + n*ld + h*128 + d

@@ -70,6 +70,56 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def quantize_rows_fp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
+    """Per-row absmax quantisation bf16 -> e4m3 bytes: returns (q uint8 [.., rows, K], scale f32 [.., rows]) with
+    x ~= q * scale[..., None];  x [rows, K] or [B, rows, K] (row/batch strided views allowed)."""
+    _chk_dev(x, out, scale)
+    assert x.dtype == BF16
+    xp, ldx, xbs, R, B = _rows_view(x)
+    K = x.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.uint8 and scale.dtype == torch.float32 and scale.is_contiguous() and out.shape == x.shape
+    op, ldo, obs, _, _ = _rows_view(out)
+    L.check(L.lib().tfx_quantize_rows_fp8(xp, ldx, xbs, op, ldo, obs, scale.data_ptr(), R if x.dim() == 3 else 0, R, B, K,
+                                          _stream()), "quantize_rows_fp8")
+    return out, scale
+
+
+def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS,
+             gelu_from_col: int = 0, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = epi((a[b] @ w.T) * a_scale[b][:, None] * w_scale[None, :] + bias) on e4m3 operands (uint8 storage), bf16 out."""
+    _chk_dev(a, a_scale, w, w_scale, bias, out, gate, res)
+    assert a.dtype == torch.uint8 and w.dtype == torch.uint8 and w.dim() == 2 and w.stride(1) == 1
+    assert a_scale.dtype == torch.float32 and w_scale.dtype == torch.float32 and a_scale.is_contiguous() and w_scale.is_contiguous()
+    ap, lda, abs_, M, batch = _rows_view(a)
+    N, K = w.shape
+    assert a.shape[-1] == K and a_scale.numel() == M * batch and w_scale.numel() == N
+    if out is None:
+        out = torch.empty(*a.shape[:-1], N, dtype=BF16, device=a.device)
+    cp, ldc, cbs, M2, b2 = _rows_view(out)
+    assert (M2, b2) == (M, batch) and out.shape[-1] == N and out.dtype == BF16
+    g = L.GemmArgs()
+    g.A, g.lda, g.a_bstride = ap, lda, abs_
+    g.W, g.ldw, g.bias = w.data_ptr(), w.stride(0), _p(bias)
+    g.C, g.ldc, g.c_bstride = cp, ldc, cbs
+    g.M, g.N, g.K, g.batch = M, N, K, batch
+    g.epilogue, g.gelu_from_col = epilogue, gelu_from_col
+    if epilogue in (EPI_BIAS_GATE_RES, EPI_BIAS_RES):
+        assert res is not None
+        if epilogue == EPI_BIAS_GATE_RES:
+            assert gate is not None and gate.stride(-1) == 1
+            g.gate = gate.data_ptr()
+            g.gate_bstride = gate.stride(0) if gate.dim() == 2 else 0
+        rp, ldr, rbs, _, _ = _rows_view(res)
+        g.res, g.ldr, g.r_bstride = rp, ldr, rbs
+    L.check(L.lib().tfx_gemm_fp8(C.byref(g), a_scale.data_ptr(), M if batch > 1 else 0, w_scale.data_ptr(), _stream()), "gemm_fp8")
+    return out
+
+
 def ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: Optional[torch.Tensor] = None,
                 eps: float = 1e-6) -> torch.Tensor:
     """LayerNorm(x) * (1 + scale[b]) + shift[b];  x [B,R,D], shift/scale [B,D] (row-strided views allowed)."""
