@@ -125,7 +125,9 @@ int tfx_advance_step(int32_t* step_ptr, tfx_stream stream);
  *   double i: [img: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp | txt: same six]   (12D each)
  *   single j: [shift scale gate] (3D each), then norm_out: [scale shift] (2D).
  * Workspace (caller-owned, bf16): hid [B][N,D], xn [B][N,D], y [B][N,7D], with N = T + S (text rows first). */
-typedef struct tfx_linear { const void* w; const void* b; } tfx_linear;
+/* w8 / w8_scale (optional, may be NULL): the same weight as e4m3 bytes [out,in] with one fp32 scale per output channel
+ * (tfx_quantize_rows_fp8 of w); used when tfx_dit_desc.flags bit 2 is set and in % 256 == 0, see below. */
+typedef struct tfx_linear { const void* w; const void* b; const void* w8; const float* w8_scale; } tfx_linear;
 typedef struct tfx_double_block {
   tfx_linear qkv_img, qkv_txt, out_img, out_txt, ff1_img, ff2_img, ff1_txt, ff2_txt;
   const void *norm_q, *norm_k, *norm_added_q, *norm_added_k;
@@ -150,6 +152,10 @@ typedef struct tfx_dit_desc {
    * (last_block < 0 = all); flags bit 0: skip x_embedder / ctx0 copy (hid is preloaded with [text | image] rows),
    * bit 1: skip norm_out + proj_out.  A full forward is first_block = 0, last_block = -1, flags = 0. */
   int32_t first_block, last_block, flags;
+  /* flags bit 2 (BASELINE config 5, fp8 linears): every block Linear that carries w8 runs as
+   * tfx_quantize_rows_fp8(activations) -> tfx_gemm_fp8; q8 [B][N, 5D] bytes and q8_scale [B][N] fp32 are the
+   * caller-owned workspace of the quantised activations.  Embedders, modulation and proj_out stay bf16. */
+  void* q8; float* q8_scale;
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
 

@@ -46,7 +46,40 @@ class FluxConfig:
         return self.num_attention_heads * self.attention_head_dim
 
 
+# fp8 emulation (BASELINE config 5; the reference has no fp8 path -- this restates the BUILD's documented scheme so the
+# fp8 engine can be checked the same way as the bf16 one): inside `with fp8_block_linears():` every nn.Linear of the
+# 57 blocks (not the norm*.linear modulation layers, not the embedders / proj_out) quantises its input rows and its
+# weight rows to OCP e4m3 with a per-row scale absmax / 448, multiplies in fp32 and rescales.
+_FP8 = {"on": False}
+
+
+class fp8_block_linears:
+    def __enter__(self):
+        _FP8["on"] = True
+
+    def __exit__(self, *a):
+        _FP8["on"] = False
+
+
+def quantize_rows_e4m3(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """(q, scale): q = round_e4m3(x / scale) as fp32 values, scale = max|row| / 448 (1 for a zero row), fp32 [.., 1]."""
+    xf = x.float()
+    s = xf.abs().amax(-1, keepdim=True) / 448.0
+    s = torch.where(s > 0, s, torch.ones_like(s))
+    return (xf / s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float(), s
+
+
+def _is_block_linear(name: str) -> bool:
+    return name.startswith(("transformer_blocks.", "single_transformer_blocks.")) and ".norm" not in name
+
+
 def linear(x: Tensor, sd: SD, name: str) -> Tensor:
+    if _FP8["on"] and _is_block_linear(name) and x.shape[-1] % 256 == 0:
+        xq, sx = quantize_rows_e4m3(x)
+        wq, sw = quantize_rows_e4m3(sd[name + ".weight"])
+        y = (xq @ wq.T) * sx * sw.squeeze(-1)
+        b = sd.get(name + ".bias")
+        return (y + b.float() if b is not None else y).to(x.dtype)
     return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
 
 

@@ -93,3 +93,39 @@ def test_full_width_blocks_match_reference_goldens(golden):
     e_sgl = rel_mae(ses.hid, g["d3072.single.out"])
     print(f"full-width rel MAE: double enc {e_enc:.2e} hidden {e_hid:.2e}; single {e_sgl:.2e}")
     assert max(e_enc, e_hid, e_sgl) < 1e-2
+
+
+# ----------------------------------------------------------------------------- fp8 linears (BASELINE config 5)
+def _g3_inputs(golden):
+    g = golden("g3_model")
+    return g, {k[3:]: v for k, v in g.items() if k.startswith("in.")}
+
+
+def test_fp8_forward_matches_fp8_oracle(golden):
+    """enable_fp8(): e4m3 weights (per-channel scale) x e4m3 activations (per-token scale) on the fp8 MFMA.  Checked
+    against the oracle running the same quantisation scheme (oracle.flux_oracle.fp8_block_linears) in bf16, with the
+    bf16 criterion of the test above: no further from it than 1.5x the reference's own bf16-vs-fp32 distance; the cost of
+    fp8 against the bf16 engine is printed (and bounded loosely: it is a property of the scheme, not of the kernels)."""
+    g, inp = _g3_inputs(golden)
+    m = build(G3_CFG, 7)
+    kw = dict(hidden_states=inp["hidden_states"].to(BF).cuda(), encoder_hidden_states=inp["encoder_hidden_states"].to(BF).cuda(),
+              pooled_projections=inp["pooled_projections"].to(BF).cuda(), timestep=inp["timestep"].to(BF).cuda(),
+              img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], guidance=inp["guidance"].cuda(), return_dict=False)
+    out_bf16 = m.forward(**kw)[0].clone()
+    m.enable_fp8()
+    assert len(m.w8) == 2 * 8 + 2 * 2
+    out_fp8 = m.forward(**kw)[0].clone()
+    assert torch.isfinite(out_fp8).all() and not torch.equal(out_fp8, out_bf16)
+    sd = {k: v.to(BF) for k, v in fo.seeded_state_dict(G3_CFG, 7).items()}
+    with fo.fp8_block_linears():
+        ref = fo.transformer_forward(sd, G3_CFG, inp["hidden_states"].to(BF), inp["encoder_hidden_states"].to(BF),
+                                     inp["pooled_projections"].to(BF), inp["timestep"].to(BF), inp["img_ids"], inp["txt_ids"],
+                                     inp["guidance"])
+    ref_gap = rel_mae(g["out_bf16"], g["out_f32"])
+    e = rel_mae(out_fp8, ref)
+    cost = rel_mae(out_fp8, out_bf16)
+    print(f"fp8 engine vs fp8 oracle rel MAE {e:.2e} (bf16 ref gap {ref_gap:.2e}); fp8 vs bf16 engine {cost:.2e}")
+    assert e <= 1.5 * ref_gap
+    assert cost <= 0.15
+    m.enable_fp8(False)
+    assert torch.equal(m.forward(**kw)[0], out_bf16)

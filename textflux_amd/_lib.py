@@ -39,7 +39,7 @@ class AttnArgs(C.Structure):
 
 
 class Linear(C.Structure):
-    _fields_ = [("w", c_void_p), ("b", c_void_p)]
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("w8", c_void_p), ("w8_scale", c_void_p)]
 
 
 class DoubleBlock(C.Structure):
@@ -65,6 +65,7 @@ class DitDesc(C.Structure):
         ("hid", c_void_p), ("xn", c_void_p), ("y", c_void_p),
         ("out", c_void_p),
         ("first_block", c_int32), ("last_block", c_int32), ("flags", c_int32),
+        ("q8", c_void_p), ("q8_scale", c_void_p),
     ]
 
 

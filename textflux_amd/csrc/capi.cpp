@@ -17,11 +17,12 @@ inline uint16_t* bf(void* p) { return (uint16_t*)p; }
 
 struct Gemm {
   GemmArgs a;
-  Gemm(const void* A, int64_t lda, int64_t abs_, const tfx_linear& lin, int64_t ldw, void* C, int64_t ldc, int64_t cbs,
-       int M, int N, int K, int batch) {
-    std::memset(&a, 0, sizeof(a));
+  const tfx_linear* lin;
+  Gemm(const void* A, int64_t lda, int64_t abs_, const tfx_linear& l, int64_t ldw, void* C, int64_t ldc, int64_t cbs,
+       int M, int N, int K, int batch) : lin(&l) {
+    a = GemmArgs();
     a.A = A; a.lda = lda; a.a_bstride = abs_;
-    a.W = lin.w; a.ldw = ldw; a.bias = lin.b;
+    a.W = l.w; a.ldw = ldw; a.bias = l.b;
     a.C = C; a.ldc = ldc; a.c_bstride = cbs;
     a.M = M; a.N = N; a.K = K; a.batch = batch;
     a.epilogue = EPI_BIAS;
@@ -32,6 +33,17 @@ struct Gemm {
     return *this;
   }
   int run(hipStream_t st) const { return gemm_bf16(a, st); }
+  // fp8 linears (desc.flags bit 2): quantise the activation rows into the q8 workspace, then the e4m3 GEMM
+  int run(hipStream_t st, void* q8, float* q8_scale) const {
+    if (!q8 || !lin->w8 || !lin->w8_scale || a.K % 256) return gemm_bf16(a, st);
+    if (int e = quantize_rows_fp8(a.A, a.lda, a.a_bstride, q8, a.K, (int64_t)a.M * a.K, q8_scale, a.M, a.M, a.batch, a.K, st))
+      return e;
+    GemmArgs f = a;
+    f.A = q8; f.lda = a.K; f.a_bstride = (int64_t)a.M * a.K;
+    f.W = lin->w8; f.ldw = a.ldw;
+    f.a_scale = q8_scale; f.a_scale_bstride = a.M; f.w_scale = lin->w8_scale;
+    return gemm_fp8(f, st);
+  }
 };
 
 #define TRY(x)            \
@@ -58,6 +70,9 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
   const int nblk = d.n_double + d.n_single;
   const int first = d.first_block < 0 ? 0 : d.first_block;
   const int last = (d.last_block < 0 || d.last_block > nblk) ? nblk : d.last_block;
+  void* q8 = (d.flags & 4) ? d.q8 : nullptr;
+  float* q8s = (d.flags & 4) ? d.q8_scale : nullptr;
+  if ((d.flags & 4) && (!d.q8 || !d.q8_scale)) return fail("dit_forward: fp8 flag set but the q8 workspace is null");
 
   if (!(d.flags & 1)) {
     // x_embedder (transformer_flux.py:1086) straight into the image rows of the joint stream; text rows <- ctx0
@@ -85,35 +100,35 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
       const uint16_t* mt = mi + 6 * D;                   // txt: same six
       TRY(ln_modulate(hid_img, xn_img, mi, mi + D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
       if (T > 0) TRY(ln_modulate(hid, xn, mt, mt + D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
-      TRY(Gemm(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B).run(st));
-      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.qkv_txt, D, y, D7, y_bs, T, 3 * D, D, B).run(st));
+      TRY(Gemm(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B).run(st, q8, q8s));
+      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.qkv_txt, D, y, D7, y_bs, T, 3 * D, D, B).run(st, q8, q8s));
       TRY(attention(T, w.norm_q, w.norm_k, w.norm_added_q, w.norm_added_k));
       // hidden += gate_msa * to_out(attn)   (:817-818, 830-831)
       TRY(Gemm(y_img + 2 * D, D7, y_bs, w.out_img, D, hid_img, D, hid_bs, Sn, D, D, B)
-              .gate_res(mi + 2 * D, mbs, hid_img, D, hid_bs).run(st));
+              .gate_res(mi + 2 * D, mbs, hid_img, D, hid_bs).run(st, q8, q8s));
       if (T > 0)
         TRY(Gemm(y + 2 * D, D7, y_bs, w.out_txt, D, hid, D, hid_bs, T, D, D, B)
-                .gate_res(mt + 2 * D, mbs, hid, D, hid_bs).run(st));
+                .gate_res(mt + 2 * D, mbs, hid, D, hid_bs).run(st, q8, q8s));
       // MLP: norm2 * (1 + scale_mlp) + shift_mlp -> ff -> gated residual (:820-826, 833-837)
       TRY(ln_modulate(hid_img, xn_img, mi + 3 * D, mi + 4 * D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
       if (T > 0) TRY(ln_modulate(hid, xn, mt + 3 * D, mt + 4 * D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
-      TRY(Gemm(xn_img, D, hid_bs, w.ff1_img, D, y_img + 3 * D, D7, y_bs, Sn, 4 * D, D, B).gelu(0).run(st));
-      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.ff1_txt, D, y + 3 * D, D7, y_bs, T, 4 * D, D, B).gelu(0).run(st));
+      TRY(Gemm(xn_img, D, hid_bs, w.ff1_img, D, y_img + 3 * D, D7, y_bs, Sn, 4 * D, D, B).gelu(0).run(st, q8, q8s));
+      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.ff1_txt, D, y + 3 * D, D7, y_bs, T, 4 * D, D, B).gelu(0).run(st, q8, q8s));
       TRY(Gemm(y_img + 3 * D, D7, y_bs, w.ff2_img, 4 * D, hid_img, D, hid_bs, Sn, D, 4 * D, B)
-              .gate_res(mi + 5 * D, mbs, hid_img, D, hid_bs).run(st));
+              .gate_res(mi + 5 * D, mbs, hid_img, D, hid_bs).run(st, q8, q8s));
       if (T > 0)
         TRY(Gemm(y + 3 * D, D7, y_bs, w.ff2_txt, 4 * D, hid, D, hid_bs, T, D, 4 * D, B)
-                .gate_res(mt + 5 * D, mbs, hid, D, hid_bs).run(st));
+                .gate_res(mt + 5 * D, mbs, hid, D, hid_bs).run(st, q8, q8s));
     } else {
       // ---- FluxSingleTransformerBlock.forward (transformer_flux.py:715-739) on the joint [text | image] sequence
       const int j = blk - d.n_double;
       const tfx_single_block& w = d.sgl[j];
       const uint16_t* ms = mod + (int64_t)d.n_double * 12 * D + (int64_t)j * 3 * D;  // shift scale gate
       TRY(ln_modulate(hid, xn, ms, ms + D, mbs, N, B, D, D, hid_bs, D, hid_bs, eps, st));
-      TRY(Gemm(xn, D, hid_bs, w.qkv_mlp, D, y, D7, y_bs, N, 7 * D, D, B).gelu(3 * D).run(st));
+      TRY(Gemm(xn, D, hid_bs, w.qkv_mlp, D, y, D7, y_bs, N, 7 * D, D, B).gelu(3 * D).run(st, q8, q8s));
       TRY(attention(0, w.norm_q, w.norm_k, w.norm_q, w.norm_k));
       TRY(Gemm(y + 2 * D, D7, y_bs, w.proj_out, 5 * D, hid, D, hid_bs, N, D, 5 * D, B)
-              .gate_res(ms + 2 * D, mbs, hid, D, hid_bs).run(st));
+              .gate_res(ms + 2 * D, mbs, hid, D, hid_bs).run(st, q8, q8s));
     }
   }
 

@@ -72,6 +72,7 @@ class FluxTransformer2DModel:
         self.dtype = BF16
         self.device = torch.device("cpu")
         self.w: Dict[str, torch.Tensor] = {}     # fused weights (see module docstring)
+        self.w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}   # enable_fp8(): name -> (e4m3 bytes [out,in], scale f32 [out])
         self._session: Optional["DitSession"] = None
         D = self.inner_dim
         self.mod_len = 12 * D * num_layers + 3 * D * num_single_layers + 2 * D
@@ -236,11 +237,36 @@ class FluxTransformer2DModel:
             raise ValueError("the HIP engine computes in bf16")
         if device is not None and self.w and torch.device(device).type != self.device.type:
             self.w = {k: v.to(device) for k, v in self.w.items()}
+            self.w8 = {k: (q.to(device), sc.to(device)) for k, (q, sc) in self.w8.items()}
             self.device = torch.device(device)
             self._session = None
         return self
 
     def eval(self):
+        return self
+
+    def fp8_linear_names(self) -> List[str]:
+        """The Linears that run in fp8 under enable_fp8(): every GEMM inside the 57 blocks.  Embedders, the modulation
+        GEMM and proj_out stay bf16 (K = 384 / once per image / N = 64)."""
+        c = self.config
+        names = [f"d{i}.{n}" for i in range(c.num_layers)
+                 for n in ("qkv_img", "qkv_txt", "out_img", "out_txt", "ff1_img", "ff2_img", "ff1_txt", "ff2_txt")]
+        names += [f"s{j}.{n}" for j in range(c.num_single_layers) for n in ("qkv_mlp", "proj_out")]
+        return [n for n in names if self.w[n + ".w"].shape[1] % 256 == 0]
+
+    def enable_fp8(self, on: bool = True):
+        """BASELINE config 5 (no reference counterpart: the reference computes in bf16): quantise the block weights to
+        OCP e4m3 with one scale per output channel (absmax / 448) on the device; activations are quantised per token
+        row at run time (tfx_quantize_rows_fp8) and the GEMMs run on the fp8 MFMA with fp32 accumulation, bf16 outputs.
+        Call after the weights (and any LoRA merge) are final; the bf16 weights stay resident."""
+        if not self.w:
+            raise RuntimeError("weights not loaded")
+        self.w8 = {}
+        if on:
+            for n in self.fp8_linear_names():
+                q, sc = ops.quantize_rows_fp8(self.w[n + ".w"])
+                self.w8[n] = (q, sc)
+        self._session = None
         return self
 
     # ------------------------------------------------------------------ conditioning (step-invariant work)
@@ -323,9 +349,16 @@ class DitSession:
         self._ids_key = None
         w = model.w
 
-        def lin(name):
-            return L.Linear(w[name + ".w"].data_ptr(), w[name + ".b"].data_ptr())
+        w8 = model.w8   # {} unless enable_fp8() was called: e4m3 copies of the block linears + per-channel scales
 
+        def lin(name):
+            q = w8.get(name)
+            return L.Linear(w[name + ".w"].data_ptr(), w[name + ".b"].data_ptr(), q[0].data_ptr() if q else None,
+                            q[1].data_ptr() if q else None)
+
+        self.fp8 = bool(w8)
+        self.q8 = torch.empty(B, N, 5 * D, dtype=torch.uint8, device=dev) if self.fp8 else None
+        self.q8_scale = torch.empty(B, N, dtype=torch.float32, device=dev) if self.fp8 else None
         self._dbl = (L.DoubleBlock * max(1, c.num_layers))()
         for i in range(c.num_layers):
             b = self._dbl[i]
@@ -347,6 +380,8 @@ class DitSession:
         d.xin, d.ctx0 = self.xin.data_ptr(), self.ctx0.data_ptr()
         d.hid, d.xn, d.y, d.out = self.hid.data_ptr(), self.xn.data_ptr(), self.y.data_ptr(), self.out.data_ptr()
         d.first_block, d.last_block, d.flags = 0, -1, 0
+        if self.fp8:
+            d.q8, d.q8_scale = self.q8.data_ptr(), self.q8_scale.data_ptr()
         self.graphs = {}
         self._gb = None
 
@@ -386,6 +421,6 @@ class DitSession:
         self._mod_keepalive = mod
         d = self.desc
         d.mod, d.mod_bstride = mod.data_ptr(), mod.stride(0)
-        d.first_block, d.last_block, d.flags = first_block, last_block, flags
+        d.first_block, d.last_block, d.flags = first_block, last_block, flags | (4 if self.fp8 else 0)
         L.check(L.lib().tfx_dit_forward(C.byref(d), ops._stream()), "dit_forward")
         return self.out
