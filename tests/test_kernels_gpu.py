@@ -118,6 +118,56 @@ def test_gemm_persistent_rejects_odd_k_tiles(ops):
         ops.gemm(a, w, None, variant=3)
 
 
+# ----------------------------------------------------------------------------- fp8 (e4m3) GEMM path, BASELINE config 5
+F8 = torch.float8_e4m3fn
+
+
+@pytest.mark.parametrize("shape", [(1, 37, 256), (2, 300, 3072), (3, 64, 15360)])
+def test_quantize_rows_fp8_matches_torch(ops, shape):
+    """scale = max|row| / 448 and bytes = torch's round-to-nearest-even e4m3 cast of the exactly rounded quotient x / scale,
+    bit for bit (bf16 data with a scale of few mantissa bits sits on e4m3 rounding ties all the time, so the kernel divides
+    rather than multiplying by a reciprocal)."""
+    B, R, K = shape
+    x = (rnd(shape, 31) * (rnd((B, R, 1), 32).abs() * 3 + 0.01)).to(BF)
+    x[0, 0] = 0                                            # all-zero row -> scale 1, zeros
+    q, sc = ops.quantize_rows_fp8(x.cuda())
+    s_ref = x.float().abs().amax(-1) / 448.0
+    s_ref = torch.where(s_ref > 0, s_ref, torch.ones_like(s_ref))
+    assert torch.equal(sc.cpu(), s_ref)
+    ref = (x.float() / s_ref[..., None]).clamp(-448, 448).to(F8).float()
+    got = q.cpu().view(F8).float()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref)
+    assert got[0, 0].abs().max().item() == 0 and sc[0, 0].item() == 1.0
+
+
+@pytest.mark.parametrize("B,M,N,K", [(1, 512, 512, 256), (2, 1000, 3136, 512), (1, 300, 264, 12288), (2, 4736, 3072, 3072)])
+def test_gemm_fp8_matches_dequantised_matmul(ops, B, M, N, K):
+    """tfx_gemm_fp8 against (q_a . q_w^T) * s_a * s_w + bias evaluated in fp32 on the SAME e4m3 operands, all epilogues;
+    tolerance = the bf16 output rounding (max-norm 1e-2, MAE 2e-3 relative, as for the bf16 GEMM)."""
+    a = (rnd((B, M, K), 41) * (rnd((B, M, 1), 42).abs() + 0.1)).to(BF).cuda()
+    w = rnd((N, K), 43, 0.05).to(BF).cuda()
+    bias, gate, res = rnd((N,), 44).to(BF).cuda(), rnd((B, N), 45).to(BF).cuda(), rnd((B, M, N), 46).to(BF).cuda()
+    aq, sa = ops.quantize_rows_fp8(a)
+    wq, sw = ops.quantize_rows_fp8(w)
+    lin = (aq.view(F8).float() @ wq.view(F8).float().T) * sa[..., None] * sw[None, None, :] + bias.float()
+    gf = max(0, (N // 256 - 1) * 256)
+    gelu_ref = torch.cat([lin[..., :gf], torch.nn.functional.gelu(lin[..., gf:], approximate="tanh")], -1)
+    cases = [(ops.EPI_BIAS, {}, lin), (ops.EPI_BIAS_GELU, dict(gelu_from_col=gf), gelu_ref),
+             (ops.EPI_BIAS_GATE_RES, dict(gate=gate, res=res), res.float() + (gate.float()[:, None] * lin.to(BF).float()).to(BF).float()),
+             (ops.EPI_BIAS_RES, dict(res=res), res.float() + lin.to(BF).float())]
+    for epi, kw, ref in cases:
+        close(ops.gemm_fp8(aq, sa, wq, sw, bias, epilogue=epi, **kw), ref.to(BF))
+
+
+def test_gemm_fp8_rejects_unsupported_k(ops):
+    aq = torch.zeros(64, 384, dtype=torch.uint8, device="cuda")
+    wq = torch.zeros(64, 384, dtype=torch.uint8, device="cuda")
+    one = torch.ones(64, dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError, match="gemm_fp8"):
+        ops.gemm_fp8(aq, one, wq, one)
+
+
 # ----------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,H,N", [(1, 1, 64), (2, 2, 96), (1, 3, 300), (2, 2, 1664), (1, 24, 520)])
 def test_attention(ops, B, H, N):

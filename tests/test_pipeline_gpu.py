@@ -205,3 +205,36 @@ def test_hip_graph_amo_internal_noise_runs():
                masked_image_latents=torch.randn(1, 64, 320, generator=gi).to(BF).cuda(), height=128, width=128,
                num_inference_steps=5, guidance_scale=30.0, output_type="latent").images
     assert torch.isfinite(out.float()).all() and out.float().std().item() > 0.1
+
+
+def test_fp8_call_matches_fp8_oracle_trajectory_and_graph_replay(golden):
+    """BASELINE config 5 precision (fp8 block linears) through FluxFillPipeline.__call__: per-step latents against the
+    oracle running the same e4m3 scheme (flux_oracle.fp8_block_linears) in bf16, under the bf16 criterion of the tests
+    above; hipGraph replay stays bit-identical; the cost of fp8 against the reference's bf16 trajectory is printed and
+    bounded (it is the scheme's property, not the kernels')."""
+    g = golden("g5_pipeline")
+    kw = dict(prompt_embeds=g["prompt_embeds"].to(BF).cuda(), pooled_prompt_embeds=g["pooled"].to(BF).cuda(),
+              latents=g["latents"].to(BF).cuda(), masked_image_latents=g["masked_image_latents"].to(BF).cuda(),
+              height=128, width=128, num_inference_steps=4, guidance_scale=30.0, output_type="latent")
+    pipe = make_pipe("euler")
+    pipe.transformer.enable_fp8()
+    steps = []
+
+    def cb(p, i, t, k):
+        steps.append(k["latents"].clone())
+        return {}
+
+    out = pipe(callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents"], **kw).images
+    sd = {k: v.to(BF) for k, v in fo.seeded_state_dict(G3_CFG, 7).items()}
+    with fo.fp8_block_linears():
+        _, traj = po.denoise(sd, G3_CFG, g["latents"].to(BF), g["masked_image_latents"].to(BF), g["prompt_embeds"].to(BF),
+                             g["pooled"].to(BF), 8, 8, 4, 30.0, scheduler="euler", sched_cfg=SCHED)
+    for i in range(4):
+        gap = mae(g[f"euler.bf16.step{i}"], g[f"euler.f32.step{i}"])
+        e, cost = mae(steps[i], traj[i]), mae(steps[i], g[f"euler.bf16.step{i}"])
+        print(f"fp8 step {i}: MAE vs fp8 oracle {e:.2e} (bf16 ref gap {gap:.2e}); vs reference bf16 {cost:.2e}")
+        assert e <= 1.5 * gap + 1e-4
+        assert cost <= 5e-2
+    pipe.enable_hip_graph(True)
+    graphed = pipe(**kw).images
+    assert torch.equal(out, graphed)

@@ -431,8 +431,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
   if ((tid & 63) == 0) red[tid >> 6] = amax;
   __syncthreads();
   amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
-  const float inv = 1.0f / sc;
+  const float sc = amax > 0.f ? __fdiv_rn(amax, 448.0f) : 1.0f;   // the correctly rounded quotient, as torch's amax / 448
   if (tid == 0) scale[b * s_bs + row] = sc;
   uint8_t* orow = out + b * o_bs + (int64_t)row * ldo;
 #pragma unroll
@@ -442,7 +441,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     float f[8];
     unpack8(v[i], f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e] * inv, -448.f), 448.f);
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(__fdiv_rn(f[e], sc), -448.f), 448.f);  // exact quotient: bf16 data sits on e4m3 ties
     uint32_t w0 = 0, w1 = 0;
     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
