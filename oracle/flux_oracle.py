@@ -77,7 +77,7 @@ def linear(x: Tensor, sd: SD, name: str) -> Tensor:
     if _FP8["on"] and _is_block_linear(name) and x.shape[-1] % 256 == 0:
         xq, sx = quantize_rows_e4m3(x)
         wq, sw = quantize_rows_e4m3(sd[name + ".weight"])
-        y = (xq @ wq.T) * sx * sw.squeeze(-1)
+        y = ((xq @ wq.T) * sx) * sw.squeeze(-1)     # row scale first, then channel scale (the engine's order)
         b = sd.get(name + ".bias")
         return (y + b.float() if b is not None else y).to(x.dtype)
     return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))

@@ -724,10 +724,15 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     // for ONCE; the residual rows of block mi+1 are requested as soon as block mi has consumed its own.  (Loaded at their
     // first use they cost one memory round trip each: 16-28 of them per tile, 26 us of a 95 us tile at K = 3072.)
     const int m0 = cur.m0, n0 = cur.n0, b = cur.b;
-    const int ncol = n0 + wc * 64 + hi * 4;
+    // lane-derived offsets are rebuilt from an opaque copy of the lane id: derived from `lane` they are loop invariants
+    // that hipcc keeps in ~20 VGPRs across the K loop, which is what pushed this kernel into spilling
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int hi_e = lane_e >> 5;
+    const int ncol = n0 + wc * 64 + hi_e * 4;
     const bool do_gelu = (EPI == EPI_BIAS_GELU) && (n0 >= p.gelu_from);
-    const int r32 = lane & 31;
-    const int crow = lane >> 3, cchunk = lane & 7;
+    const int r32 = lane_e & 31;
+    const int crow = lane_e >> 3, cchunk = lane_e & 7;
     const int nst = n0 + wc * 64 + cchunk * 8;
     constexpr bool HAS_RES = (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES);
     const bf16_t* resp = HAS_RES ? p.res + b * p.r_bs + min(nst, p.N - 8) : nullptr;
@@ -759,11 +764,11 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[mi][nj][qd * 4 + e] *= sa[mi] * sw[nj][qd][e];
+            for (int e = 0; e < 4; ++e) acc[mi][nj][qd * 4 + e] = (acc[mi][nj][qd * 4 + e] * sa[mi]) * sw[nj][qd][e];
       __builtin_amdgcn_sched_barrier(0);
     }
     u32x2 bsr[2][4], gtr[2][4];   // bias / gate stay packed (bf16 pairs) until they are used
-    constexpr int RES_DEPTH = 1;   // residual row blocks requested ahead of their use (2: spills eat the gain)
+    constexpr int RES_DEPTH = FP8 ? 1 : 2;   // residual row blocks requested ahead of their use
     u32x4 rr[RES_DEPTH][4];
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj)
@@ -811,7 +816,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
           // row r32, 16-byte chunk c = nj*4 + qd stored at chunk c ^ (r32 & 7); the 8-byte half is flipped for rows
           // 8..15 / 24..31 so the 16 lanes of a ds_write_b64 group touch 16 different bank pairs
           const int c = nj * 4 + qd;
-          *reinterpret_cast<u32x2*>(stg + r32 * 128 + ((c ^ (r32 & 7)) << 4) + ((hi ^ ((r32 >> 3) & 1)) << 3)) = o;
+          *reinterpret_cast<u32x2*>(stg + r32 * 128 + ((c ^ (r32 & 7)) << 4) + ((hi_e ^ ((r32 >> 3) & 1)) << 3)) = o;
         }
       // wave-private region + in-order LDS pipe: no barrier between the writes above and the reads below
 #pragma unroll
