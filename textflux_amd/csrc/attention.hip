@@ -20,6 +20,7 @@ constexpr int KVBLK = 64, HD = 128;
 constexpr int K_BYTES = KVBLK * HD * 2;          // 16 KiB
 constexpr int ATT_LDS = 2 * 2 * K_BYTES;         // K,V x 2 buffers = 64 KiB
 constexpr int ATT_LDS2 = 2 * ATT_LDS;            // two 64-key sub-tiles per buffer = 128 KiB
+constexpr int ATT_LDS_PP = 5 * K_BYTES;          // ping-pong kernel: K x 2, V x 3 buffers = 80 KiB
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ unsigned long long* g_dbg_ptr = nullptr;  // bench-only (tools/attn_timing.py)
@@ -265,15 +266,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
 
 
 // -------------------------------------------------------------------------------------------------------------
-// Ping-pong variant (default).  Same math and data layouts as attn_kernel<8>, different schedule: the tile loop is
-// split into a VALU phase PA(u) = online softmax of tile u (scores already in registers) and an MFMA phase
-// PB(u) = O *= alpha; O^T += V(u)^T P(u)^T; S(u+1) = K(u+1) Q^T, and the two wave groups (waves 0-3 / 4-7, one
-// wave of each per SIMD) run half an iteration apart, offset by one s_barrier -- while one group's waves are in
-// their softmax the partner waves on the same SIMDs issue 32 MFMAs, so the matrix pipe and the VALU overlap instead
-// of both waves of a SIMD queueing for the same pipe.  Slots: G0 PA(u)=2u, PB(u)=2u+1; G1 one slot later.
-// LDS: K(t) is read in slots 2t-1, 2t, V(t) in 2t+1, 2t+2 (two buffers each); in PB(u) every thread writes its
-// chunks of V(u+1) and K(u+2) (both regions idle since >= 1 barrier, first readers >= 1 barrier later), then
-// re-issues the global loads for V(u+2), K(u+3) that stay in flight for two slots.
+// Ping-pong variant.  Same math and data layouts as attn_kernel<8>, different schedule: the tile loop is split into
+// a VALU phase   PA(u) = request the 16 V(u) fragments into registers; online softmax of tile u (scores already in
+//                        registers); O *= alpha (skipped, exactly, when no row maximum of the wave moved)
+// and an MFMA phase PB(u) = O^T += V(u)^T P(u)^T out of registers, the K(u+1) fragments read into the registers the V
+//                        fragments vacate, S(u+1) = K(u+1) Q^T out of registers, then the staging writes / requests,
+// and the two wave groups (waves 0-3 / 4-7, one wave of each per SIMD) run half an iteration apart, offset by one
+// s_barrier: while one group's waves are in their softmax the partner waves on the same SIMDs issue 32 MFMAs whose
+// operands are already in registers, so the matrix pipe and the VALU overlap instead of both waves of a SIMD queueing
+// for the same pipe.  Slots: G0 PA(u) = 2u, PB(u) = 2u+1; G1 one slot later.
+// LDS: K(t) (2 buffers) is read in PB(t-1) and written in PB(t-2); V(t) (3 buffers) is read in PA(t) and written in
+// PB(t-2): every write lands >= 1 barrier after the last read of the bytes it replaces and >= 1 barrier before its first
+// reader.  Each thread stages its chunks global -> registers one iteration ahead of the write (V(u+3), K(u+3) are
+// requested in PB(u) and written in PB(u+1)).
 template <bool TIMING>
 __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
                                                          const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq,
@@ -310,12 +315,16 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
 
   const int nkv = (N + KVBLK - 1) / KVBLK;
   char* kbuf = smem;                 // K(t) at kbuf + (t&1)*16K
-  char* vbuf = smem + 2 * K_BYTES;   // V(t) at vbuf + (t&1)*16K
+  char* vbuf = smem + 2 * K_BYTES;   // V(t) at vbuf + (t%3)*16K
   u32x4 kreg[2], vreg[2];
+  // staging addresses are rebuilt from an opaque copy of the thread id in every iteration: derived from `tid` they are
+  // loop invariants that hipcc parks in ~12 VGPRs, which this kernel does not have
+  auto opaque_tid = [&]() { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; };
   auto load_rows = [&](const bf16_t* base, int64_t ld, int t, u32x4* reg) {
+    const int te = opaque_tid();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 512;
+      const int c = te + i * 512;
       int key = t * KVBLK + (c >> 4);
       if (key > N - 1) key = N - 1;
       reg[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)key * ld + (c & 15) * 8);
@@ -323,17 +332,19 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
   };
   auto write_k = [&](int t) {
     char* kd = kbuf + (t & 1) * K_BYTES;
+    const int te = opaque_tid();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 512, key = c >> 4, ch = c & 15;
+      const int c = te + i * 512, key = c >> 4, ch = c & 15;
       *reinterpret_cast<u32x4*>(kd + key * 256 + ((ch ^ (key & 15)) << 4)) = kreg[i];
     }
   };
   auto write_v = [&](int t) {
-    char* vd = vbuf + (t & 1) * K_BYTES;
+    char* vd = vbuf + (t % 3) * K_BYTES;
+    const int te = opaque_tid();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 512, key = c >> 4, ch = c & 15;
+      const int c = te + i * 512, key = c >> 4, ch = c & 15;
       *reinterpret_cast<u32x4*>(vd + key * 256 + ((((ch >> 2) ^ (key & 3)) << 6) | ((ch & 3) << 4))) = vreg[i];
     }
   };
@@ -352,39 +363,19 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f, alpha = 1.f;
+  float m_run = -INFINITY, l_run = 0.f;
   bf16x8 pf[4];
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-  // S(t) = K(t) Q^T from LDS, software pipelined by hand: the fragment reads run two k-steps (4 MFMAs = 128 matrix
-  // cycles) ahead of their MFMAs in a 3-deep register ring -- in the ping-pong schedule only ONE wave per SIMD is in
-  // its MFMA phase, so LDS latency is not covered by a partner wave; sched_barriers keep hipcc from sinking the
-  // prefetches back next to their uses.
-  auto qk = [&](int t) {
-    const char* kt = kbuf + (t & 1) * K_BYTES;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-    bf16x8 kf[3][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      kf[s][0] = *reinterpret_cast<const bf16x8*>(kt + koff[s]);
-      kf[s][1] = *reinterpret_cast<const bf16x8*>(kt + koff[s] + 32 * 256);
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      if (s + 2 < 8) {
-        kf[(s + 2) % 3][0] = *reinterpret_cast<const bf16x8*>(kt + koff[s + 2]);
-        kf[(s + 2) % 3][1] = *reinterpret_cast<const bf16x8*>(kt + koff[s + 2] + 32 * 256);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s % 3][0], qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s % 3][1], qf[s], s1, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_setprio(0);
+  // V fragment i = ks * 4 + db of the tile in buffer vt (two transpose reads each)
+  auto ldvf = [&](const char* vt, int i) -> bf16x8 {
+    const char* va = vt + voff[i & 3] + (i >> 2) * 16 * 256;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 8 * 256));
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
   };
 
-  // ---- prologue: K(0), V(0), K(1) into LDS; V(1) loaded (written in PB(0)); K(2) requested
+  // ---- prologue: K(0), K(1), V(0), V(1) into LDS; K(2), V(2) requested; S(0) = K(0) Q^T
   load_rows(Kb, ldk, 0, kreg);
   load_rows(Vb, ldv, 0, vreg);
   write_k(0);
@@ -393,16 +384,37 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
     load_rows(Kb, ldk, 1, kreg);
     load_rows(Vb, ldv, 1, vreg);
     write_k(1);
-    if (nkv > 2) load_rows(Kb, ldk, 2, kreg);
+    write_v(1);
+    if (nkv > 2) {
+      load_rows(Kb, ldk, 2, kreg);
+      load_rows(Vb, ldv, 2, vreg);
+    }
   }
   __syncthreads();
-  qk(0);
+  {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kbuf + koff[s]);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kbuf + koff[s] + 32 * 256);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+    }
+  }
   TFX_ATT_BARRIER();
   if (g == 1) TFX_ATT_BARRIER();  // stagger: group 1 runs one slot behind
 
+  int vslot = 0;  // u % 3
   for (int u = 0; u < nkv; ++u) {
     ATM();
-    // ================= PA(u): online softmax of tile u (VALU) =================
+    // ================= PA(u): V(u) fragments -> registers; online softmax of tile u; rescale of O (VALU) =============
+    bf16x8 vf[16];
+    {
+      const char* vt = vbuf + vslot * K_BYTES;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) vf[i] = ldvf(vt, i);
+    }
     if (u == nkv - 1 && (N & (KVBLK - 1))) {
       const int kbase = u * KVBLK + 4 * hi;
 #pragma unroll
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float mc = m_new * scale_log2e;
-      alpha = __builtin_amdgcn_exp2f(m_run * scale_log2e - mc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run * scale_log2e - mc);
       m_run = m_new;
       float psum = 0.f;
 #pragma unroll
@@ -438,47 +450,62 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
         pf[2][e] = (__bf16)s1[e];
         pf[3][e] = (__bf16)s1[8 + e];
       }
+      if (!__all(alpha == 1.0f)) {  // exact: alpha is exactly 1 whenever the running max did not move
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
     }
     ATA(t_pa);
     TFX_ATT_BARRIER();
     ATA(t_b1);
-    // ================= PB(u): rescale, PV(u), QK(u+1), staging (MFMA) =================
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    // ================= PB(u): PV(u) and QK(u+1) out of registers (MFMA), staging ====================================
+    const char* kt = kbuf + ((u + 1) & 1) * K_BYTES;
+    bf16x8 kf[8][2];
+    uint32_t kofs[8];   // rebuilt here (opaque lane id): as loop invariants they would sit in 8 VGPRs across PA, the peak
     {
-      // O^T += V(u)^T P(u)^T: 16 MFMAs over (ks, db), V fragments (2 transpose reads each) 4 MFMAs ahead in a 5-deep ring
-      const char* vt = vbuf + (u & 1) * K_BYTES;
-      typedef __attribute__((ext_vector_type(8))) short s16x8;
-      auto ldv = [&](int i) -> bf16x8 {
-        const char* va = vt + voff[i & 3] + (i >> 2) * 16 * 256;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va));
-        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 8 * 256));
-        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
-      };
-      bf16x8 vf[5];
+      int le = lane;
+      asm volatile("" : "+v"(le));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) vf[i] = ldv(i);
-      __builtin_amdgcn_s_setprio(1);
+      for (int s = 0; s < 8; ++s) kofs[s] = (le & 31) * 256 + (((2 * s + (le >> 5)) ^ (le & 15)) << 4);
+    }
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i + 4 < 16) vf[(i + 4) % 5] = ldv(i + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 5], pf[i >> 2], o[i & 3], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks * 4 + db], pf[ks], o[db], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // K(u+1) fragments of k-steps 2ks, 2ks+1 into the registers the V fragments above just vacated (the last tile
+      // reads a stale buffer: harmless, its scores are never used)
+#pragma unroll
+      for (int s = 2 * ks; s < 2 * ks + 2; ++s) {
+        kf[s][0] = *reinterpret_cast<const bf16x8*>(kt + kofs[s]);
+        kf[s][1] = *reinterpret_cast<const bf16x8*>(kt + kofs[s] + 32 * 256);
       }
-      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (u + 1 < nkv) {
-      qk(u + 1);
-      write_v(u + 1);
-      if (u + 2 < nkv) {
-        write_k(u + 2);
-        load_rows(Vb, ldv, u + 2, vreg);
-        if (u + 3 < nkv) load_rows(Kb, ldk, u + 3, kreg);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) asm volatile("" : "+v"(o[db]));   // PV stays in front of what follows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s][0], qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s][1], qf[s], s1, 0, 0, 0);
+    }
+    asm volatile("" : "+v"(s0), "+v"(s1));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    if (u + 2 < nkv) {
+      write_k(u + 2);
+      write_v(u + 2);
+      if (u + 3 < nkv) {
+        load_rows(Kb, ldk, u + 3, kreg);
+        load_rows(Vb, ldv, u + 3, vreg);
       }
     }
+    vslot = vslot == 2 ? 0 : vslot + 1;
     ATA(t_pb);
     TFX_ATT_BARRIER();
     ATA(t_b2);
@@ -537,7 +564,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<8, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS2);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_PP);
     if (e != hipSuccess) return fail("attention: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
@@ -557,12 +584,12 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
 #undef ATT_ABL
   } else if (pp)
     if (g_attn_dbg) {
-      (void)hipFuncSetAttribute((const void*)attn_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-      attn_pp_kernel<true><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
+      (void)hipFuncSetAttribute((const void*)attn_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_PP);
+      attn_pp_kernel<true><<<grid, 512, ATT_LDS_PP, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
                                                        a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
                                                        a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f, g_attn_dbg);
     } else
-      attn_pp_kernel<false><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
+      attn_pp_kernel<false><<<grid, 512, ATT_LDS_PP, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
                                                         a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
                                                         a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f, nullptr);
   else if (g_attn_waves == 9)   // 8 waves, two 64-key sub-tiles per barrier
