@@ -173,10 +173,14 @@ int tfx_conv3x3_nhwc(const void* x, int32_t B, int32_t inH, int32_t inW, int32_t
 int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* workspace, int32_t B,
                        int64_t HW, int32_t C, int32_t groups, float eps, int32_t silu, tfx_stream stream);
 
-/* ---- tuning knobs (no reference counterpart).  "attention_waves": 8 = one 512-thread workgroup of 256 query rows per
- *      CU (default), 4 = two independent 256-thread workgroups of 128 query rows per CU, 9 = 8 waves with 128 keys per
- *      barrier, 16 = ping-pong variant.  "gemm_group_m": row tiles per group of the GEMM tile order (default 4).
- *      "gemm_place": slot assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip). */
+/* ---- tuning knobs (no reference counterpart).  "attention_waves" selects the attention kernel: 10 (default) = one
+ *      512-thread workgroup of 256 query rows per CU with the softmax bookkeeping on the matrix pipe (pre-scaled Q, lazy
+ *      reference maximum subtracted by an extra MFMA k-step, row sums from a ones-block of the PV MFMA); 8 = the same
+ *      schedule with the textbook exact online maximum; 12 / 4 = two independent 256-thread workgroups per CU of 10 / 8;
+ *      9 = 8 with 128 keys per barrier; 16 = softmax / MFMA ping-pong between the wave groups.  All compute the same
+ *      softmax; 10 and 12 differ from the others in rounding only (one extra bf16 rounding of q * scale, row sums of the
+ *      bf16 weights).  "gemm_group_m": row tiles per group of the GEMM tile order (default 4).  "gemm_place": slot
+ *      assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip). */
 int tfx_set_option(const char* name, int value);
 
 /* ---- measurement hooks (no reference counterpart: the reference has no profiling) --------------------

@@ -178,9 +178,10 @@ def test_attention(ops, B, H, N):
     close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
-@pytest.mark.parametrize("nw", [4, 9, 16])
+@pytest.mark.parametrize("nw", [4, 8, 9, 12, 16])
 def test_attention_waves_variants(ops, nw):
-    """The alternative schedules kept for A/B (4-wave workgroups, 128 keys per barrier, ping-pong) compute the same thing."""
+    """The alternative kernels kept for A/B (exact online maximum, 4-wave workgroups, 128 keys per barrier, ping-pong)
+    compute the same thing as the default (10: matrix-pipe softmax)."""
     B, H, N = 2, 2, 712
     q, k, v = (rnd((B, N, H * 128), s).to(BF) for s in (27, 28, 29))
     qh, kh, vh = (t.float().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
@@ -189,8 +190,41 @@ def test_attention_waves_variants(ops, nw):
     try:
         got = ops.attention(q.cuda(), k.cuda(), v.cuda())
     finally:
-        ops.set_option("attention_waves", 8)
+        ops.set_option("attention_waves", 10)
     close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+
+
+@pytest.mark.parametrize("nw", [8, 10])
+def test_attention_reference_maximum_paths_vs_fp64(ops, nw):
+    """Inputs that drive every path of the (lazy) reference-maximum logic, against an fp64 softmax: scores that are all
+    very negative (first tile must pin the reference to the true maximum: no underflow of the row sum), a maximum that
+    grows in every tile, isolated spikes in late tiles (everything accumulated so far is rescaled exactly once), and a
+    peaked distribution.  Same bound for the exact-online-max kernel (8) and the matrix-pipe kernel (10)."""
+    B, H, N = 2, 2, 1216
+    g = torch.Generator().manual_seed(77)
+    q, k, v = (torch.randn(B, N, H * 128, generator=g).to(BF) for _ in range(3))
+
+    def ref64(q, k, v):
+        qh, kh, vh = (t.double().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
+        return (torch.softmax((qh @ kh.transpose(-1, -2)) * 128 ** -0.5, -1) @ vh).transpose(1, 2).reshape(B, N, H * 128)
+
+    k_spike = k.clone()
+    k_spike[0, 900, :128] = q[0, 17, :128] * 6.0
+    k_spike[1, 1100, 128:] = q[1, 300, 128:] * 9.0
+    ramp = (torch.arange(N).view(1, N, 1) / N * 6).to(BF).expand(B, N, H * 128).contiguous()
+    cases = {"very negative": (q.abs() + 0.5, -(k.abs() + 0.5) * 2, v), "growing maximum": (q.abs() + 0.1, ramp, v),
+             "late spikes": (q, k_spike, v), "peaked": (q * 3, k, v)}
+    ops.set_option("attention_waves", nw)
+    try:
+        for name, (qq, kk, vv) in cases.items():
+            got = ops.attention(qq.cuda(), kk.cuda(), vv.cuda()).double().cpu()
+            ref = ref64(qq, kk, vv)
+            assert torch.isfinite(got).all(), name
+            err = (got - ref).abs()
+            assert err.max().item() <= 2e-2 * ref.abs().max().item() + 1e-3, (name, err.max().item())
+            assert err.mean().item() <= 6e-3 * ref.abs().mean().item() + 1e-5, (name, err.mean().item(), ref.abs().mean().item())
+    finally:
+        ops.set_option("attention_waves", 10)
 
 
 def test_attention_online_softmax_rescale_branch(ops):

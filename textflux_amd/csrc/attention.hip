@@ -266,6 +266,212 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(const bf16_t* Q, const
 
 
 // -------------------------------------------------------------------------------------------------------------
+// Matrix-pipe softmax variant (attention_waves = 10).  The lock-step loop above is bound by VALU ISSUE, not by the matrix
+// pipe: per 64-key tile a wave issues 32 MFMAs and ~190 VALU instructions, and only ~5 single-issue instructions fit
+// beside one 32-cycle MFMA (a v_exp_f32 counts for several) -- the ping-pong experiment below shows the two streams
+// mostly serialise.  This kernel moves the softmax's bookkeeping arithmetic onto the idle matrix pipe:
+//   * Q is pre-multiplied by scale*log2(e) once per block (one extra bf16 rounding of q), so the scores leave the MFMA in
+//     the exp2 domain: no per-score multiply;
+//   * the running reference maximum is subtracted BY the MFMA: one extra k-step whose K-side operand is 1 and whose
+//     Q-side operand is -m_ref[q] (kept bf16-exact), so S' = K.Q^T - m_ref arrives ready for exp2: no per-score subtract;
+//   * the reference maximum is lazy: it only moves when a row's tile maximum exceeds it by more than ATT_THR (in log2
+//     units), so P <= 2^ATT_THR and the O rescale, its exp2 and the per-score subtract sit in a rarely taken branch
+//     (always taken on the first tile, which pins m_ref to the true row maximum: no underflow of the row sum);
+//   * the row sums come out of the PV MFMA: a fifth "d block" whose V-side operand is all ones (4 MFMAs per tile)
+//     accumulates l[q] = sum_k bf16(P[k][q]) -- the sum of exactly the weights PV used -- and no lane-local adds.
+// Per tile: 38 MFMAs (+19 %), ~90 VALU instructions (-53 %).  Mathematically the same softmax; rounding differs from the
+// exact-online-max kernel in q*c and in l (documented, tested against the fp32 oracle with the same tolerance).
+constexpr float ATT_THR = 4.0f;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_mx_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
+                                                         const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq,
+                                                         int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs,
+                                                         int64_t v_bs, int64_t o_bs, int H, int N, int nqb, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int qb = bid % nqb;
+  bid /= nqb;
+  const int h = bid % H;
+  const int b = bid / H;
+  const bf16_t* Qb = Q + b * q_bs + h * HD;
+  const bf16_t* Kb = Kp + b * k_bs + h * HD;
+  const bf16_t* Vb = Vp + b * v_bs + h * HD;
+  bf16_t* Ob = O + b * o_bs + h * HD;
+
+  // ---- Q fragments, pre-scaled into the exp2 domain
+  constexpr int NT = NW * 64, CPT = 1024 / NT;   // threads, 16-byte chunks of a 16 KiB tile per thread
+  const int qrow = qb * (NW * 32) + wave * 32 + l31;
+  const int qrow_c = qrow < N ? qrow : N - 1;
+  bf16x8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    qf[s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)qrow_c * ldq + s * 16 + hi * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[s][e] = (__bf16)((float)qf[s][e] * scale_log2e);
+  }
+
+  const int nkv = (N + KVBLK - 1) / KVBLK;
+  u32x4 kreg[CPT], vreg[CPT];
+  auto load_tile = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * NT;
+      int key = j * KVBLK + (c >> 4);
+      if (key > N - 1) key = N - 1;
+      kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (int64_t)key * ldk + (c & 15) * 8);
+      vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (int64_t)key * ldv + (c & 15) * 8);
+    }
+  };
+  auto write_tile = [&](int buf) {
+    char* kd = smem + buf * 2 * K_BYTES;
+    char* vd = kd + K_BYTES;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + i * NT;
+      const int key = c >> 4, ch = c & 15;
+      *reinterpret_cast<u32x4*>(kd + key * 256 + ((ch ^ (key & 15)) << 4)) = kreg[i];
+      *reinterpret_cast<u32x4*>(vd + key * 256 + ((((ch >> 2) ^ (key & 3)) << 6) | ((ch & 3) << 4))) = vreg[i];
+    }
+  };
+  uint32_t koff[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) koff[s] = l31 * 256 + (((2 * s + hi) ^ (lane & 15)) << 4);
+  const int vi = lane & 15;
+  const uint32_t vrow = (4 * hi + (vi >> 2)) * 256 + 32 * ((lane >> 4) & 1) + (vi & 3) * 8;
+  uint32_t voff[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) voff[db] = vrow + ((db ^ ((vi >> 2) & 3)) << 6);
+
+  f32x16 o[4], ol;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    ol[r] = 0.f;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db][r] = 0.f;
+  }
+  // constant operands of the two bookkeeping MFMAs.  k-slot 0 belongs to the lanes with hi == 0 (element 0).
+  bf16x8 kone, vone, qm;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { kone[e] = (__bf16)0.f; vone[e] = (__bf16)1.0f; qm[e] = (__bf16)0.f; }
+  if (hi == 0) kone[0] = (__bf16)1.0f;
+  float m_ref = 0.f;   // bf16-exact reference maximum of this lane's query row (exp2 domain); -m_ref sits in qm[0]
+
+  load_tile(0);
+  write_tile(0);
+  if (nkv > 1) load_tile(1);
+  __syncthreads();
+
+  for (int j = 0; j < nkv; ++j) {
+    const int buf = j & 1;
+    if (j + 1 < nkv) {
+      write_tile(buf ^ 1);
+      if (j + 2 < nkv) load_tile(j + 2);
+    }
+    const char* kt = smem + buf * 2 * K_BYTES;
+    const char* vt = kt + K_BYTES;
+
+    // ---- S'^T = K Q^T - m_ref : the offset k-step first (C = 0), then the 8 real ones
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, qm, s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, qm, s1, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kt + koff[s]);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kt + koff[s] + 32 * 256);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+    }
+    if (j == nkv - 1 && (N & (KVBLK - 1))) {  // ragged last tile: keys >= N get -inf
+      const int kbase = j * KVBLK + 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        if (key >= N) s0[r] = -INFINITY;
+        if (key + 32 >= N) s1[r] = -INFINITY;
+      }
+    }
+    // ---- row maximum of the tile relative to m_ref (this lane: 32 keys; partner lane^32: the other 32)
+    float mx = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (j == 0 || !__all(mx <= ATT_THR)) {
+      // move the reference: everything accumulated against the old one is rescaled exactly once, the scores of this
+      // tile are shifted before they are exponentiated (first tile: pin m_ref to the true maximum, whatever its sign)
+      const float m_new = round_bf(m_ref + (j == 0 ? mx : fmaxf(mx, 0.f)));
+      const float d = m_new - m_ref;
+      const float f = __builtin_amdgcn_exp2f(-d);
+      m_ref = m_new;
+      qm[0] = (__bf16)(hi == 0 ? -m_new : 0.f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] -= d;
+        s1[r] -= d;
+        ol[r] *= f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db][r] *= f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+      s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+    }
+    bf16x8 pf[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pf[0][e] = (__bf16)s0[e];
+      pf[1][e] = (__bf16)s0[8 + e];
+      pf[2][e] = (__bf16)s1[e];
+      pf[3][e] = (__bf16)s1[8 + e];
+    }
+    // ---- O^T += V^T P^T, l += 1^T P^T
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const char* va = vt + voff[db] + ks * 16 * 256;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 8 * 256));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf[ks], o[db], 0, 0, 0);
+      }
+      ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vone, pf[ks], ol, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- finish: every row of the ones-block holds the full row sum (all 64 keys of every tile)
+  const float inv = 1.0f / ol[0];
+  if (qrow < N) {
+    bf16_t* orow = Ob + (int64_t)qrow * ldo + 4 * hi;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        u32x2 w;
+        w[0] = pack_bf2(o[db][qd * 4 + 0] * inv, o[db][qd * 4 + 1] * inv);
+        w[1] = pack_bf2(o[db][qd * 4 + 2] * inv, o[db][qd * 4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(orow + db * 32 + qd * 8) = w;
+      }
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------------------------
 // Ping-pong variant.  Same math and data layouts as attn_kernel<8>, different schedule: the tile loop is split into
 // a VALU phase   PA(u) = request the 16 V(u) fragments into registers; online softmax of tile u (scores already in
 //                        registers); O *= alpha (skipped, exactly, when no row maximum of the wave moved)
@@ -534,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
   }
 }
 
-static int g_attn_waves = 8;  // 8 (default) / 4 = lock-step kernel with 8 / 4 waves per workgroup; 16 = ping-pong kernel (slower: kept for A/B)
+static int g_attn_waves = 10;  // 10 (default) matrix-pipe softmax; 8 exact-online-max lock-step kernel; 4 / 12 = 4-wave workgroups of 8 / 10; 9 = 128 keys per barrier; 16 = ping-pong
 static unsigned long long* g_attn_dbg = nullptr;  // bench-only phase timing buffer
 void set_attention_debug(void* p) {
   g_attn_dbg = (unsigned long long*)p;
@@ -542,7 +748,7 @@ void set_attention_debug(void* p) {
 }
 static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
-void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 9) ? nw : 16; }
+void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12) ? nw : 16; }
 
 int joint_attention(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.H <= 0 || a.N <= 0) return 0;
@@ -550,7 +756,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     return fail("attention: strides must be multiples of 8 elements (q,k,v) / 4 (o)");
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 || (uintptr_t)a.o % 8)
     return fail("attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
-  const int NW = (g_attn_waves == 16 || g_attn_waves == 9) ? 8 : g_attn_waves;
+  const int NW = (g_attn_waves == 16 || g_attn_waves == 9 || g_attn_waves == 10) ? 8 : g_attn_waves == 12 ? 4 : g_attn_waves;
   const bool pp = g_attn_waves == 16;
   const int qblk = NW * 32;
   static bool attr_set = false;
@@ -560,11 +766,15 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<4>);
     (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<8, 0, 2>);
     (void)hipFuncGetAttributes(&fa, (const void*)attn_pp_kernel<false>);
+    (void)hipFuncGetAttributes(&fa, (const void*)attn_mx_kernel<8>);
+    (void)hipFuncGetAttributes(&fa, (const void*)attn_mx_kernel<4>);
     (void)hipGetLastError();
     hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<8, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS2);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_PP);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_mx_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_mx_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     if (e != hipSuccess) return fail("attention: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
@@ -592,6 +802,14 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
       attn_pp_kernel<false><<<grid, 512, ATT_LDS_PP, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
                                                         a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
                                                         a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f, nullptr);
+  else if (g_attn_waves == 10)  // matrix-pipe softmax, one 8-wave workgroup per CU
+    attn_mx_kernel<8><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
+                                                  a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
+                                                  a.N, nqb, a.scale * 1.4426950408889634f);
+  else if (g_attn_waves == 12)  // matrix-pipe softmax, two independent 4-wave workgroups per CU
+    attn_mx_kernel<4><<<grid, 256, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
+                                                  a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
+                                                  a.N, nqb, a.scale * 1.4426950408889634f);
   else if (g_attn_waves == 9)   // 8 waves, two 64-key sub-tiles per barrier
     attn_kernel<8, 0, 2><<<grid, 512, ATT_LDS2, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
                                                       a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,

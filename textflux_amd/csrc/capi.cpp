@@ -290,8 +290,8 @@ int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* 
 int tfx_set_option(const char* name, int value) {
   if (!name) return fail("tfx_set_option: null name");
   if (!std::strcmp(name, "attention_waves")) {
-    if (value != 4 && value != 8 && value != 9 && value != 16)
-      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (8 waves, 128 keys per barrier) or 16 (ping-pong)");
+    if (value != 4 && value != 8 && value != 9 && value != 10 && value != 12 && value != 16)
+      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves) or 16 (ping-pong)");
     set_attention_waves(value);
     return 0;
   }

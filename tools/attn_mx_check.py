@@ -1,0 +1,43 @@
+"""Accuracy and speed of the matrix-pipe-softmax attention (option 10) against the exact-online-max kernel (8) and fp64."""
+import sys, os, json, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from textflux_amd import ops
+from tools.bench_kernels import timeit
+BF = torch.bfloat16
+torch.manual_seed(0)
+def ref64(q, k, v, H):
+    B, N, D = q.shape
+    qh, kh, vh = (t.double().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) * 128 ** -0.5
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, N, D)
+cases = {}
+B, H, N = 2, 4, 1216
+q, k, v = (torch.randn(B, N, H * 128, device="cuda").to(BF) for _ in range(3))
+cases["randn"] = (q, k, v, H)
+cases["randn x3 (peaked)"] = (q * 3, k, v, H)
+q2, k2 = q.clone(), k.clone()
+k2[0, 900, :128] = q2[0, 17, :128] * 6.0      # spike in a late tile: forces the slow path mid-sequence
+k2[1, 1100, 128:256] = q2[1, 300, 128:256] * 9.0
+cases["late spikes"] = (q2, k2, v, H)
+cases["very negative scores"] = (q, -q.roll(1, 1) * 0 + k * 0 - 0.0 * k + (k - 4.0), v, H)
+cases["ramp (max grows every tile)"] = (q.abs() + 0.1, (torch.arange(N, device="cuda").view(1, N, 1) / N * 6).to(BF).expand(B, N, H * 128).contiguous(), v, H)
+for name, (q, k, v, H) in cases.items():
+    r = ref64(q, k, v, H)
+    out = {}
+    for nw in (8, 10):
+        ops.set_option("attention_waves", nw)
+        o = ops.attention(q.contiguous(), k.contiguous(), v.contiguous())
+        e = (o.double() - r).abs()
+        out[nw] = (e.max().item(), e.mean().item())
+        assert torch.isfinite(o).all(), (name, nw)
+    print(f"{name:32s} exact-max kernel: max {out[8][0]:.3e} mean {out[8][1]:.3e} | matrix-pipe: max {out[10][0]:.3e} mean {out[10][1]:.3e}   (|ref| max {r.abs().max().item():.2f} mean {r.abs().mean().item():.3f})", flush=True)
+D = 3072
+for (B, N) in [(8, 4608), (1, 4608), (8, 8704), (1, 1664)]:
+    y = torch.randn(B, N, 3 * D, device="cuda").to(BF)
+    q, k, v = y[:, :, 2 * D:], y[:, :, :D], y[:, :, D:2 * D]
+    for nw in (8, 10, 12, 4, 8, 10, 12):
+        ops.set_option("attention_waves", nw)
+        o = torch.empty(B, N, D, dtype=BF, device="cuda")
+        t = timeit(lambda: ops.attention(q, k, v, out=o), iters=10)
+        print(json.dumps(dict(B=B, N=N, waves=nw, ms=round(t * 1e3, 4), tflops=round(4.0 * B * 24 * N * N * 128 / t / 1e12, 1))), flush=True)
+ops.set_option("attention_waves", 10)
