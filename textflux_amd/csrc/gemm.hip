@@ -130,8 +130,10 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* smem, uint32_t lds
     __builtin_amdgcn_sched_barrier(0);         \
   } while (0)
 
-// ABL (bench-only ablations, never dispatched by the product path): bit0 no prefetch in the main loop, bit1 no LDS
-// fragment reads, bit2 no barriers.  ABL = 0 is the real kernel.
+// ABL (bench-only ablations with WRONG results by construction, never dispatched by the product path; tools/
+// bench_gemm_abl.py, gemm_abl2.py, energy_probe.py): bit 0 no operand requests in the main loop, bit 1 no LDS fragment
+// reads, bit 2 no barriers, bit 3 every tile reads panel 0 (L2-resident), bit 4 no MFMAs, bit 15 half the request bytes,
+// bit 16 every request reads the same 1 KiB (L1-resident).  ABL = 0 is the real kernel.
 template <int EPI, int ABL = 0, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -220,19 +222,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)Xb, 0, 0x7fffffff, 0x00020000);
   const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, 0x7fffffff, 0x00020000);
 
-  auto stage = [&](int q, int tile, int jsel = -1) {
+  auto stage = [&](int q, int tile) {
     const bool ok = tile < nt;
     const int kt = ok ? tile : nt - 1;
-    const bf16_t* base = (isx[q] ? Xb : Wb) + (int64_t)kt * 64;
     const uint32_t setoff = (tile & 1) * (isx[q] ? 16384u : 32768u);
-    constexpr int kAux = ((ABL >> 5) & 3) == 1 ? 16 : ((ABL >> 5) & 3) == 2 ? 2 : ((ABL >> 5) & 3) == 3 ? 1 : GLDS_AUX;
+    constexpr int kAux = GLDS_AUX;
     if (CONV && isx[q]) {
       // K index -> (tap, channel block): a 64-wide K-tile never straddles a tap because Cin % 64 == 0
       const int k0 = kt * 64, tap = k0 / p.cin, ci0 = k0 - tap * p.cin, dy = tap / 3, dx = tap - 3 * dy;
       const int vh = p.inH << p.cup, vw = p.inW << p.cup;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if (jsel >= 0 && j != jsel) continue;
         const int yy = (cyx[q][j] >> 16) - 1 + dy, xx = (cyx[q][j] & 0xffff) - 1 + dx;
         const bool inside = (unsigned)yy < (unsigned)vh && (unsigned)xx < (unsigned)vw;
         const bf16_t* src = inside ? p.A + ((int64_t)(cpix[q][j] + (yy >> p.cup) * p.inW + (xx >> p.cup)) * p.cin + ci0 + goff[q][j])
@@ -241,21 +241,18 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       }
       return;
     }
-    if (!CONV && !(ABL & 16384)) {
+    if (!CONV) {
       // buffer form of the LDS DMA: per-lane 32-bit byte offset + scalar K offset against a per-tile descriptor -- no
       // 64-bit per-lane address arithmetic in the issue path
       const auto rs = isx[q] ? rsrcX : rsrcW;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        if ((jsel < 0 || j == jsel) && !((ABL & 32768) && j == 1))   // bench-only bit 15: half the prefetch bytes
+        if (!((ABL & 32768) && j == 1))   // bench-only bit 15: half the prefetch bytes
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (ok ? ldst[q][j] + setoff : dummy)), 16,
                                                    (ABL & 65536) ? lane * 16 : goff[q][j] * 2,  // bit 16: L1-hot source
                                                    (ABL & 65536) ? 0 : kt * 128, 0, kAux);
       return;
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (jsel < 0 || j == jsel) glds16<kAux>(base + goff[q][j], smem, ok ? ldst[q][j] + setoff : dummy);
   };
 
   // ---- fragment read addresses (set 0); per-lane swizzle key is (lane>>1)&7 because fragment rows are
@@ -291,47 +288,34 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   bf16x8 xf[2][4], wlo[4], whi[4];
 
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
-#define MFMA8(WF, ROWBASE, NJ, MID, END)                                                                          \
-  do {                                                                                                    \
-    if ((ABL & 1024) && g == 1) break; /* bench-only: one MFMA stream per SIMD */                          \
-    if (ABL & 16) {                                                                                       \
-      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
-        asm volatile("" ::"v"(WF[kk]), "v"(xf[0][kk]), "v"(xf[1][kk]));  /* keep the fragment reads live */ \
-      break;                                                                                              \
-    }                                                                                                     \
-    if (!(ABL & 256)) __builtin_amdgcn_s_setprio(1);                                                                        \
-    if (ABL & 2048) { /* bench-only: the two accumulators interleaved */                                  \
-      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
-        acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-      }                                                                                                   \
-      MID;                                                                                                \
-    } else {                                                                                              \
-    /* same-accumulator MFMAs back to back: D -> C forwarding of an accumulate chain costs no wait states, while an */ \
-    /* interleaved second accumulator exposes the write-back latency of the first on every other issue            */ \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
+  // One MFMA section: two 4-long same-accumulator chains (D -> C forwarding of an accumulate chain costs no wait states,
+  // an interleaved second accumulator exposes the write-back latency of the first on every other issue) with the
+  // section's operand request (MID) between them.  The empty asm statements pin each chain inside its section.
+#define MFMA8(WF, ROWBASE, NJ, MID)                                                                           \
+  do {                                                                                                        \
+    if (ABL & 16) { /* bench-only: no MFMAs, fragment reads kept live */                                      \
+      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(WF[kk]), "v"(xf[0][kk]), "v"(xf[1][kk])); \
+      break;                                                                                                  \
+    }                                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
       acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
-    __builtin_amdgcn_sched_barrier(0); /* keep hipcc from re-interleaving the two chains */              \
-    MID;                                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                      \
+    asm volatile("" : "+v"(acc[ROWBASE][NJ]));                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    MID;                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
       acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
-    }                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                    \
-    END;                                                                                                  \
-    if (!(ABL & 256)) __builtin_amdgcn_s_setprio(0);                                                      \
+    asm volatile("" : "+v"(acc[ROWBASE + 1][NJ]));                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                                            \
   } while (0)
-// waits sit in the loads section: the 4 newest sections (8 loads; 10 with the old placement) may still be in flight
-#define WAIT_PREFETCH() do { if (ABL & 512) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else if (ABL & 32768) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
-
-// The prefetch of a phase is issued BETWEEN the two accumulate chains of the wave's own MFMA section (ABL bit 9
-// = old placement, in the loads section): the texture path then works while the matrix pipe is busy and the loads
-// section -- the critical path of the partner group's MFMA slot -- carries only the fragment reads (+3 %).
-#define BODY_STAGE(q, t) do { if (!(ABL & 1) && (ABL & 512)) stage(q, t); } while (0)
-#define MID_STAGE(q, t) do { if (!(ABL & 1) && !(ABL & 512)) { if (ABL & 8192) stage(q, t, 0); else stage(q, t); } } while (0)
-#define END_STAGE(q, t) do { if (!(ABL & 1) && !(ABL & 512) && (ABL & 8192)) stage(q, t, 1); } while (0)
+  // waits sit in the loads section: the 4 newest sections (8 requests) may still be in flight
+#define WAIT_PREFETCH() do { if (ABL & 32768) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
+  // The request of a phase is issued BETWEEN the two accumulate chains of the wave's own MFMA section: +3 % over issuing
+  // it in the loads section of the same phase.  (The persistent kernel below moves all requests into the two light loads
+  // sections instead, which is better still.)
+#define MID_STAGE(q, t) do { if (!(ABL & 1)) stage(q, t); } while (0)
 #define BODY_BARRIER() do { if (!(ABL & 4)) TFX_BARRIER(); } while (0)
   if (ABL & 2) {
 #pragma unroll
@@ -340,11 +324,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       wlo[kk] = LDS_FRAG(fw[kk]); whi[kk] = LDS_FRAG(fw[kk] + 4096);
     }
   }
-  // ABL bit 7: cycle accounting (s_memtime) of one tile's phases by every wave's lane 0 -> p.res reinterpreted as
-  // uint64 [block][wave][4] = {vmcnt wait, barrier after loads, MFMA section, barrier after MFMA}
-  unsigned long long tw = 0, tb1 = 0, tm = 0, tb2 = 0, tmark = 0;
-#define TMARK() do { if (ABL & 128) tmark = __builtin_readcyclecounter(); } while (0)
-#define TACC(acc_) do { if (ABL & 128) { unsigned long long n_ = __builtin_readcyclecounter(); acc_ += n_ - tmark; tmark = n_; } } while (0)
   auto tile_body = [&](int u, const uint32_t xs, const uint32_t ws) {
     // xs / ws: byte offset of this tile's set inside the X / W regions (0 or 16384 / 32768)
     // ---- q0: X_lo (rows 0..63 of the group's half), W_lo (cols 0..31 of the stripe)
@@ -356,31 +335,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
         wlo[kk] = LDS_FRAG(fw[kk] + ws);
       }
     }
-    BODY_STAGE(0, u + 1);
-    TMARK();
     WAIT_PREFETCH();
-    TACC(tw);
     BODY_BARRIER();
-    TACC(tb1);
-    MFMA8(wlo, 0, 0, MID_STAGE(0, u + 1), END_STAGE(0, u + 1));
-    TACC(tm);
+    MFMA8(wlo, 0, 0, MID_STAGE(0, u + 1));
     BODY_BARRIER();
-    TACC(tb2);
     // ---- q1: W_hi (cols 32..63)
     if (!(ABL & 2)) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);
     }
-    BODY_STAGE(1, u + 2);
-    TMARK();
     WAIT_PREFETCH();
-    TACC(tw);
     BODY_BARRIER();
-    TACC(tb1);
-    MFMA8(whi, 0, 1, MID_STAGE(1, u + 2), END_STAGE(1, u + 2));
-    TACC(tm);
+    MFMA8(whi, 0, 1, MID_STAGE(1, u + 2));
     BODY_BARRIER();
-    TACC(tb2);
     // ---- q2: X_hi (rows 64..127)
     if (!(ABL & 2)) {
 #pragma unroll
@@ -389,27 +356,15 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
         xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);
       }
     }
-    BODY_STAGE(2, u + 2);
-    TMARK();
     WAIT_PREFETCH();
-    TACC(tw);
     BODY_BARRIER();
-    TACC(tb1);
-    MFMA8(whi, 2, 1, MID_STAGE(2, u + 2), END_STAGE(2, u + 2));
-    TACC(tm);
+    MFMA8(whi, 2, 1, MID_STAGE(2, u + 2));
     BODY_BARRIER();
-    TACC(tb2);
     // ---- q3: no reads
-    BODY_STAGE(3, u + 2);
-    TMARK();
     WAIT_PREFETCH();
-    TACC(tw);
     BODY_BARRIER();
-    TACC(tb1);
-    MFMA8(wlo, 2, 0, MID_STAGE(3, u + 2), END_STAGE(3, u + 2));
-    TACC(tm);
+    MFMA8(wlo, 2, 0, MID_STAGE(3, u + 2));
     BODY_BARRIER();
-    TACC(tb2);
   };
 
   for (int u = 0; u < nt; u += 2) {
@@ -417,19 +372,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     if (u + 1 < nt) tile_body(u + 1, 16384u, 32768u);
   }
   if (g == 0) TFX_BARRIER();  // re-align the two groups
-  if ((ABL & 128) && lane == 0) {
-    unsigned long long* dbg = (unsigned long long*)p.res + ((size_t)blockIdx.x * 8 + wave) * 4;
-    dbg[0] = tw; dbg[1] = tb1; dbg[2] = tm; dbg[3] = tb2;
-  }
 #undef LDS_FRAG
 #undef MFMA8
 #undef WAIT_PREFETCH
-#undef BODY_STAGE
 #undef MID_STAGE
-#undef END_STAGE
 #undef BODY_BARRIER
-#undef TMARK
-#undef TACC
 
   // ---- epilogue.  Lane holds, per (mi, nj, quad), 4 consecutive columns of one row:
   //   m = m0 + g*128 + mi*32 + (lane & 31),  n = n0 + wc*64 + nj*32 + quad*8 + hi*4 + (r & 3).
@@ -926,24 +873,8 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
       case 7: return launch_ablation<7>(p, st);
       case 8: return launch_ablation<8>(p, st);
       case 16: return launch_ablation<16>(p, st);
-      case 32: return launch_ablation<32>(p, st);
-      case 128: return launch_ablation<128>(p, st);
-      case 256: return launch_ablation<256>(p, st);
-      case 512: return launch_ablation<512>(p, st);
-      case 1031: return launch_ablation<1031>(p, st);
-      case 8192: return launch_ablation<8192>(p, st);
-      case 16384: return launch_ablation<16384>(p, st);
-      case 3079: return launch_ablation<3079>(p, st);
-      case 2055: return launch_ablation<2055>(p, st);
-      case 2048: return launch_ablation<2048>(p, st);
-      case 263: return launch_ablation<263>(p, st);
-      case 129: return launch_ablation<129>(p, st);
-      case 135: return launch_ablation<135>(p, st);
-      case 144: return launch_ablation<144>(p, st);
-      case 64: return launch_ablation<64>(p, st);
-      case 96: return launch_ablation<96>(p, st);
-      case 18: return launch_ablation<18>(p, st);
       case 17: return launch_ablation<17>(p, st);
+      case 18: return launch_ablation<18>(p, st);
       case 32768: return launch_ablation<32768>(p, st);
       case 65536: return launch_ablation<65536>(p, st);
       case 98304: return launch_ablation<98304>(p, st);

@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from textflux_amd import ops
-from tools.power_probe2 import probe
+from tools.power_probe import probe
 BF = torch.bfloat16
 M, N, K = 36864, 9216, 3072
 x = torch.randn(M, K, device="cuda").to(BF); w = (torch.randn(N, K, device="cuda") * 0.02).to(BF)
