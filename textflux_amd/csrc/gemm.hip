@@ -241,18 +241,15 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
       }
       return;
     }
-    if (!CONV) {
-      // buffer form of the LDS DMA: per-lane 32-bit byte offset + scalar K offset against a per-tile descriptor -- no
-      // 64-bit per-lane address arithmetic in the issue path
-      const auto rs = isx[q] ? rsrcX : rsrcW;
+    // buffer form of the LDS DMA (everything except the gathered X rows of the conv mode above): per-lane 32-bit byte
+    // offset + scalar K offset against a per-tile descriptor -- no 64-bit per-lane address arithmetic in the issue path
+    const auto rs = isx[q] ? rsrcX : rsrcW;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (!((ABL & 32768) && j == 1))   // bench-only bit 15: half the prefetch bytes
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (ok ? ldst[q][j] + setoff : dummy)), 16,
-                                                   (ABL & 65536) ? lane * 16 : goff[q][j] * 2,  // bit 16: L1-hot source
-                                                   (ABL & 65536) ? 0 : kt * 128, 0, kAux);
-      return;
-    }
+    for (int j = 0; j < 2; ++j)
+      if (!((ABL & 32768) && j == 1))   // bench-only bit 15: half the prefetch bytes
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + (ok ? ldst[q][j] + setoff : dummy)), 16,
+                                                 (ABL & 65536) ? lane * 16 : goff[q][j] * 2,  // bit 16: L1-hot source
+                                                 (ABL & 65536) ? 0 : kt * 128, 0, kAux);
   };
 
   // ---- fragment read addresses (set 0); per-lane swizzle key is (lane>>1)&7 because fragment rows are
@@ -290,7 +287,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
   // One MFMA section: two 4-long same-accumulator chains (D -> C forwarding of an accumulate chain costs no wait states,
   // an interleaved second accumulator exposes the write-back latency of the first on every other issue) with the
-  // section's operand request (MID) between them.  The empty asm statements pin each chain inside its section.
+  // section's operand request (MID) between them; sched_barriers keep hipcc from re-interleaving the chains.
 #define MFMA8(WF, ROWBASE, NJ, MID)                                                                           \
   do {                                                                                                        \
     if (ABL & 16) { /* bench-only: no MFMAs, fragment reads kept live */                                      \
@@ -300,13 +297,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     __builtin_amdgcn_s_setprio(1);                                                                            \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
       acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
-    asm volatile("" : "+v"(acc[ROWBASE][NJ]));                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     MID;                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
       acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
-    asm volatile("" : "+v"(acc[ROWBASE + 1][NJ]));                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                                            \
   } while (0)
