@@ -77,4 +77,7 @@ def max_over_ranks(value: float, device) -> float:
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":      # name the device: RCCL would otherwise guess it from the rank
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
