@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--layers", type=int, nargs=2, default=[19, 38], help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of per-step hipGraph replay")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help=argparse.SUPPRESS)  # tuning knobs (tfx_set_option)
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: e4m3 block linears on the fp8 MFMA (NOT the bf16 headline)")
     a = ap.parse_args()
 
@@ -105,6 +106,9 @@ def main():
     from textflux_amd.vae import AutoencoderKL
 
     rank, world, local = tdist.init_from_env()
+    for kv in a.option:
+        name, _, val = kv.partition("=")
+        ops.set_option(name, int(val))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     dev = torch.device("cuda", local)
