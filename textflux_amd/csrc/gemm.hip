@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
   // one K-tile out of buffer set SET; (GO, XO, WO, KT) = the operands requested meanwhile (two K-tiles ahead)
-#define PP_TILE(SET, GO, XO, WO, KT)                                                                         \
+#define PP_TILE_W(SET, GO, XO, WO, KT, W0, W1, W3)                                                           \
   do {                                                                                                       \
     constexpr uint32_t xs = (SET) * 16384u, ws = (SET) * 32768u;                                             \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {            /* L0: X_lo, W_lo */                       \
@@ -614,12 +614,13 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
       xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);                                                              \
       wlo[kk] = LDS_FRAG(fw[kk] + ws);                                                                       \
     }                                                                                                        \
-    PP_VMCNT(10); TFX_BARRIER();                                                                             \
+    if (W0) PP_VMCNT(10);                                                                                    \
+    TFX_BARRIER();                                                                                           \
     PP_MFMA8(wlo, 0, 0);                                                                                     \
     TFX_BARRIER();                                                                                           \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);  /* L1: W_hi */ \
     stage(0, GO, XO, WO, KT, SET);                                                                           \
-    if (PLACE == 1) { stage(1, GO, XO, WO, KT, SET); PP_VMCNT(12); } else { PP_VMCNT(10); }                  \
+    if (PLACE == 1) { stage(1, GO, XO, WO, KT, SET); if (W1) PP_VMCNT(12); } else { if (W1) PP_VMCNT(10); }  \
     TFX_BARRIER();                                                                                           \
     PP_MFMA8(whi, 0, 1);                                                                                     \
     TFX_BARRIER();                                                                                           \
@@ -633,10 +634,12 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     TFX_BARRIER();                                                                                           \
     stage(2, GO, XO, WO, KT, SET);                                /* L3: no reads */                         \
     stage(3, GO, XO, WO, KT, SET);                                                                           \
-    PP_VMCNT(12); TFX_BARRIER();                                                                             \
+    if (W3) PP_VMCNT(12);                                                                                    \
+    TFX_BARRIER();                                                                                           \
     PP_MFMA8(wlo, 2, 0);                                                                                     \
     TFX_BARRIER();                                                                                           \
   } while (0)
+#define PP_TILE(SET, GO, XO, WO, KT) PP_TILE_W(SET, GO, XO, WO, KT, 1, 1, 1)
 
   char* stg = smem + PP_STG + wave * PP_STG_WAVE;
   for (;;) {
@@ -654,7 +657,17 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int u = 0; u < nt - 2; u += 2) {
+    // Everything K-tiles 0 and 1 read was waited for before this tile started (prologue / the epilogue's vmcnt(0)), and
+    // the first requests of THIS tile have their deadline at L3 of K-tile 1: the earlier counted waits could only stall
+    // on the previous epilogue's stores, which retire in issue order with the requests.
+    int u0 = 0;
+    // (not in the fp8 gated-residual instantiation: there the two extra loop bodies tip hipcc's allocation into 80+ spills)
+    if (nt >= 4 && !(FP8 && EPI == EPI_BIAS_GATE_RES)) {
+      PP_TILE_W(0, goc, cx, cw, 2, 0, 0, 0);
+      PP_TILE_W(1, goc, cx, cw, 3, 0, 0, 1);
+      u0 = 2;
+    }
+    for (int u = u0; u < nt - 2; u += 2) {
       PP_TILE(0, goc, cx, cw, u + 2);
       PP_TILE(1, goc, cx, cw, u + 3);
     }
@@ -798,6 +811,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #undef PP_CHAIN
 #undef PP_CAT
 #undef PP_TILE
+#undef PP_TILE_W
 }
 
 // ------------------------------------------------------------------------------------------------
