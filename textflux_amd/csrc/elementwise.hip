@@ -88,40 +88,60 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16_t* __restrict__ 
                                                            const bf16_t* __restrict__ wk_txt,
                                                            const float* __restrict__ cosT,
                                                            const float* __restrict__ sinT, float eps) {
+  // 16 lanes per token, HSPLIT lane groups share a token's heads: each lane keeps the token's cos / sin for its 8
+  // positions and both norm weights in registers and walks over its share of the 2H head rows (q heads, then k heads),
+  // so the rotary table is read once per token instead of once per head row (it was 2/3 of this kernel's L2 traffic).
+  constexpr int HSPLIT = 4;
   const int sub = threadIdx.x & 15;
-  const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;  // head-row id
-  const int64_t total = (int64_t)B * Ntok * 2 * H;
-  if (g >= total) return;
-  const int h = (int)(g % H);
-  const int which = (int)((g / H) & 1);
-  const int64_t tokrow = g / (2 * H);
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int64_t tokrow = grp / HSPLIT;
+  const int part = (int)(grp - tokrow * HSPLIT);
+  if (tokrow >= (int64_t)B * Ntok) return;
   const int b = (int)(tokrow / Ntok);
   const int n = (int)(tokrow - (int64_t)b * Ntok);
-  bf16_t* p = buf + b * bstride + (int64_t)n * ld + (which ? k_off : q_off) + h * 128 + sub * 8;
-  const bf16_t* w = (n < T) ? (which ? wk_txt : wq_txt) : (which ? wk_img : wq_img);
-  float x[8], wv[8];
-  unpack8(*reinterpret_cast<const u32x4*>(p), x);
-  unpack8(*reinterpret_cast<const u32x4*>(w + sub * 8), wv);
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-  const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
   const float4* c4 = reinterpret_cast<const float4*>(cosT + (int64_t)n * 128 + sub * 8);
   const float4* s4 = reinterpret_cast<const float4*>(sinT + (int64_t)n * 128 + sub * 8);
   const float4 ca = c4[0], cb = c4[1], sa = s4[0], sb = s4[1];
   const float cs[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
   const float sn[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
-  float y[8], o[8];
+  float wq[8], wk[8];
+  unpack8(*reinterpret_cast<const u32x4*>(((n < T) ? wq_txt : wq_img) + sub * 8), wq);
+  unpack8(*reinterpret_cast<const u32x4*>(((n < T) ? wk_txt : wk_img) + sub * 8), wk);
+  bf16_t* row = buf + b * bstride + (int64_t)n * ld + sub * 8;
+  const int per = (2 * H + HSPLIT - 1) / HSPLIT;
+  const int hr0 = part * per, hr_end = min(2 * H, (part + 1) * per);
+  constexpr int CH = 6;   // head rows requested together: in place, so hipcc will not move a load above an earlier store
+  for (int base = hr0; base < hr_end; base += CH) {
+    u32x4 raw[CH];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = round_bf(round_bf(x[i] * r) * wv[i]);  // .to(bf16) then * weight (bf16)
+    for (int c = 0; c < CH; ++c) {
+      const int hr = min(base + c, hr_end - 1);
+      raw[c] = *reinterpret_cast<const u32x4*>(row + (hr >= H ? k_off + (hr - H) * 128 : q_off + hr * 128));
+    }
 #pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    o[i] = y[i] * cs[i] + (-y[i + 1]) * sn[i];
-    o[i + 1] = y[i + 1] * cs[i + 1] + y[i] * sn[i + 1];
+    for (int c = 0; c < CH; ++c) {
+      const int hr = base + c;
+      if (hr >= hr_end) break;
+      const bool is_k = hr >= H;
+      float x[8];
+      unpack8(raw[c], x);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+      float y[8], o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = round_bf(round_bf(x[i] * r) * (is_k ? wk[i] : wq[i]));  // .to(bf16) then * weight (bf16)
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        o[i] = y[i] * cs[i] + (-y[i + 1]) * sn[i];
+        o[i + 1] = y[i + 1] * cs[i + 1] + y[i] * sn[i + 1];
+      }
+      *reinterpret_cast<u32x4*>(row + (is_k ? k_off + (hr - H) * 128 : q_off + hr * 128)) = pack8(o);
+    }
   }
-  *reinterpret_cast<u32x4*>(p) = pack8(o);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,8 +335,8 @@ int ln_modulate(const void* x, void* out, const void* shift, const void* scale, 
 int rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int q_off, int k_off, int H, int Ntok, int T, int B,
                  const void* wq_img, const void* wk_img, const void* wq_txt, const void* wk_txt, const float* cosT,
                  const float* sinT, float eps, hipStream_t st) {
-  const int64_t groups = (int64_t)B * Ntok * 2 * H;
-  if (groups == 0) return 0;
+  const int64_t groups = (int64_t)B * Ntok * 4;   // 4 lane groups of 16 per token (HSPLIT in the kernel)
+  if (groups == 0 || H == 0) return 0;
   rmsnorm_rope_kernel<<<dim3((unsigned)((groups + 15) / 16)), 256, 0, st>>>(
       (bf16_t*)buf, ld, bstride, q_off, k_off, H, Ntok, T, B, (const bf16_t*)wq_img, (const bf16_t*)wk_img,
       (const bf16_t*)wq_txt, (const bf16_t*)wk_txt, cosT, sinT, eps);
