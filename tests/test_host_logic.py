@@ -190,6 +190,22 @@ def test_encode_prompt_with_tiny_text_encoders():
     assert torch.allclose(pooled[0], ref_pooled[0])
     pe2, pooled2, _ = p.encode_prompt(prompt=None, prompt_2=None, prompt_embeds=pe, pooled_prompt_embeds=pooled, device="cpu")
     assert pe2 is pe and pooled2 is pooled
+    # prompt cache: same results, the encoders only see strings they have not seen before
+    calls = {"clip": 0, "t5": 0}
+    clip_fwd, t5_fwd = clip.forward, t5.forward
+    clip.forward = lambda *a, **k: (calls.__setitem__("clip", calls["clip"] + a[0].shape[0]), clip_fwd(*a, **k))[1]
+    t5.forward = lambda *a, **k: (calls.__setitem__("t5", calls["t5"] + a[0].shape[0]), t5_fwd(*a, **k))[1]
+    p.enable_prompt_cache(8)
+    pe3, pooled3, _ = p.encode_prompt(prompt=["a", "b"], prompt_2=["c d", "e"], device="cpu", num_images_per_prompt=2,
+                                      max_sequence_length=24)
+    assert torch.equal(pe3, pe) and torch.equal(pooled3, pooled) and calls == {"clip": 2, "t5": 2}
+    pe4, pooled4, _ = p.encode_prompt(prompt=["a", "a", "b"], prompt_2=["e", "new", "c d"], device="cpu", max_sequence_length=24)
+    assert calls == {"clip": 2, "t5": 3}                                        # only "new" reached an encoder
+    assert torch.equal(pe4[0], pe[2]) and torch.equal(pe4[2], pe[0]) and torch.equal(pooled4[0], pooled4[1])
+    p.enable_prompt_cache(0)
+    p.encode_prompt(prompt=["a"], prompt_2=["e"], device="cpu", max_sequence_length=24)
+    assert calls == {"clip": 3, "t5": 4}
+    clip.forward, t5.forward = clip_fwd, t5_fwd
     p.text_encoder = None
     with pytest.raises(ValueError):
         p.encode_prompt(prompt="a", prompt_2=None, device="cpu")

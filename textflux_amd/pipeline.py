@@ -221,6 +221,29 @@ class FluxFillPipeline:
         self.load_lora_into_transformer(sd, alphas, self.transformer)
 
     # ------------------------------------------------------------------ prompt encoding (third-party `transformers`)
+    def enable_prompt_cache(self, max_entries: int = 256):
+        """Keep the encoder outputs of the last `max_entries` distinct prompt strings (0 disables).  TextFlux drives the
+        pipeline with ONE fixed CLIP prompt (the template) and T5 prompts that differ only in the quoted words
+        (run_inference.py:27-40), so a batch driver re-encodes the same strings over and over.  Results
+        are exactly what the encoders return for the string -- the cache only skips the call."""
+        self._prompt_cache = {} if max_entries > 0 else None
+        self._prompt_cache_max = int(max_entries)
+        return self
+
+    def _cached_encode(self, kind, prompts, key_extra, encode):
+        """Rows of `encode(list_of_missing_prompts)` ([n, ...] tensor) for every prompt, served from the cache where possible."""
+        cache = getattr(self, "_prompt_cache", None)
+        if cache is None:
+            return encode(prompts)
+        missing = [p for p in dict.fromkeys(prompts) if (kind, p, key_extra) not in cache]
+        if missing:
+            out = encode(missing)
+            for p, row in zip(missing, out):
+                if len(cache) >= self._prompt_cache_max:
+                    cache.pop(next(iter(cache)))           # oldest entry out
+                cache[(kind, p, key_extra)] = row.detach().clone()
+        return torch.stack([cache[(kind, p, key_extra)] for p in prompts])
+
     def _get_t5_prompt_embeds(self, prompt=None, num_images_per_prompt: int = 1, max_sequence_length: int = 512,
                               device=None, dtype=None):
         """P:1411-1458."""
@@ -228,9 +251,13 @@ class FluxFillPipeline:
         dtype = dtype or self.text_encoder_2.dtype
         prompt = [prompt] if isinstance(prompt, str) else prompt
         batch_size = len(prompt)
-        ids = self.tokenizer_2(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
-                               return_length=False, return_overflowing_tokens=False, return_tensors="pt").input_ids
-        emb = self.text_encoder_2(ids.to(device), output_hidden_states=False)[0]
+
+        def encode(ps):
+            ids = self.tokenizer_2(ps, padding="max_length", max_length=max_sequence_length, truncation=True,
+                                   return_length=False, return_overflowing_tokens=False, return_tensors="pt").input_ids
+            return self.text_encoder_2(ids.to(device), output_hidden_states=False)[0]
+
+        emb = self._cached_encode("t5", prompt, (max_sequence_length, str(device)), encode)
         emb = emb.to(dtype=self.text_encoder_2.dtype, device=device)
         _, seq_len, _ = emb.shape
         emb = emb.repeat(1, num_images_per_prompt, 1)
@@ -241,9 +268,13 @@ class FluxFillPipeline:
         device = device or self._execution_device
         prompt = [prompt] if isinstance(prompt, str) else prompt
         batch_size = len(prompt)
-        ids = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer_max_length, truncation=True,
-                             return_overflowing_tokens=False, return_length=False, return_tensors="pt").input_ids
-        emb = self.text_encoder(ids.to(device), output_hidden_states=False).pooler_output
+
+        def encode(ps):
+            ids = self.tokenizer(ps, padding="max_length", max_length=self.tokenizer_max_length, truncation=True,
+                                 return_overflowing_tokens=False, return_length=False, return_tensors="pt").input_ids
+            return self.text_encoder(ids.to(device), output_hidden_states=False).pooler_output
+
+        emb = self._cached_encode("clip", prompt, (self.tokenizer_max_length, str(device)), encode)
         emb = emb.to(dtype=self.text_encoder.dtype, device=device)
         emb = emb.repeat(1, num_images_per_prompt)
         return emb.view(batch_size * num_images_per_prompt, -1)
