@@ -189,6 +189,9 @@ int tfx_set_option(const char* name, int value);
  * returns the summed kernel time, FLOPs and launch count (kind 2: fp8 GEMM launches), then clears the records.  Not capturable into a graph. */
 int tfx_prof_enable(int on);
 int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches);
+/* Phase timing of the attention kernels (tools/attn_timing.py): buf = device uint64 [blocks][8 waves][4 phases] that the
+ * instrumented kernel variants fill with cycle counts, NULL switches back to the plain kernels. */
+int tfx_debug_attention_timing(void* buf);
 
 #ifdef __cplusplus
 }

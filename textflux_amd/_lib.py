@@ -103,6 +103,7 @@ SIGNATURES = {
     "tfx_set_option": (c_int, [c_char_p, c_int]),
     "tfx_prof_enable": (c_int, [c_int]),
     "tfx_prof_collect": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
+    "tfx_debug_attention_timing": (c_int, [c_void_p]),
 }
 
 _lib = None

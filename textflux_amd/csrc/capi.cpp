@@ -301,7 +301,7 @@ int tfx_set_option(const char* name, int value) {
   return fail("tfx_set_option: unknown option '%s'", name);
 }
 
-int tfx_debug_attention_timing(void* buf) { set_attention_debug(buf); return 0; }  // bench-only, not in the header
+int tfx_debug_attention_timing(void* buf) { set_attention_debug(buf); return 0; }
 
 int tfx_prof_enable(int on) { prof_enable(on); return 0; }
 int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches) {
