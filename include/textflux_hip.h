@@ -50,6 +50,10 @@ typedef struct tfx_gemm_args {
   int32_t gelu_from_col;
   const void* gate; int64_t gate_bstride;
   const void* res; int64_t ldr; int64_t r_bstride;
+  /* optional caller-owned scratch (>= 16-byte aligned): when a GEMM has fewer 256x256 tiles than the device has CUs, the
+   * auto path splits K into 2-4 slices, writes fp32 partials [slices][batch][M][N] here and finishes in a second pass
+   * (deterministic: slices are summed in order).  NULL / too small = no split. */
+  void* workspace; int64_t workspace_bytes;
 } tfx_gemm_args;
 int tfx_gemm_bf16(const tfx_gemm_args* args, int variant, tfx_stream stream);
 
@@ -156,6 +160,7 @@ typedef struct tfx_dit_desc {
    * tfx_quantize_rows_fp8(activations) -> tfx_gemm_fp8; q8 [B][N, 5D] bytes and q8_scale [B][N] fp32 are the
    * caller-owned workspace of the quantised activations.  Embedders, modulation and proj_out stay bf16. */
   void* q8; float* q8_scale;
+  void* gemm_workspace; int64_t gemm_workspace_bytes;   /* optional, passed to every block Linear (tfx_gemm_args.workspace) */
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
 
@@ -180,7 +185,8 @@ int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* 
  *      9 = 8 with 128 keys per barrier; 16 = softmax / MFMA ping-pong between the wave groups.  All compute the same
  *      softmax; 10 and 12 differ from the others in rounding only (one extra bf16 rounding of q * scale, row sums of the
  *      bf16 weights).  "gemm_group_m": row tiles per group of the GEMM tile order (default 4).  "gemm_place": slot
- *      assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip). */
+ *      assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip).  "gemm_splitk": 0 disables the
+ *      split-K path of few-tile GEMMs (default 1). */
 int tfx_set_option(const char* name, int value);
 
 /* ---- measurement hooks (no reference counterpart: the reference has no profiling) --------------------

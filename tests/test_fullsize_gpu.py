@@ -96,6 +96,19 @@ def test_full_model_batch_consistency_and_determinism():
     o2 = m(hidden_states=hs.repeat(2, 1, 1), encoder_hidden_states=pe.repeat(2, 1, 1),
            pooled_projections=pooled.repeat(2, 1), timestep=t1.repeat(2), guidance=g1.repeat(2), **kw)[0]
     assert torch.isfinite(o1.float()).all() and o1.float().std().item() > 1e-3
-    assert torch.equal(o2[0], o2[1]) and torch.equal(o2[0], o1[0])
+    assert torch.equal(o2[0], o2[1])
+    # batch 1 vs batch 2: the text-stream GEMMs have fewer tiles than CUs at batch 1 and take the split-K path there
+    # (another fp32 summation order): isolated one-ulp differences that six blocks of bf16 arithmetic amplify to the usual
+    # bf16 noise level (the reference's own bf16-vs-fp32 distance on a 4-block model is 1e-2) -- and not at all with
+    # split-K off, which is asserted below
+    rel = ((o2[0].float() - o1[0].float()).abs().mean() / o1[0].float().abs().mean()).item()
+    assert rel < 2e-2, rel
     o3 = m(hidden_states=hs, encoder_hidden_states=pe, pooled_projections=pooled, timestep=t1, guidance=g1, **kw)[0]
     assert torch.equal(o1, o3)
+    from textflux_amd import ops
+    ops.set_option("gemm_splitk", 0)
+    try:
+        o4 = m(hidden_states=hs, encoder_hidden_states=pe, pooled_projections=pooled, timestep=t1, guidance=g1, **kw)[0]
+    finally:
+        ops.set_option("gemm_splitk", 1)
+    assert torch.equal(o4[0], o2[0])

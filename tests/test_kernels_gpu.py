@@ -112,6 +112,32 @@ def test_gemm_persistent_bit_identical_to_one_tile_kernel(ops, B, M, N, K):
         ops.set_option("gemm_place", 2)
 
 
+@pytest.mark.parametrize("B,M,N,K", [(1, 1664, 3072, 3072), (1, 1152, 3072, 12288), (2, 300, 3136, 4096), (1, 512, 9216, 3072)])
+def test_gemm_split_k_matches_unsplit(ops, B, M, N, K):
+    """Few-tile GEMMs (fewer 256x256 tiles than CUs) with a workspace take the split-K path: fp32 partials per K slice,
+    summed in slice order by the second pass with the same epilogues.  Against the unsplit persistent kernel the only
+    difference is the fp32 summation order: bf16 results agree except for isolated one-ulp flips; without a workspace,
+    or with gemm_splitk = 0, the auto path is bit-identical to the unsplit kernel."""
+    a, w = rnd((B, M, K), 51).to(BF).cuda(), rnd((N, K), 52, 0.03).to(BF).cuda()
+    bias, gate, res = rnd((N,), 53).to(BF).cuda(), rnd((B, N), 54).to(BF).cuda(), rnd((B, M, N), 55).to(BF).cuda()
+    ws = torch.empty(4 * B * M * N, dtype=torch.float32, device="cuda")
+    cases = [(ops.EPI_BIAS, {}), (ops.EPI_BIAS_GELU, dict(gelu_from_col=max(0, (N // 256 - 2) * 256))),
+             (ops.EPI_BIAS_GATE_RES, dict(gate=gate, res=res)), (ops.EPI_BIAS_RES, dict(res=res))]
+    for epi, kw in cases:
+        unsplit = ops.gemm(a, w, bias, epilogue=epi, variant=3, **kw)
+        split = ops.gemm(a, w, bias, epilogue=epi, variant=1, workspace=ws, **kw)
+        d = (unsplit.float() - split.float()).abs()
+        assert torch.isfinite(split).all()
+        assert d.max().item() <= 2 ** -7 * unsplit.float().abs().max().item()          # at most one bf16 ulp of the largest value
+        assert (d > 0).float().mean().item() < 2e-2 and d.mean().item() < 1e-5 * max(1.0, unsplit.float().abs().mean().item())
+        assert torch.equal(ops.gemm(a, w, bias, epilogue=epi, variant=1, **kw), unsplit)            # no workspace: no split
+    ops.set_option("gemm_splitk", 0)
+    try:
+        assert torch.equal(ops.gemm(a, w, bias, variant=1, workspace=ws), ops.gemm(a, w, bias, variant=3))
+    finally:
+        ops.set_option("gemm_splitk", 1)
+
+
 def test_gemm_persistent_rejects_odd_k_tiles(ops):
     a, w = rnd((512, 192), 1).to(BF).cuda(), rnd((256, 192), 2).to(BF).cuda()
     with pytest.raises(RuntimeError, match="persistent"):

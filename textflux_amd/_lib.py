@@ -26,6 +26,7 @@ class GemmArgs(C.Structure):
         ("epilogue", c_int32), ("gelu_from_col", c_int32),
         ("gate", c_void_p), ("gate_bstride", c_int64),
         ("res", c_void_p), ("ldr", c_int64), ("r_bstride", c_int64),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -66,6 +67,7 @@ class DitDesc(C.Structure):
         ("out", c_void_p),
         ("first_block", c_int32), ("last_block", c_int32), ("flags", c_int32),
         ("q8", c_void_p), ("q8_scale", c_void_p),
+        ("gemm_workspace", c_void_p), ("gemm_workspace_bytes", c_int64),
     ]
 
 

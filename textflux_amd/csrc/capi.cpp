@@ -32,6 +32,7 @@ struct Gemm {
     a.epilogue = EPI_BIAS_GATE_RES; a.gate = gate; a.gate_bstride = gbs; a.res = res; a.ldr = ldr; a.r_bstride = rbs;
     return *this;
   }
+  Gemm& scratch(void* ws, int64_t bytes) { a.workspace = ws; a.workspace_bytes = bytes; return *this; }
   int run(hipStream_t st) const { return gemm_bf16(a, st); }
   // fp8 linears (desc.flags bit 2): quantise the activation rows into the q8 workspace, then the e4m3 GEMM
   int run(hipStream_t st, void* q8, float* q8_scale) const {
@@ -100,35 +101,35 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
       const uint16_t* mt = mi + 6 * D;                   // txt: same six
       TRY(ln_modulate(hid_img, xn_img, mi, mi + D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
       if (T > 0) TRY(ln_modulate(hid, xn, mt, mt + D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
-      TRY(Gemm(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B).run(st, q8, q8s));
-      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.qkv_txt, D, y, D7, y_bs, T, 3 * D, D, B).run(st, q8, q8s));
+      TRY(Gemm(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
+      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.qkv_txt, D, y, D7, y_bs, T, 3 * D, D, B).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
       TRY(attention(T, w.norm_q, w.norm_k, w.norm_added_q, w.norm_added_k));
       // hidden += gate_msa * to_out(attn)   (:817-818, 830-831)
       TRY(Gemm(y_img + 2 * D, D7, y_bs, w.out_img, D, hid_img, D, hid_bs, Sn, D, D, B)
-              .gate_res(mi + 2 * D, mbs, hid_img, D, hid_bs).run(st, q8, q8s));
+              .gate_res(mi + 2 * D, mbs, hid_img, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
       if (T > 0)
         TRY(Gemm(y + 2 * D, D7, y_bs, w.out_txt, D, hid, D, hid_bs, T, D, D, B)
-                .gate_res(mt + 2 * D, mbs, hid, D, hid_bs).run(st, q8, q8s));
+                .gate_res(mt + 2 * D, mbs, hid, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
       // MLP: norm2 * (1 + scale_mlp) + shift_mlp -> ff -> gated residual (:820-826, 833-837)
       TRY(ln_modulate(hid_img, xn_img, mi + 3 * D, mi + 4 * D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
       if (T > 0) TRY(ln_modulate(hid, xn, mt + 3 * D, mt + 4 * D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
-      TRY(Gemm(xn_img, D, hid_bs, w.ff1_img, D, y_img + 3 * D, D7, y_bs, Sn, 4 * D, D, B).gelu(0).run(st, q8, q8s));
-      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.ff1_txt, D, y + 3 * D, D7, y_bs, T, 4 * D, D, B).gelu(0).run(st, q8, q8s));
+      TRY(Gemm(xn_img, D, hid_bs, w.ff1_img, D, y_img + 3 * D, D7, y_bs, Sn, 4 * D, D, B).gelu(0).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
+      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.ff1_txt, D, y + 3 * D, D7, y_bs, T, 4 * D, D, B).gelu(0).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
       TRY(Gemm(y_img + 3 * D, D7, y_bs, w.ff2_img, 4 * D, hid_img, D, hid_bs, Sn, D, 4 * D, B)
-              .gate_res(mi + 5 * D, mbs, hid_img, D, hid_bs).run(st, q8, q8s));
+              .gate_res(mi + 5 * D, mbs, hid_img, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
       if (T > 0)
         TRY(Gemm(y + 3 * D, D7, y_bs, w.ff2_txt, 4 * D, hid, D, hid_bs, T, D, 4 * D, B)
-                .gate_res(mt + 5 * D, mbs, hid, D, hid_bs).run(st, q8, q8s));
+                .gate_res(mt + 5 * D, mbs, hid, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
     } else {
       // ---- FluxSingleTransformerBlock.forward (transformer_flux.py:715-739) on the joint [text | image] sequence
       const int j = blk - d.n_double;
       const tfx_single_block& w = d.sgl[j];
       const uint16_t* ms = mod + (int64_t)d.n_double * 12 * D + (int64_t)j * 3 * D;  // shift scale gate
       TRY(ln_modulate(hid, xn, ms, ms + D, mbs, N, B, D, D, hid_bs, D, hid_bs, eps, st));
-      TRY(Gemm(xn, D, hid_bs, w.qkv_mlp, D, y, D7, y_bs, N, 7 * D, D, B).gelu(3 * D).run(st, q8, q8s));
+      TRY(Gemm(xn, D, hid_bs, w.qkv_mlp, D, y, D7, y_bs, N, 7 * D, D, B).gelu(3 * D).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
       TRY(attention(0, w.norm_q, w.norm_k, w.norm_q, w.norm_k));
       TRY(Gemm(y + 2 * D, D7, y_bs, w.proj_out, 5 * D, hid, D, hid_bs, N, D, 5 * D, B)
-              .gate_res(ms + 2 * D, mbs, hid, D, hid_bs).run(st, q8, q8s));
+              .gate_res(ms + 2 * D, mbs, hid, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
     }
   }
 
@@ -171,6 +172,7 @@ int tfx_gemm_bf16(const tfx_gemm_args* g, int variant, tfx_stream stream) {
   a.epilogue = g->epilogue; a.gelu_from_col = g->gelu_from_col;
   a.gate = g->gate; a.gate_bstride = g->gate_bstride;
   a.res = g->res; a.ldr = g->ldr; a.r_bstride = g->r_bstride;
+  a.workspace = g->workspace; a.workspace_bytes = g->workspace_bytes;
   if (!a.A || !a.W || !a.C) return fail("tfx_gemm_bf16: null matrix pointer");
   return variant < 0 ? gemm_bf16(a, S(stream)) : gemm_bf16_variant(a, variant, S(stream));
 }
@@ -297,6 +299,7 @@ int tfx_set_option(const char* name, int value) {
   }
   if (!std::strcmp(name, "gemm_group_m")) { set_gemm_group_m(value); return 0; }
   if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
+  if (!std::strcmp(name, "gemm_splitk")) { set_gemm_splitk(value); return 0; }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only
   return fail("tfx_set_option: unknown option '%s'", name);
 }

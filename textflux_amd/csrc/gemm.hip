@@ -37,6 +37,7 @@ struct GemmParams {
   int cin, inH, inW, oH, oW, cstride, cup, cpad;   // implicit 3x3 convolution (cin > 0), see GemmArgs
   const bf16_t* zero;
   const float* a_scale; int64_t as_bs; const float* w_scale;   // fp8 kernel only
+  float* ws; int sk;                                             // split-K: fp32 partials [sk][batch][M][N], slices
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -473,7 +474,10 @@ constexpr int PP_LDS_TOTAL = PP_STG + 8 * PP_STG_WAVE;  // 163840 = all of the C
 // v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; 64 matrix cycles each) instead of four 32x32x16 bf16 (32 each),
 // i.e. the same 256 cycles per section for twice the k, and the epilogue applies the per-row / per-channel scales.
 // Lane l supplies row (l & 31), k bytes (l >> 5) * 32 .. +32 of a 64-k step (checked by tools/ubench/mfma_fp8_layout.hip).
-template <int EPI, int PLACE = 2, bool FP8 = false>
+// SPLIT: the work unit is (tile, K slice): p.sk slices of nt / p.sk K-tiles each, units ordered slice-major; the epilogue
+// stores the raw fp32 accumulators to p.ws [slice][batch][M][N] and splitk_reduce_kernel<EPI> finishes (sum over the
+// slices in order, bias, activation, gate, residual).  Used when a GEMM has fewer tiles than the chip has CUs.
+template <int EPI, int PLACE = 2, bool FP8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -482,11 +486,12 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   const int g = wave >> 2;
   const int wc = wave & 3;
   constexpr int ESZ = FP8 ? 1 : 2;       // bytes per operand element
-  const int nt = (p.K * ESZ) >> 7;        // K-tiles of 128 bytes per row
+  const int nt = ((p.K * ESZ) >> 7) / (SPLIT ? p.sk : 1);   // K-tiles of 128 bytes per row (per slice)
 
   // ---- this block's tiles: XCD x owns a contiguous range of the (grouped) tile order; its blocks stride through it
   const int per_batch = p.tm * p.tn;
-  const int T = p.batch * per_batch;
+  const int T1 = p.batch * per_batch;               // tiles
+  const int T = SPLIT ? T1 * p.sk : T1;             // work units
   const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
   const int q8 = T >> 3, r8 = T & 7;
   const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -494,9 +499,11 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   int it = blockIdx.x >> 3;
   if (it >= xcnt) return;
 
-  struct Tile { int b, m0, n0; uint32_t xoff, woff; };
+  struct Tile { int b, m0, n0, slice; uint32_t xoff, woff; };
   auto coords = [&](int id) {
     Tile t;
+    t.slice = SPLIT ? id / T1 : 0;
+    if (SPLIT) id -= t.slice * T1;
     t.b = id / per_batch;
     int idx = id - t.b * per_batch;
     const int GM = p.gm;
@@ -506,8 +513,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     idx -= grp * GM * p.tn;
     t.m0 = (first_m + idx % gsz) * 256;
     t.n0 = (idx / gsz) * 256;
-    t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * ESZ);
-    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * ESZ);
+    t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * ESZ) + (uint32_t)(t.slice * nt) * 128u;
+    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * ESZ) + (uint32_t)(t.slice * nt) * 128u;
     return t;
   };
 
@@ -678,6 +685,34 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     // Every vector the epilogue needs (bias, gate, the first block's residual rows) is requested up front and waited
     // for ONCE; the residual rows of block mi+1 are requested as soon as block mi has consumed its own.  (Loaded at their
     // first use they cost one memory round trip each: 16-28 of them per tile, 26 us of a 95 us tile at K = 3072.)
+    if (SPLIT) {
+      // raw fp32 partials: lane = row r32 of each 32-row block, 4 consecutive columns per (nj, quad) -> 16-byte stores
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      float* wsp = p.ws + ((int64_t)(cur.slice * p.batch + cur.b) * p.M) * p.N;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = cur.m0 + g * 128 + mi * 32 + (le & 31);
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int n = cur.n0 + wc * 64 + nj * 32 + qd * 8 + (le >> 5) * 4;
+            if (m < p.M && n < p.N)
+              *reinterpret_cast<f32x4*>(wsp + (int64_t)m * p.N + n) =
+                  f32x4{acc[mi][nj][qd * 4], acc[mi][nj][qd * 4 + 1], acc[mi][nj][qd * 4 + 2], acc[mi][nj][qd * 4 + 3]};
+          }
+      }
+      if (!has_next) break;
+      cur = nxt;
+      it = nit;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) goc[q][j] = gon[q][j];
+      continue;
+    }
     const int m0 = cur.m0, n0 = cur.n0, b = cur.b;
     // lane-derived offsets are rebuilt from an opaque copy of the lane id: derived from `lane` they are loop invariants
     // that hipcc keeps in ~20 VGPRs across the K loop, which is what pushed this kernel into spilling
@@ -814,7 +849,61 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #undef PP_TILE_W
 }
 
+// Second pass of the split-K path: C = epi(sum_s P[s] + bias), 8 columns per thread, slices summed in order.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
+  const int64_t chunks_per_row = p.N >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)p.batch * p.M * chunks_per_row) return;
+  const int64_t row = i / chunks_per_row;       // b * M + m
+  const int n = (int)(i - row * chunks_per_row) * 8;
+  const int b = (int)(row / p.M);
+  const int m = (int)(row - (int64_t)b * p.M);
+  const int64_t slice_stride = (int64_t)p.batch * p.M * p.N;
+  const float* src = p.ws + row * p.N + n;
+  float v[8];
+  {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
+  }
+  for (int s = 1; s < p.sk; ++s) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + s * slice_stride);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + s * slice_stride + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
+  }
+  if (p.bias) {
+    float bs[8];
+    unpack8(*reinterpret_cast<const u32x4*>(p.bias + n), bs);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bs[e];
+  }
+  if (EPI == EPI_BIAS_GELU && n >= p.gelu_from) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+  }
+  if (EPI == EPI_BIAS_GATE_RES) {
+    float gt[8];
+    unpack8(*reinterpret_cast<const u32x4*>(p.gate + b * p.gate_bs + n), gt);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gt[e] * round_bf(v[e]);
+  }
+  u32x4 val = pack8(v);
+  if (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES) {
+    float fv[8], fr[8];
+    unpack8(val, fv);
+    unpack8(*reinterpret_cast<const u32x4*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + n), fr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+    val = pack8(fv);
+  }
+  *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + n) = val;
+}
+
 // ------------------------------------------------------------------------------------------------
+static int g_gemm_splitk = 1;     // 0 disables the split-K path (A/B knob)
+void set_gemm_splitk(int v) { g_gemm_splitk = v; }
 static int g_gemm_place = 2;      // request placement of the persistent kernel (bench knob, see gemm8pp_kernel)
 void set_gemm_place(int v) { g_gemm_place = v; }
 static int g_gemm_group_m = 4;  // row tiles per group of the tile order (L2 locality knob)
@@ -834,6 +923,7 @@ static GemmParams make_params(const GemmArgs& a) {
   p.cin = a.conv_cin; p.inH = a.conv_inH; p.inW = a.conv_inW; p.oH = a.conv_H; p.oW = a.conv_W;
   p.cstride = a.conv_stride; p.cup = a.conv_up_shift; p.cpad = a.conv_pad_lo; p.zero = (const bf16_t*)a.zero_page;
   p.a_scale = a.a_scale; p.as_bs = a.a_scale_bstride; p.w_scale = a.w_scale;
+  p.ws = nullptr; p.sk = 1;
   return p;
 }
 
@@ -872,7 +962,7 @@ static int launch_ablation(const GemmParams& p, hipStream_t st) {
 }
 
 template <int EPI>
-static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
+static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws_bytes, hipStream_t st) {
   if (variant >= 10) {  // tools/bench_kernels.py only: timing ablations with WRONG results by construction
     switch (variant - 10) {
       case 1: return launch_ablation<1>(p, st);
@@ -909,8 +999,35 @@ static int launch_variant(const GemmParams& p, int variant, hipStream_t st) {
     }
     const bool prof = prof_on(st);
     if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
-    if (g_gemm_place == 1) gemm8pp_kernel<EPI, 1><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
-    else gemm8pp_kernel<EPI, 2><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+    // Fewer tiles than CUs: split K so that (tile, slice) units fill the chip (variant 1 = auto only; the caller must
+    // have passed a workspace for the fp32 partials).  Slices keep an even number >= 8 of K-tiles.
+    const int T = p.batch * p.tm * p.tn, nt = p.K >> 6;
+    int sk = 1;
+    if (variant == 1 && g_gemm_splitk && ws && T < grid && p.N % 8 == 0) {
+      for (int c = 4; c >= 2; --c)
+        if (T * c <= grid && nt % (2 * c) == 0 && nt / c >= 8 && (int64_t)c * p.batch * p.M * p.N * 4 <= ws_bytes) { sk = c; break; }
+    }
+    if (sk > 1) {
+      static bool attr = false;
+      if (!attr) {
+        const void* fn = (const void*)gemm8pp_kernel<EPI_BIAS, 2, false, true>;
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, fn);
+        (void)hipGetLastError();
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess)
+          return fail("gemm: cannot raise dynamic LDS limit for the split-K kernel");
+        attr = true;
+      }
+      GemmParams ps = p;
+      ps.ws = (float*)ws; ps.sk = sk;
+      gemm8pp_kernel<EPI_BIAS, 2, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(ps);
+      const int64_t chunks = (int64_t)p.batch * p.M * (p.N >> 3);
+      splitk_reduce_kernel<EPI><<<(unsigned)((chunks + 255) / 256), 256, 0, st>>>(ps);
+    } else if (g_gemm_place == 1) {
+      gemm8pp_kernel<EPI, 1><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+    } else {
+      gemm8pp_kernel<EPI, 2><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+    }
     if (prof) prof_end(0, st);
     return check_launch("gemm_bf16");
   }
@@ -951,10 +1068,10 @@ int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
   if (a.epilogue == EPI_BIAS_RES && !a.res) return fail("gemm: res pointer required");
   const GemmParams p = make_params(a);
   switch (a.epilogue) {
-    case EPI_BIAS: return launch_variant<EPI_BIAS>(p, variant, st);
-    case EPI_BIAS_GELU: return launch_variant<EPI_BIAS_GELU>(p, variant, st);
-    case EPI_BIAS_GATE_RES: return launch_variant<EPI_BIAS_GATE_RES>(p, variant, st);
-    case EPI_BIAS_RES: return launch_variant<EPI_BIAS_RES>(p, variant, st);
+    case EPI_BIAS: return launch_variant<EPI_BIAS>(p, variant, a.workspace, a.workspace_bytes, st);
+    case EPI_BIAS_GELU: return launch_variant<EPI_BIAS_GELU>(p, variant, a.workspace, a.workspace_bytes, st);
+    case EPI_BIAS_GATE_RES: return launch_variant<EPI_BIAS_GATE_RES>(p, variant, a.workspace, a.workspace_bytes, st);
+    case EPI_BIAS_RES: return launch_variant<EPI_BIAS_RES>(p, variant, a.workspace, a.workspace_bytes, st);
   }
   return fail("gemm: unknown epilogue %d", a.epilogue);
 }

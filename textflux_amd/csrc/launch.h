@@ -49,9 +49,12 @@ struct GemmArgs {
   // fp8 (e4m3) operands, gemm_fp8 only: A and W hold one byte per element, C = (A.W^T) * a_scale[b][m] * w_scale[n] + bias
   const float* a_scale = nullptr; int64_t a_scale_bstride = 0;   // per activation row
   const float* w_scale = nullptr;                                 // per output channel
+  // optional scratch for split-K (fp32 partials); without it few-tile GEMMs run unsplit
+  void* workspace = nullptr; int64_t workspace_bytes = 0;
 };
 void set_gemm_group_m(int gm);
 void set_gemm_place(int v);
+void set_gemm_splitk(int v);
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
 int gemm_fp8(const GemmArgs& a, hipStream_t st);             // persistent MFMA kernel on e4m3 operands (K % 256 == 0)

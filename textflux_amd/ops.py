@@ -41,9 +41,10 @@ def _rows_view(t: torch.Tensor):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
          epilogue: int = EPI_BIAS, gelu_from_col: int = 0, gate: Optional[torch.Tensor] = None,
-         res: Optional[torch.Tensor] = None, variant: int = -1) -> torch.Tensor:
-    """out[b] = epi(a[b] @ w.T + bias).  a: [M,K] or [B,M,K] (row/batch strided views allowed), w: [N,K]."""
-    _chk_dev(a, w, bias, out, gate, res)
+         res: Optional[torch.Tensor] = None, variant: int = -1, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = epi(a[b] @ w.T + bias).  a: [M,K] or [B,M,K] (row/batch strided views allowed), w: [N,K].
+    workspace: optional device scratch tensor; lets the auto path split K when the GEMM has fewer tiles than CUs."""
+    _chk_dev(a, w, bias, out, gate, res, workspace)
     assert a.dtype == BF16 and w.dtype == BF16 and w.dim() == 2 and w.stride(1) == 1
     ap, lda, abs_, M, batch = _rows_view(a)
     N, K = w.shape
@@ -66,6 +67,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
             g.gate_bstride = gate.stride(0) if gate.dim() == 2 else 0
         rp, ldr, rbs, _, _ = _rows_view(res)
         g.res, g.ldr, g.r_bstride = rp, ldr, rbs
+    if workspace is not None:
+        g.workspace, g.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     L.check(L.lib().tfx_gemm_bf16(C.byref(g), variant, _stream()), "gemm")
     return out
 
