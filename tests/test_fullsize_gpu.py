@@ -108,7 +108,9 @@ def test_full_model_batch_consistency_and_determinism():
     from textflux_amd import ops
     ops.set_option("gemm_splitk", 0)
     try:
-        o4 = m(hidden_states=hs, encoder_hidden_states=pe, pooled_projections=pooled, timestep=t1, guidance=g1, **kw)[0]
+        n1 = m(hidden_states=hs, encoder_hidden_states=pe, pooled_projections=pooled, timestep=t1, guidance=g1, **kw)[0]
+        n2 = m(hidden_states=hs.repeat(2, 1, 1), encoder_hidden_states=pe.repeat(2, 1, 1),
+               pooled_projections=pooled.repeat(2, 1), timestep=t1.repeat(2), guidance=g1.repeat(2), **kw)[0]
     finally:
         ops.set_option("gemm_splitk", 1)
-    assert torch.equal(o4[0], o2[0])
+    assert torch.equal(n2[0], n2[1]) and torch.equal(n2[0], n1[0])

@@ -382,12 +382,10 @@ class DitSession:
         d.first_block, d.last_block, d.flags = 0, -1, 0
         if self.fp8:
             d.q8, d.q8_scale = self.q8.data_ptr(), self.q8_scale.data_ptr()
-        # scratch for the split-K path of few-tile GEMMs (small batch x resolution): fp32 partials, <= 4 slices of the
-        # widest few-tile output; only problem sizes whose GEMMs can have < 256 tiles get one
-        self.gemm_ws = None
-        if B * ((N + 255) // 256) * 12 < 256:
-            self.gemm_ws = torch.empty(4 * B * N * 4 * D, dtype=torch.float32, device=dev)
-            d.gemm_workspace, d.gemm_workspace_bytes = self.gemm_ws.data_ptr(), self.gemm_ws.numel() * 4
+        # scratch for the split-K path of few-tile GEMMs (text stream, small batch x resolution): fp32 partials of at most
+        # slices x tiles <= 256 tiles of 256 x 256, i.e. 64 MiB whatever the problem size
+        self.gemm_ws = torch.empty(256 * 256 * 256, dtype=torch.float32, device=dev)
+        d.gemm_workspace, d.gemm_workspace_bytes = self.gemm_ws.data_ptr(), self.gemm_ws.numel() * 4
         self.graphs = {}
         self._gb = None
 
