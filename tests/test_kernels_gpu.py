@@ -182,8 +182,10 @@ def test_gemm_fp8_matches_dequantised_matmul(ops, B, M, N, K):
     cases = [(ops.EPI_BIAS, {}, lin), (ops.EPI_BIAS_GELU, dict(gelu_from_col=gf), gelu_ref),
              (ops.EPI_BIAS_GATE_RES, dict(gate=gate, res=res), res.float() + (gate.float()[:, None] * lin.to(BF).float()).to(BF).float()),
              (ops.EPI_BIAS_RES, dict(res=res), res.float() + lin.to(BF).float())]
+    ws = torch.empty(4 * B * M * N, dtype=torch.float32, device="cuda")   # few-tile shapes then also run split-K
     for epi, kw, ref in cases:
         close(ops.gemm_fp8(aq, sa, wq, sw, bias, epilogue=epi, **kw), ref.to(BF))
+        close(ops.gemm_fp8(aq, sa, wq, sw, bias, epilogue=epi, workspace=ws, **kw), ref.to(BF))
 
 
 def test_gemm_fp8_rejects_unsupported_k(ops):

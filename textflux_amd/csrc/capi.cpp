@@ -189,6 +189,7 @@ int tfx_gemm_fp8(const tfx_gemm_args* g, const float* a_scale, int64_t a_scale_b
   a.gate = g->gate; a.gate_bstride = g->gate_bstride;
   a.res = g->res; a.ldr = g->ldr; a.r_bstride = g->r_bstride;
   a.a_scale = a_scale; a.a_scale_bstride = a_scale_bstride; a.w_scale = w_scale;
+  a.workspace = g->workspace; a.workspace_bytes = g->workspace_bytes;
   if (!a.A || !a.W || !a.C) return fail("tfx_gemm_fp8: null matrix pointer");
   return gemm_fp8(a, S(stream));
 }

@@ -850,7 +850,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 }
 
 // Second pass of the split-K path: C = epi(sum_s P[s] + bias), 8 columns per thread, slices summed in order.
-template <int EPI>
+template <int EPI, bool FP8 = false>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   const int64_t chunks_per_row = p.N >> 3;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -872,6 +872,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + s * slice_stride + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
+  }
+  if (FP8) {  // dequantise: row scale, then channel scale (the order of the unsplit epilogue)
+    const float sa = p.a_scale[b * p.as_bs + m];
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.w_scale + n), w1 = *reinterpret_cast<const f32x4*>(p.w_scale + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = (v[e] * sa) * w0[e]; v[4 + e] = (v[4 + e] * sa) * w1[e]; }
   }
   if (p.bias) {
     float bs[8];
@@ -1080,23 +1086,39 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st) { return gemm_bf16_variant(a, f
 
 // ---- fp8 (e4m3 x e4m3 -> fp32) path: the persistent kernel only
 template <int EPI>
-static int launch_fp8(const GemmParams& p, hipStream_t st) {
+static int launch_fp8(const GemmParams& p, void* ws, int64_t ws_bytes, hipStream_t st) {
   static int grid = 0;
   if (!grid) {
     int dev = 0, cus = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-    const void* fn = (const void*)gemm8pp_kernel<EPI, 2, true>;
-    hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, fn);
-    (void)hipGetLastError();
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL);
-    if (e != hipSuccess) return fail("gemm_fp8: cannot raise dynamic LDS limit to %d bytes: %s", PP_LDS_TOTAL, hipGetErrorString(e));
+    const void* fns[2] = {(const void*)gemm8pp_kernel<EPI, 2, true>, (const void*)gemm8pp_kernel<EPI_BIAS, 2, true, true>};
+    for (const void* fn : fns) {
+      hipFuncAttributes fa;
+      (void)hipFuncGetAttributes(&fa, fn);
+      (void)hipGetLastError();
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL);
+      if (e != hipSuccess) return fail("gemm_fp8: cannot raise dynamic LDS limit to %d bytes: %s", PP_LDS_TOTAL, hipGetErrorString(e));
+    }
     grid = cus & ~7;
   }
   const bool prof = prof_on(st);
   if (prof) prof_begin(2, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
-  gemm8pp_kernel<EPI, 2, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+  const int T = p.batch * p.tm * p.tn, nt = p.K >> 7;   // 128-byte K-tiles of e4m3
+  int sk = 1;
+  if (g_gemm_splitk && ws && T < grid) {
+    for (int c = 4; c >= 2; --c)
+      if (T * c <= grid && nt % (2 * c) == 0 && nt / c >= 8 && (int64_t)c * p.batch * p.M * p.N * 4 <= ws_bytes) { sk = c; break; }
+  }
+  if (sk > 1) {
+    GemmParams ps = p;
+    ps.ws = (float*)ws; ps.sk = sk;
+    gemm8pp_kernel<EPI_BIAS, 2, true, true><<<grid, 512, PP_LDS_TOTAL, st>>>(ps);
+    const int64_t chunks = (int64_t)p.batch * p.M * (p.N >> 3);
+    splitk_reduce_kernel<EPI, true><<<(unsigned)((chunks + 255) / 256), 256, 0, st>>>(ps);
+  } else {
+    gemm8pp_kernel<EPI, 2, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+  }
   if (prof) prof_end(2, st);
   return check_launch("gemm_fp8");
 }
@@ -1120,10 +1142,10 @@ int gemm_fp8(const GemmArgs& a, hipStream_t st) {
   if (a.epilogue == EPI_BIAS_GELU && a.gelu_from_col % 256) return fail("gemm_fp8: gelu_from_col must be a multiple of 256");
   const GemmParams p = make_params(a);
   switch (a.epilogue) {
-    case EPI_BIAS: return launch_fp8<EPI_BIAS>(p, st);
-    case EPI_BIAS_GELU: return launch_fp8<EPI_BIAS_GELU>(p, st);
-    case EPI_BIAS_GATE_RES: return launch_fp8<EPI_BIAS_GATE_RES>(p, st);
-    case EPI_BIAS_RES: return launch_fp8<EPI_BIAS_RES>(p, st);
+    case EPI_BIAS: return launch_fp8<EPI_BIAS>(p, a.workspace, a.workspace_bytes, st);
+    case EPI_BIAS_GELU: return launch_fp8<EPI_BIAS_GELU>(p, a.workspace, a.workspace_bytes, st);
+    case EPI_BIAS_GATE_RES: return launch_fp8<EPI_BIAS_GATE_RES>(p, a.workspace, a.workspace_bytes, st);
+    case EPI_BIAS_RES: return launch_fp8<EPI_BIAS_RES>(p, a.workspace, a.workspace_bytes, st);
   }
   return fail("gemm_fp8: unknown epilogue %d", a.epilogue);
 }

@@ -93,9 +93,11 @@ def quantize_rows_fp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale
 
 def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor,
              bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS,
-             gelu_from_col: int = 0, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[b] = epi((a[b] @ w.T) * a_scale[b][:, None] * w_scale[None, :] + bias) on e4m3 operands (uint8 storage), bf16 out."""
-    _chk_dev(a, a_scale, w, w_scale, bias, out, gate, res)
+             gelu_from_col: int = 0, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+             workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = epi((a[b] @ w.T) * a_scale[b][:, None] * w_scale[None, :] + bias) on e4m3 operands (uint8 storage), bf16 out.
+    workspace: optional scratch, enables split-K for few-tile shapes (see gemm)."""
+    _chk_dev(a, a_scale, w, w_scale, bias, out, gate, res, workspace)
     assert a.dtype == torch.uint8 and w.dtype == torch.uint8 and w.dim() == 2 and w.stride(1) == 1
     assert a_scale.dtype == torch.float32 and w_scale.dtype == torch.float32 and a_scale.is_contiguous() and w_scale.is_contiguous()
     ap, lda, abs_, M, batch = _rows_view(a)
@@ -119,6 +121,8 @@ def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: t
             g.gate_bstride = gate.stride(0) if gate.dim() == 2 else 0
         rp, ldr, rbs, _, _ = _rows_view(res)
         g.res, g.ldr, g.r_bstride = rp, ldr, rbs
+    if workspace is not None:
+        g.workspace, g.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     L.check(L.lib().tfx_gemm_fp8(C.byref(g), a_scale.data_ptr(), M if batch > 1 else 0, w_scale.data_ptr(), _stream()), "gemm_fp8")
     return out
 
