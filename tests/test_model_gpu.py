@@ -129,3 +129,47 @@ def test_fp8_forward_matches_fp8_oracle(golden):
     assert cost <= 0.15
     m.enable_fp8(False)
     assert torch.equal(m.forward(**kw)[0], out_bf16)
+
+
+def test_fp8_full_width_blocks_match_fp8_oracle(golden):
+    """One double + one single block at the real width (D = 3072: the fp8 GEMMs at K = 3072 / 12288 / 15360, split-K on the
+    few-tile ones) against the oracle's own blocks under fp8_block_linears (bf16), same inputs as the bf16 full-width test.
+    Quantisation is discontinuous: a one-ulp bf16 difference upstream (LayerNorm summation order, say) moves a row's scale
+    or flips e4m3 codes (12 % steps), so engine and oracle decorrelate at the level of the fp8 noise itself.  Bound: the
+    engine is closer to the fp8 oracle than fp8 is to the reference's bf16 blocks (the cost of the scheme, also bounded),
+    and within 3e-2 relative MAE."""
+    g = golden("g2_blocks")
+    heads, S, T, seed, h2, w2 = [int(v) for v in g["d3072.meta"]]
+    D = heads * 128
+    cfg = fo.FluxConfig(num_layers=1, num_single_layers=1, num_attention_heads=heads, joint_attention_dim=64,
+                        pooled_projection_dim=32)
+    sd = {k: v.to(BF) for k, v in fo.seeded_state_dict(cfg, seed).items()}
+    m = build(cfg, seed).enable_fp8()
+
+    def rnd(shape, s):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(s))
+
+    hidden, enc, temb = rnd((2, S, D), seed + 1).to(BF), rnd((2, T, D), seed + 2).to(BF), rnd((2, D), seed + 3).to(BF)
+    ses = m.session(2, S, T)
+    ids_img, ids_txt = po.latent_image_ids(h2, w2), torch.zeros(T, 3)
+    ses.set_conditioning(torch.zeros(2, T, 64, dtype=BF, device="cuda"), ids_txt, ids_img)
+    mod = m.modulation(temb.cuda())
+    cos, sin = fo.flux_pos_embed(torch.cat([ids_txt, ids_img]))
+    with fo.fp8_block_linears():
+        r_enc, r_hid = fo.double_block(sd, "transformer_blocks.0", heads, hidden, enc, temb, cos, sin)
+        r_sgl = fo.single_block(sd, "single_transformer_blocks.0", heads, torch.cat([enc, hidden], 1), temb, cos, sin)
+    ses.hid[:, :T].copy_(enc)
+    ses.hid[:, T:].copy_(hidden)
+    ses.run(mod, first_block=0, last_block=1, flags=3)
+    got = ses.hid.clone()
+    e_enc, e_hid = rel_mae(got[:, :T], r_enc), rel_mae(got[:, T:], r_hid)
+    c_hid = rel_mae(got[:, T:], g["d3072.double.hidden_out"])
+    ses.hid[:, :T].copy_(enc)
+    ses.hid[:, T:].copy_(hidden)
+    ses.run(mod, first_block=1, last_block=2, flags=3)
+    e_sgl, c_sgl = rel_mae(ses.hid, r_sgl), rel_mae(ses.hid, g["d3072.single.out"])
+    print(f"fp8 full-width rel MAE vs fp8 oracle: double enc {e_enc:.2e} hidden {e_hid:.2e}; single {e_sgl:.2e}; "
+          f"vs the reference's bf16 blocks: double {c_hid:.2e} single {c_sgl:.2e}")
+    assert max(e_enc, e_hid, e_sgl) < 3e-2
+    assert e_hid < c_hid and e_sgl < c_sgl
+    assert max(c_hid, c_sgl) < 6e-2
