@@ -11,6 +11,8 @@
 // K and V tiles are staged global -> registers -> LDS (issue early / write late), double buffered, one barrier
 // per tile.  K rows (256 B) have their 16-byte chunks XOR-swizzled with (key & 15); V rows have their 64-byte
 // segments XOR-swizzled with (key & 3); both make the respective LDS reads bank-conflict free.
+#include <type_traits>
+
 #include "common.h"
 #include "launch.h"
 
@@ -369,8 +371,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_mx_kernel(const bf16_t* Q, co
   if (nkv > 1) load_tile(1);
   __syncthreads();
 
-  for (int j = 0; j < nkv; ++j) {
-    const int buf = j & 1;
+  // one 64-key tile out of LDS buffer BUF (a compile-time constant: the tile loop is unrolled by two so that the K / V
+  // fragment addresses are a per-lane base plus an immediate instead of 14 VALU adds per tile)
+  auto tile = [&](int j, auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
     if (j + 1 < nkv) {
       write_tile(buf ^ 1);
       if (j + 2 < nkv) load_tile(j + 2);
@@ -452,6 +456,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_mx_kernel(const bf16_t* Q, co
       ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vone, pf[ks], ol, 0, 0, 0);
     }
     __syncthreads();
+  };
+  for (int j = 0; j < nkv; j += 2) {
+    tile(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nkv) tile(j + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- finish: every row of the ones-block holds the full row sum (all 64 keys of every tile)
