@@ -322,14 +322,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_mx_kernel(const bf16_t* Q, co
 
   const int nkv = (N + KVBLK - 1) / KVBLK;
   u32x4 kreg[CPT], vreg[CPT];
-  auto load_tile = [&](int j) {
+  // staging requests: full tiles advance a per-thread row pointer (one 64-bit add per request); only the last, possibly
+  // ragged tile recomputes clamped addresses
+  const bf16_t* kp[CPT];
+  const bf16_t* vp[CPT];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-      const int c = tid + i * NT;
-      int key = j * KVBLK + (c >> 4);
-      if (key > N - 1) key = N - 1;
-      kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (int64_t)key * ldk + (c & 15) * 8);
-      vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (int64_t)key * ldv + (c & 15) * 8);
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + i * NT;
+    kp[i] = Kb + (int64_t)(c >> 4) * ldk + (c & 15) * 8;
+    vp[i] = Vb + (int64_t)(c >> 4) * ldv + (c & 15) * 8;
+  }
+  auto load_tile = [&](int j) {
+    if (j == nkv - 1) {
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int c = tid + i * NT;
+        int key = j * KVBLK + (c >> 4);
+        if (key > N - 1) key = N - 1;
+        kreg[i] = *reinterpret_cast<const u32x4*>(Kb + (int64_t)key * ldk + (c & 15) * 8);
+        vreg[i] = *reinterpret_cast<const u32x4*>(Vb + (int64_t)key * ldv + (c & 15) * 8);
+      }
+    } else {
+      const int64_t ko = (int64_t)j * KVBLK * ldk, vo = (int64_t)j * KVBLK * ldv;
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        kreg[i] = *reinterpret_cast<const u32x4*>(kp[i] + ko);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vp[i] + vo);
+      }
     }
   };
   auto write_tile = [&](int buf) {
