@@ -66,6 +66,12 @@ int tfx_gemm_fp8(const tfx_gemm_args* args, const float* a_scale, int64_t a_scal
                  tfx_stream stream);
 int tfx_quantize_rows_fp8(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride,
                           float* scale, int64_t s_bstride, int32_t rows, int32_t batch, int32_t K, tfx_stream stream);
+/* tfx_ln_modulate whose result is written as the e4m3 quantisation of the bf16 row (== tfx_ln_modulate followed by
+ * tfx_quantize_rows_fp8, bit for bit): q8 [B][rows, D] bytes with row stride ldq / batch stride q_bstride (bytes),
+ * q8_scale[b * s_bstride + row]. */
+int tfx_ln_modulate_fp8(const void* x, int64_t ldx, int64_t x_bstride, void* q8, int64_t ldq, int64_t q_bstride,
+                        float* q8_scale, int64_t s_bstride, const void* shift, const void* scale, int64_t mod_bstride,
+                        int32_t rows_per_batch, int32_t batch, int32_t D, float eps, tfx_stream stream);
 
 /* ---- LayerNorm(no affine, eps) * (1 + scale[b]) + shift[b]   (AdaLayerNormZero / ZeroSingle / Continuous,
  *      D/models/normalization.py:170, 202, 365; norm2 + modulation, transformer_flux.py:820-821, 833-834).

@@ -188,6 +188,19 @@ def test_gemm_fp8_matches_dequantised_matmul(ops, B, M, N, K):
         close(ops.gemm_fp8(aq, sa, wq, sw, bias, epilogue=epi, workspace=ws, **kw), ref.to(BF))
 
 
+@pytest.mark.parametrize("D", [256, 3072])
+def test_ln_modulate_fp8_is_ln_modulate_then_quantize(ops, D):
+    """The fp8 mode's fused LayerNorm -> e4m3 operand: bit-identical to the two separate kernels."""
+    B, R = 2, 77
+    x, shift, scale = rnd((B, R, D), 61).to(BF).cuda(), rnd((B, D), 62, 0.5).to(BF).cuda(), rnd((B, D), 63, 0.5).to(BF).cuda()
+    x[1, 5] = 0
+    shift[1].zero_()                     # -> an all-zero output row in batch 1: scale 1, zero codes
+    q_ref, s_ref = ops.quantize_rows_fp8(ops.ln_modulate(x, shift, scale))
+    q, s = ops.ln_modulate_fp8(x, shift, scale)
+    assert torch.equal(s, s_ref) and torch.equal(q, q_ref)
+    assert s[1, 5].item() == 1.0 and q[1, 5].abs().max().item() == 0
+
+
 def test_gemm_fp8_rejects_unsupported_k(ops):
     aq = torch.zeros(64, 384, dtype=torch.uint8, device="cuda")
     wq = torch.zeros(64, 384, dtype=torch.uint8, device="cuda")

@@ -78,6 +78,8 @@ SIGNATURES = {
     "tfx_query_arch": (c_int, [c_char_p, c_int]),
     "tfx_gemm_bf16": (c_int, [C.POINTER(GemmArgs), c_int, c_void_p]),
     "tfx_gemm_fp8": (c_int, [C.POINTER(GemmArgs), c_void_p, c_int64, c_void_p, c_void_p]),
+    "tfx_ln_modulate_fp8": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "tfx_quantize_rows_fp8": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int32,
                                       c_int32, c_void_p]),
     "tfx_ln_modulate": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,

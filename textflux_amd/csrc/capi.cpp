@@ -34,6 +34,15 @@ struct Gemm {
   }
   Gemm& scratch(void* ws, int64_t bytes) { a.workspace = ws; a.workspace_bytes = bytes; return *this; }
   int run(hipStream_t st) const { return gemm_bf16(a, st); }
+  bool fp8_ready() const { return lin->w8 && lin->w8_scale && a.K % 256 == 0; }
+  // fp8 linear whose activation rows were already quantised by the producer (ln_modulate_fp8)
+  int run_pre(hipStream_t st, const void* q, int64_t qld, int64_t qbs, const float* qs, int64_t qs_bs) const {
+    GemmArgs f = a;
+    f.A = q; f.lda = qld; f.a_bstride = qbs;
+    f.W = lin->w8;
+    f.a_scale = qs; f.a_scale_bstride = qs_bs; f.w_scale = lin->w8_scale;
+    return gemm_fp8(f, st);
+  }
   // fp8 linears (desc.flags bit 2): quantise the activation rows into the q8 workspace, then the e4m3 GEMM
   int run(hipStream_t st, void* q8, float* q8_scale) const {
     if (!q8 || !lin->w8 || !lin->w8_scale || a.K % 256) return gemm_bf16(a, st);
@@ -93,16 +102,29 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
     return joint_attention(a, st);
   };
 
+  // LayerNorm + modulation of rows [row0, row0 + rows) of every batch's joint stream, feeding ONE Linear.  bf16 mode:
+  // xn (bf16) then the GEMM.  fp8 mode: the norm writes the e4m3 rows + scales straight into the q8 workspace
+  // (layout [B][N][D] bytes / [B][N]) and the GEMM consumes them -- no bf16 round trip, no separate quantisation pass.
+  auto norm_gemm = [&](const uint16_t* src, int row0, int rows, const uint16_t* shift, const uint16_t* scale, Gemm gm) -> int {
+    gm.scratch(d.gemm_workspace, d.gemm_workspace_bytes);
+    if (q8 && gm.fp8_ready()) {
+      uint8_t* q = (uint8_t*)q8 + (int64_t)row0 * D;
+      float* qs = q8s + row0;
+      TRY(ln_modulate_fp8(src, q, qs, shift, scale, mbs, rows, B, D, D, hid_bs, D, hid_bs, N, eps, st));
+      return gm.run_pre(st, q, D, hid_bs, qs, N);
+    }
+    TRY(ln_modulate(src, xn + (int64_t)row0 * D, shift, scale, mbs, rows, B, D, D, hid_bs, D, hid_bs, eps, st));
+    return gm.run(st, q8, q8s);
+  };
+
   for (int blk = first; blk < last; ++blk) {
     if (blk < d.n_double) {
       // ---- FluxTransformerBlock.forward (transformer_flux.py:794-841)
       const tfx_double_block& w = d.dbl[blk];
       const uint16_t* mi = mod + (int64_t)blk * 12 * D;  // img: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp
       const uint16_t* mt = mi + 6 * D;                   // txt: same six
-      TRY(ln_modulate(hid_img, xn_img, mi, mi + D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
-      if (T > 0) TRY(ln_modulate(hid, xn, mt, mt + D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
-      TRY(Gemm(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
-      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.qkv_txt, D, y, D7, y_bs, T, 3 * D, D, B).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
+      TRY(norm_gemm(hid_img, T, Sn, mi, mi + D, Gemm(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B)));
+      if (T > 0) TRY(norm_gemm(hid, 0, T, mt, mt + D, Gemm(xn, D, hid_bs, w.qkv_txt, D, y, D7, y_bs, T, 3 * D, D, B)));
       TRY(attention(T, w.norm_q, w.norm_k, w.norm_added_q, w.norm_added_k));
       // hidden += gate_msa * to_out(attn)   (:817-818, 830-831)
       TRY(Gemm(y_img + 2 * D, D7, y_bs, w.out_img, D, hid_img, D, hid_bs, Sn, D, D, B)
@@ -111,10 +133,10 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
         TRY(Gemm(y + 2 * D, D7, y_bs, w.out_txt, D, hid, D, hid_bs, T, D, D, B)
                 .gate_res(mt + 2 * D, mbs, hid, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
       // MLP: norm2 * (1 + scale_mlp) + shift_mlp -> ff -> gated residual (:820-826, 833-837)
-      TRY(ln_modulate(hid_img, xn_img, mi + 3 * D, mi + 4 * D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
-      if (T > 0) TRY(ln_modulate(hid, xn, mt + 3 * D, mt + 4 * D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
-      TRY(Gemm(xn_img, D, hid_bs, w.ff1_img, D, y_img + 3 * D, D7, y_bs, Sn, 4 * D, D, B).gelu(0).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
-      if (T > 0) TRY(Gemm(xn, D, hid_bs, w.ff1_txt, D, y + 3 * D, D7, y_bs, T, 4 * D, D, B).gelu(0).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
+      TRY(norm_gemm(hid_img, T, Sn, mi + 3 * D, mi + 4 * D,
+                    Gemm(xn_img, D, hid_bs, w.ff1_img, D, y_img + 3 * D, D7, y_bs, Sn, 4 * D, D, B).gelu(0)));
+      if (T > 0)
+        TRY(norm_gemm(hid, 0, T, mt + 3 * D, mt + 4 * D, Gemm(xn, D, hid_bs, w.ff1_txt, D, y + 3 * D, D7, y_bs, T, 4 * D, D, B).gelu(0)));
       TRY(Gemm(y_img + 3 * D, D7, y_bs, w.ff2_img, 4 * D, hid_img, D, hid_bs, Sn, D, 4 * D, B)
               .gate_res(mi + 5 * D, mbs, hid_img, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
       if (T > 0)
@@ -125,8 +147,7 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
       const int j = blk - d.n_double;
       const tfx_single_block& w = d.sgl[j];
       const uint16_t* ms = mod + (int64_t)d.n_double * 12 * D + (int64_t)j * 3 * D;  // shift scale gate
-      TRY(ln_modulate(hid, xn, ms, ms + D, mbs, N, B, D, D, hid_bs, D, hid_bs, eps, st));
-      TRY(Gemm(xn, D, hid_bs, w.qkv_mlp, D, y, D7, y_bs, N, 7 * D, D, B).gelu(3 * D).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
+      TRY(norm_gemm(hid, 0, N, ms, ms + D, Gemm(xn, D, hid_bs, w.qkv_mlp, D, y, D7, y_bs, N, 7 * D, D, B).gelu(3 * D)));
       TRY(attention(0, w.norm_q, w.norm_k, w.norm_q, w.norm_k));
       TRY(Gemm(y + 2 * D, D7, y_bs, w.proj_out, 5 * D, hid, D, hid_bs, N, D, 5 * D, B)
               .gate_res(ms + 2 * D, mbs, hid, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
@@ -198,6 +219,14 @@ int tfx_quantize_rows_fp8(const void* x, int64_t ldx, int64_t x_bstride, void* o
                           float* scale, int64_t s_bstride, int32_t rows, int32_t batch, int32_t K, tfx_stream stream) {
   if (!x || !out || !scale) return fail("tfx_quantize_rows_fp8: null pointer");
   return quantize_rows_fp8(x, ldx, x_bstride, out, ldo, o_bstride, scale, s_bstride, rows, batch, K, S(stream));
+}
+
+int tfx_ln_modulate_fp8(const void* x, int64_t ldx, int64_t x_bstride, void* q8, int64_t ldq, int64_t q_bstride,
+                        float* q8_scale, int64_t s_bstride, const void* shift, const void* scale, int64_t mod_bstride,
+                        int32_t rows_per_batch, int32_t batch, int32_t D, float eps, tfx_stream stream) {
+  if (!x || !q8 || !q8_scale || !shift || !scale) return fail("tfx_ln_modulate_fp8: null pointer");
+  return ln_modulate_fp8(x, q8, q8_scale, shift, scale, mod_bstride, rows_per_batch, batch, D, ldx, x_bstride, ldq,
+                         q_bstride, s_bstride, eps, S(stream));
 }
 
 int tfx_ln_modulate(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride,

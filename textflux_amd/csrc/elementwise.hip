@@ -12,12 +12,16 @@ namespace tfx {
 // AdaLayerNormZeroSingle / AdaLayerNormContinuous, D/models/normalization.py:170, :202, :365 and the
 // norm2 path of FluxTransformerBlock, transformer_flux.py:820-821).
 // One wave per token row, row held in registers (<= NCH*8*64 elements), two-pass statistics.
-template <int NCH>
+// F8: instead of the bf16 row, write its per-row absmax e4m3 quantisation (quant_rows_fp8_kernel of the SAME bf16 values,
+// bit for bit) to q8 / q8_scale -- the fp8 mode's fused LayerNorm -> GEMM operand path.
+template <int NCH, bool F8 = false>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ shift,
                                                           const bf16_t* __restrict__ scale, int64_t mod_bstride,
                                                           int rows_per_batch, int64_t rows, int D, int64_t ldx,
-                                                          int64_t x_bstride, int64_t ldo, int64_t o_bstride, float eps) {
+                                                          int64_t x_bstride, int64_t ldo, int64_t o_bstride, float eps,
+                                                          uint8_t* __restrict__ q8 = nullptr, float* __restrict__ q8_scale = nullptr,
+                                                          int64_t s_bstride = 0) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -69,7 +73,41 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restri
         const float t = round_bf(1.0f + s8[i]);               // (1 + scale), bf16
         o8[i] = round_bf(xn * t) + h8[i];                     // product rounded, sum rounded by pack8
       }
-      *reinterpret_cast<u32x4*>(orow + ch * 8) = pack8(o8);
+      if (F8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[c][i] = round_bf(o8[i]);   // the bf16 row the unfused path would have stored
+      } else {
+        *reinterpret_cast<u32x4*>(orow + ch * 8) = pack8(o8);
+      }
+    }
+  }
+  if (F8) {
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (lane + c * 64 < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[c][i]));
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float qs = amax > 0.f ? __fdiv_rn(amax, 448.0f) : 1.0f;
+    if (lane == 0) q8_scale[b * s_bstride + r] = qs;
+    uint8_t* qrow = q8 + b * o_bstride + r * ldo;   // ldo / o_bstride count bytes of the e4m3 rows here
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + c * 64;
+      if (ch < nchunk) {
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = fminf(fmaxf(__fdiv_rn(v[c][i], qs), -448.f), 448.f);
+        uint32_t w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+        *reinterpret_cast<u32x2*>(qrow + ch * 8) = u32x2{w0, w1};
+      }
     }
   }
 }
@@ -330,6 +368,19 @@ int ln_modulate(const void* x, void* out, const void* shift, const void* scale, 
       (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)shift, (const bf16_t*)scale, mod_bstride, rows_per_batch, rows, D,
       ldx, x_bstride, ldo, o_bstride, eps);
   return check_launch("ln_modulate");
+}
+
+int ln_modulate_fp8(const void* x, void* q8, float* q8_scale, const void* shift, const void* scale, int64_t mod_bstride,
+                    int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldq, int64_t q_bstride,
+                    int64_t s_bstride, float eps, hipStream_t st) {
+  if (D % 8 || D > 6 * 512) return fail("ln_modulate_fp8: D must be a multiple of 8 and <= 3072");
+  if (ldq % 8 || q_bstride % 8 || (uintptr_t)q8 % 8) return fail("ln_modulate_fp8: e4m3 rows must be 8-byte aligned");
+  const int64_t rows = (int64_t)rows_per_batch * batch;
+  if (rows == 0) return 0;
+  ln_modulate_kernel<6, true><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(
+      (const bf16_t*)x, nullptr, (const bf16_t*)shift, (const bf16_t*)scale, mod_bstride, rows_per_batch, rows, D, ldx,
+      x_bstride, ldq, q_bstride, eps, (uint8_t*)q8, q8_scale, s_bstride);
+  return check_launch("ln_modulate_fp8");
 }
 
 int rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int q_off, int k_off, int H, int Ntok, int T, int B,

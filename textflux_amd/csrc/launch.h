@@ -59,6 +59,11 @@ int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast 
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
 int gemm_fp8(const GemmArgs& a, hipStream_t st);             // persistent MFMA kernel on e4m3 operands (K % 256 == 0)
 // per-row absmax quantisation bf16 -> e4m3: out = x / scale, scale = absmax / 448 (1 for an all-zero row)
+// LayerNorm + modulation whose output is written as the e4m3 quantisation of the bf16 row (fp8 mode; == ln_modulate followed
+// by quantize_rows_fp8, bit for bit)
+int ln_modulate_fp8(const void* x, void* q8, float* q8_scale, const void* shift, const void* scale, int64_t mod_bstride,
+                    int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldq, int64_t q_bstride,
+                    int64_t s_bstride, float eps, hipStream_t st);
 int quantize_rows_fp8(const void* x, int64_t ldx, int64_t x_bstride, void* out, int64_t ldo, int64_t o_bstride, float* scale,
                       int64_t s_bstride, int rows, int batch, int K, hipStream_t st);
 

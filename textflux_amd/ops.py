@@ -142,6 +142,20 @@ def ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: 
     return out
 
 
+def ln_modulate_fp8(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float = 1e-6):
+    """ln_modulate followed by quantize_rows_fp8 in one pass: returns (q uint8 [B,R,D], scale f32 [B,R])."""
+    _chk_dev(x, shift, scale)
+    assert x.dim() == 3 and x.dtype == BF16
+    xp, ldx, xbs, R, B = _rows_view(x)
+    D = x.shape[-1]
+    q = torch.empty(B, R, D, dtype=torch.uint8, device=x.device)
+    qs = torch.empty(B, R, dtype=torch.float32, device=x.device)
+    assert shift.stride(-1) == 1 and scale.stride(-1) == 1 and shift.stride(0) == scale.stride(0)
+    L.check(L.lib().tfx_ln_modulate_fp8(xp, ldx, xbs, q.data_ptr(), D, R * D, qs.data_ptr(), R, shift.data_ptr(),
+                                        scale.data_ptr(), shift.stride(0), R, B, D, eps, _stream()), "ln_modulate_fp8")
+    return q, qs
+
+
 def rmsnorm_rope_(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, wq_img, wk_img, wq_txt, wk_txt,
                   cos: torch.Tensor, sin: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     """In place on buf [B,N,ld]: q at columns q_off.., k at k_off.. (H heads of 128)."""
