@@ -1,25 +1,31 @@
-// bf16 GEMM for the DiT linear layers:  C[b][M,N] = epi( A[b][M,K] @ W[N,K]^T + bias ).
+// bf16 (and e4m3) GEMM for the DiT linear layers:  C[b][M,N] = epi( A[b][M,K] @ W[N,K]^T + bias ).
 //
-// Fast path (gemm8p_kernel): 256x256x64 block tile, 8 waves (512 threads) as 2 row-groups x 4 column
-// stripes, v_mfma_f32_32x32x16_bf16 with the operands swapped (MFMA "A" = weight rows, "B" = token rows) so
-// that every lane ends up holding 4 consecutive output columns of one token row -> 8-byte row-major stores.
-// Operand tiles go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip); the 16-byte chunks of each
-// 128-byte LDS row are XOR-swizzled with ((row>>1)&7) (applied on the per-lane *source* address, LDS image
-// stays lane-linear) so every ds_read_b128 lane group is bank-conflict free.  The two row-groups run a
-// ping-pong schedule offset by one s_barrier: while one group's 4 waves (one per SIMD) issue 8 MFMAs, the
-// other group reads its next fragments from LDS and issues the prefetch of a quarter K-tile that is one and
-// a half K-tiles ahead; waits are counted (vmcnt(6)), never drained, inside the main loop.
+// Three kernels:
+//   gemm8pp_kernel  persistent MFMA kernel, what the DiT runs on (K % 128 == 0): see the comment above it;
+//                   template flags select the e4m3 operand type (FP8) and the split-K work unit (SPLIT);
+//   gemm8p_kernel   one tile per block: same tile / fragments / ping-pong, K % 64 == 0, and the implicit-GEMM 3x3
+//                   convolution mode of the VAE (CONV);
+//   gemm_generic_kernel  fp32 FMA fallback for any shape (unit-test configs) and on-device cross-check.
 //
-// Schedule (slots = half phases; tile t, phase q in 0..3; group g runs loads(p) at slot 2p-1+g and MFMA(p) at
-// slot 2p+g, p = 4t+q).  Each wave keeps X fragments for 64 rows and both 32-column W fragments in registers:
+// Common to the MFMA kernels: 256x256x64 block tile, 8 waves (512 threads) as 2 row-groups x 4 column stripes,
+// v_mfma_f32_32x32x16_bf16 with the operands swapped (MFMA "A" = weight rows, "B" = token rows) so that every lane ends
+// up holding 4 consecutive output columns of one token row.  Operand tiles go L2 -> LDS with LDS-DMA
+// (buffer_load_dwordx4 ... lds, no VGPR round trip); the 16-byte chunks of each 128-byte LDS row are XOR-swizzled with
+// ((row>>1)&7) (applied on the per-lane *source* address, the LDS image stays lane-linear) so every ds_read_b128 lane
+// group is bank-conflict free.  The two row-groups run a ping-pong schedule offset by one s_barrier: while one group's
+// 4 waves (one per SIMD) issue 8 MFMAs, the other group reads its next fragments from LDS; waits on the operand
+// requests are counted (s_waitcnt vmcnt(n)), never drained, inside the main loop.
+//
+// One-tile kernel schedule (slots = half phases; tile t, phase q in 0..3; group g runs loads(p) at slot 2p-1+g and
+// MFMA(p) at slot 2p+g, p = 4t+q).  Each wave keeps X fragments for 64 rows and both 32-column W fragments in registers:
 //   q0: read X_lo, W_lo | q1: read W_hi | q2: read X_hi | q3: no reads,
 // so the last LDS read of tile t is X_lo, W_lo @q0, W_hi @q1, X_hi @q2.  With 2 buffer sets tile t+2 overwrites tile t,
 // one 64-row quarter per slot, each in the first slot where every read of the overwritten bytes has been waited for
 // (own lgkmcnt) and fenced (>= 1 barrier):
 //   slot 8t+1 G0:X0_lo  +2 G1:W_lo_a  +3 G0:W_lo_b  +4 G1:X1_lo  +5 G0:W_hi_a  +6 G1:W_hi_b  +7 G0:X0_hi  +8 G1:X1_hi
-// first readers: X0_lo/W_lo 8t+15, X1_lo 8t+16, W_hi 8t+17, X0_hi 8t+19, X1_hi 8t+20 -> >= 11 slots in flight.
-// A request issued in slot s is waited for by its issuer at the end of its 5th following section (vmcnt(10), 2 loads
-// per section) = slot s+10, then one barrier -> readable from s+11.  See DESIGN.md "GEMM schedule".
+// first readers: X0_lo/W_lo 8t+15, X1_lo 8t+16, W_hi 8t+17, X0_hi 8t+19, X1_hi 8t+20 -> >= 11 slots in flight; a request
+// is waited for by its issuer (vmcnt(8): the 4 newest sections may still be in flight), then one barrier -> readable.
+// See DESIGN.md "GEMM".
 #include "common.h"
 #include "launch.h"
 
