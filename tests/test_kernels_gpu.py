@@ -210,7 +210,7 @@ def test_gemm_fp8_rejects_unsupported_k(ops):
 
 
 # ----------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("B,H,N", [(1, 1, 64), (2, 2, 96), (1, 3, 300), (2, 2, 1664), (1, 24, 520)])
+@pytest.mark.parametrize("B,H,N", [(1, 1, 1), (2, 3, 8), (1, 2, 33), (1, 1, 64), (1, 1, 65), (2, 2, 96), (1, 3, 300), (2, 2, 1664), (1, 24, 520)])
 def test_attention(ops, B, H, N):
     q, k, v = (rnd((B, N, H * 128), s).to(BF) for s in (20, 21, 22))
     qh, kh, vh = (t.float().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
