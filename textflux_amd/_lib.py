@@ -6,11 +6,13 @@ ops raises -- a CPU or eager-PyTorch path would silently void every parity claim
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtextflux_hip.so")
+HASH_PATH = LIB_PATH + ".srchash"
 CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_int32, c_int64, c_float, c_char_p = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_char_p
@@ -113,15 +115,38 @@ SIGNATURES = {
 _lib = None
 
 
+def _sources():
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", "Makefile")))
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "textflux_hip.h"))
+    return srcs
+
+
+def _src_hash() -> str:
+    h = hashlib.sha256()
+    for p in _sources():
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def is_stale() -> bool:
+    """True when libtextflux_hip.so is missing or was not built from the sources now in csrc/ (content hash kept in a
+    side file next to the library; mtimes do not survive the copy to the GPU box)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
+        return True
+    with open(HASH_PATH) as f:
+        return f.read().strip() != _src_hash()
+
+
 def build(force: bool = False) -> str:
     """Compile textflux_amd/csrc for gfx950 into libtextflux_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", "Makefile"))]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "textflux_hip.h"))
-    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if stale:
-        r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if force or is_stale():
+        r = subprocess.run(["make", "-C", CSRC, "-j8"] + (["-B"] if force else []), capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("building libtextflux_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+        with open(HASH_PATH, "w") as f:
+            f.write(_src_hash() + "\n")
     return LIB_PATH
 
 
@@ -132,12 +157,12 @@ def lib() -> C.CDLL:
         # torch bundles its own libamdhip64; it must be in the process BEFORE our library is dlopen'ed so both share
         # ONE HIP runtime (loading ours first pulls /opt/rocm's copy and its kernels then see "no device").
         import torch  # noqa: F401
-        if not os.path.exists(LIB_PATH):
-            try:                      # same HIP sources, just not compiled yet (fresh checkout): compile, never substitute
+        if is_stale():
+            try:    # same HIP sources, not compiled yet or edited since (never a silently stale .so): compile, never substitute
                 build()
             except Exception as e:
-                raise RuntimeError(f"{LIB_PATH} is missing and could not be built ({e}); textflux_amd has no CPU / eager "
-                                   "fallback") from e
+                raise RuntimeError(f"{LIB_PATH} is missing or stale and could not be built ({e}); textflux_amd has no "
+                                   "CPU / eager fallback") from e
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

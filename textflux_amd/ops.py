@@ -191,6 +191,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: Optional[t
 def euler_step_(v: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, step: int = 0,
                 step_ptr: Optional[torch.Tensor] = None, xin: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk_dev(v, x, coef, step_ptr, xin)
+    if v.dtype != BF16 or x.dtype != BF16 or (xin is not None and xin.dtype != BF16):
+        raise TypeError("euler_step_: the HIP scheduler kernels operate on bf16 latents / model outputs")
     assert v.is_contiguous() and x.is_contiguous() and coef.dtype == torch.float32
     Cc = x.shape[-1]
     rows = x.numel() // Cc
@@ -202,6 +204,8 @@ def euler_step_(v: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, step: int 
 def amo_step_(v: torch.Tensor, x: torch.Tensor, coef: torch.Tensor, noise: torch.Tensor, step: int = 0,
               step_ptr: Optional[torch.Tensor] = None, xin: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk_dev(v, x, coef, noise, step_ptr, xin)
+    if v.dtype != BF16 or x.dtype != BF16 or (xin is not None and xin.dtype != BF16):
+        raise TypeError("amo_step_: the HIP scheduler kernels operate on bf16 latents / model outputs")
     assert v.is_contiguous() and x.is_contiguous() and noise.is_contiguous() and noise.dtype == torch.float32
     Cc = x.shape[-1]
     rows = x.numel() // Cc

@@ -235,14 +235,16 @@ class FluxFillPipeline:
         cache = getattr(self, "_prompt_cache", None)
         if cache is None:
             return encode(prompts)
-        missing = [p for p in dict.fromkeys(prompts) if (kind, p, key_extra) not in cache]
+        rows = {p: cache[(kind, p, key_extra)] for p in dict.fromkeys(prompts) if (kind, p, key_extra) in cache}
+        missing = [p for p in dict.fromkeys(prompts) if p not in rows]
         if missing:
             out = encode(missing)
             for p, row in zip(missing, out):
+                rows[p] = row.detach().clone()     # this call is served from `rows`, so eviction below cannot hurt it
                 if len(cache) >= self._prompt_cache_max:
                     cache.pop(next(iter(cache)))           # oldest entry out
-                cache[(kind, p, key_extra)] = row.detach().clone()
-        return torch.stack([cache[(kind, p, key_extra)] for p in prompts])
+                cache[(kind, p, key_extra)] = rows[p]
+        return torch.stack([rows[p] for p in prompts])
 
     def _get_t5_prompt_embeds(self, prompt=None, num_images_per_prompt: int = 1, max_sequence_length: int = 512,
                               device=None, dtype=None):

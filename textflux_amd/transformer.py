@@ -167,11 +167,13 @@ class FluxTransformer2DModel:
         if not self.w:
             self._alloc(device)
         for key, name, off in self._fusion_map():
-            if key + ".weight" not in sd:
-                continue
-            wt, bs = sd[key + ".weight"], sd[key + ".bias"]
-            self.w[name + ".w"][off:off + wt.shape[0]].copy_(wt.to(BF16))
-            self.w[name + ".b"][off:off + bs.shape[0]].copy_(bs.to(BF16))
+            # weight and bias are looked up independently: HF shards split on cumulative size, so a Linear's two
+            # tensors may arrive in different shards (from_pretrained calls this once per shard, strict=False)
+            wt, bs = sd.get(key + ".weight"), sd.get(key + ".bias")
+            if wt is not None:
+                self.w[name + ".w"][off:off + wt.shape[0]].copy_(wt.to(BF16))
+            if bs is not None:
+                self.w[name + ".b"][off:off + bs.shape[0]].copy_(bs.to(BF16))
         for key, name in self._norm_map():
             if key in sd:
                 self.w[name].copy_(sd[key].to(BF16))
@@ -345,7 +347,10 @@ class DitSession:
         self.ctx0 = e(B, T, D)
         self.hid, self.xn, self.y = e(B, N, D), e(B, N, D), e(B, N, 7 * D)
         self.out = e(B, S, model.out_channels)
-        self.cos = self.sin = None
+        # RoPE tables: allocated ONCE per session and refreshed in place -- captured step graphs bake these pointers
+        # into the kernel arguments, so a new ids layout for the same (B, S, T) must not move them
+        self.cos = torch.empty(N, c.attention_head_dim, dtype=torch.float32, device=dev)
+        self.sin = torch.empty(N, c.attention_head_dim, dtype=torch.float32, device=dev)
         self._ids_key = None
         w = model.w
 
@@ -380,6 +385,7 @@ class DitSession:
         d.xin, d.ctx0 = self.xin.data_ptr(), self.ctx0.data_ptr()
         d.hid, d.xn, d.y, d.out = self.hid.data_ptr(), self.xn.data_ptr(), self.y.data_ptr(), self.out.data_ptr()
         d.first_block, d.last_block, d.flags = 0, -1, 0
+        d.cos_tab, d.sin_tab = self.cos.data_ptr(), self.sin.data_ptr()
         if self.fp8:
             d.q8, d.q8_scale = self.q8.data_ptr(), self.q8_scale.data_ptr()
         # scratch for the split-K path of few-tile GEMMs (text stream, small batch x resolution): fp32 partials of at most
@@ -398,9 +404,9 @@ class DitSession:
         key = (ids.shape, float(ids.sum()), float((ids * torch.arange(1, 4)).sum()))
         if key != self._ids_key:
             cos, sin = rope_tables(ids, m.config.axes_dims_rope)
-            self.cos, self.sin = cos.to(m.device), sin.to(m.device)
+            self.cos.copy_(cos)
+            self.sin.copy_(sin)
             self._ids_key = key
-            self.desc.cos_tab, self.desc.sin_tab = self.cos.data_ptr(), self.sin.data_ptr()
 
     def graph_buffers(self, n_steps: int, n_coef: int, lat_shape):
         """Persistent device buffers a captured step graph points at (modulation table of all steps, the current
@@ -421,7 +427,7 @@ class DitSession:
     def run(self, mod: torch.Tensor, first_block: int = 0, last_block: int = -1, flags: int = 0) -> torch.Tensor:
         """One transformer forward with modulation rows `mod` [B, mod_len] (a view into a table is fine).
         first_block/last_block/flags: partial runs for block-level tests (see tfx_dit_desc)."""
-        assert mod.shape == (self.B, self.model.mod_len) and mod.stride(1) == 1 and self.cos is not None
+        assert mod.shape == (self.B, self.model.mod_len) and mod.stride(1) == 1 and self._ids_key is not None
         self._mod_keepalive = mod
         d = self.desc
         d.mod, d.mod_bstride = mod.data_ptr(), mod.stride(0)
