@@ -174,7 +174,8 @@ int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
  * 3x3 convolution as an implicit GEMM on the MFMA kernel (ResnetBlock2D convs D/models/resnet.py:327-366, Upsample2D
  * nearest-2x + conv D/models/upsampling.py:142-192 with up = 2, Downsample2D pad (0,1,0,1) stride 2
  * D/models/downsampling.py:132-150 with stride = 2, pad_lo = 0).  x [B, inH, inW, Cin] (Cin % 64 == 0),
- * w [Cout, 3, 3, Cin] (KRSC), out [B, H, W, Cout] = conv(x) + bias (+ res when res != NULL; may alias out),
+ * w [Cout, 3, 3, Cin] (KRSC) -- or the narrow form of the two conv_in layers: Cin in {8, 16, 32} with w [Cout, Kp],
+ * Kp = 9 Cin rounded up to a multiple of 64, columns (tap, ci) then zeros --, out [B, H, W, Cout] = conv(x) + bias (+ res when res != NULL; may alias out),
  * zero_page: >= 128 bytes of zeros (source of out-of-image taps).  variant: -1 auto, 0 generic, 1 MFMA. */
 int tfx_conv3x3_nhwc(const void* x, int32_t B, int32_t inH, int32_t inW, int32_t Cin, const void* w, const void* bias,
                      void* out, int32_t H, int32_t W, int32_t Cout, int32_t stride, int32_t up, int32_t pad_lo,
@@ -183,6 +184,41 @@ int tfx_conv3x3_nhwc(const void* x, int32_t B, int32_t inH, int32_t inW, int32_t
  * [B * (ceil(HW/1024) + 1) * groups * 2]. */
 int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* workspace, int32_t B,
                        int64_t HW, int32_t C, int32_t groups, float eps, int32_t silu, tfx_stream stream);
+
+/* ---- the pixel / latent layout steps around the VAE (FluxFillPipeline.__call__, D/pipelines/flux/pipeline_flux_fill.py
+ *      "P:", and VaeImageProcessor, D/image_processor.py "IP:"), so that no NCHW tensor and no torch op sits between the
+ *      caller's image and the encoder, or between the decoder and the caller's image.  dtype codes: 0 f32, 1 bf16, 2 u8. */
+/* *flag |= 1 when any element of x is negative (IP:700-707: tensors already in [-1, 1] are not re-normalised). */
+int tfx_any_negative(const void* x, int32_t dtype, int64_t n, int32_t* flag, tfx_stream stream);
+/* out [B, H, W, 8] bf16 NHWC (channels >= C zero) = bf16( norm(img) * (1 - mask) ): the encoder input.  img: f32 / bf16
+ * planes [B, C, H, W], or u8 interleaved [B, H, W, C] read as value / 255 (PIL branch, IP:133-154 inverse).  mask: NULL or
+ * f32 / u8 [mask_batch, H, W] (mask_batch 1 or B), binarised at 0.5 when binarize != 0 (IP:535-536).  norm_mode: 0 none,
+ * 1 x -> 2x - 1 (IP:221-225), 2 the same unless *neg_flag != 0.   (IP:587-716 + P:2030-2031) */
+int tfx_prep_image(const void* img, int32_t img_dtype, const void* mask, int32_t mask_dtype, void* out, int32_t B, int32_t C,
+                   int32_t H, int32_t W, int32_t mask_batch, int32_t norm_mode, int32_t binarize, const int32_t* neg_flag,
+                   tfx_stream stream);
+/* out[b, t, col0 + (i*8+j)*4 + py*2+px] = mask[(2ty+py)*8 + i, (2tx+px)*8 + j]  (P:1563-1580: 8x8 pixel blocks -> channels,
+ * then _pack_latents), t = ty * (W/16) + tx, row stride ld. */
+int tfx_pack_mask(const void* mask, int32_t mask_dtype, void* out, int32_t B, int32_t H, int32_t W, int32_t mask_batch,
+                  int32_t binarize, int64_t ld, int32_t col0, tfx_stream stream);
+/* moments [B, h, w, 2L] NHWC bf16 (mean | logvar: the encoder's conv_out), eps [B, L, h, w] f32 / bf16 or NULL (mode) ->
+ * out[b, t, col0 + c*4 + py*2+px] = ((mean + exp(0.5 clamp(logvar, -30, 20)) * eps) - shift) * scale, every intermediate
+ * rounded to bf16 as the reference's tensor ops do (D/models/autoencoders/vae.py:781-802, P:1528-1530, 1743-1748). */
+int tfx_vae_sample_pack(const void* moments, const void* eps, int32_t eps_dtype, void* out, int32_t B, int32_t h, int32_t w,
+                        int32_t L, float shift, float scale, int64_t ld, int32_t col0, tfx_stream stream);
+/* latents [B, (h/2)(w/2), >= 4L] (row stride ld) -> z [B, h, w, L] NHWC bf16 = latents / scale + shift, un-patchified
+ * (P:1752-1765, 2126-2127): the decoder input. */
+int tfx_unpack_latents(const void* latents, int64_t ld, void* out, int32_t B, int32_t h, int32_t w, int32_t L, float shift,
+                       float scale, tfx_stream stream);
+/* x [B, HW, Cs] NHWC bf16 (first C channels) -> mode 0 NCHW bf16 | 1 NHWC f32 | 2 NHWC u8 = round(255 v) | 3 NCHW f32;
+ * denorm != 0: v = clamp(x / 2 + 0.5, 0, 1) in bf16 steps (IP:227-239, 196-209, 133-154). */
+int tfx_postprocess(const void* x, void* out, int32_t B, int64_t HW, int32_t Cs, int32_t C, int32_t mode, int32_t denorm,
+                    tfx_stream stream);
+/* helpers of the VAE mid-block attention (one head of dim C over h*w tokens, AttnProcessor2_0,
+ * D/models/attention_processor.py:2799-2881): out[b][c, n] = in[b][n, c]; p = softmax(scale * s) over rows, in place. */
+int tfx_transpose(const void* in, int64_t ldi, int64_t in_bstride, void* out, int64_t ldo, int64_t out_bstride, int32_t N,
+                  int32_t C, int32_t batch, tfx_stream stream);
+int tfx_row_softmax(void* s, int64_t ld, int32_t rows, int32_t N, float scale, tfx_stream stream);
 
 /* ---- tuning knobs (no reference counterpart).  "attention_waves" selects the attention kernel: 10 (default) = one
  *      512-thread workgroup of 256 query rows per CU with the softmax bookkeeping on the matrix pipe (pre-scaled Q, lazy

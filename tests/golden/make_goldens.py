@@ -313,7 +313,7 @@ def g6_g7():
 
 
 # ----------------------------------------------------------------------------- G9 VAE + VAE-inclusive pipeline
-G9_VAE = dict(block_out_channels=(8, 16, 16, 16), layers_per_block=1, latent_channels=16, norm_num_groups=4)
+G9_VAE = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=1, latent_channels=16, norm_num_groups=16)
 
 
 def g9_vae():
@@ -323,7 +323,7 @@ def g9_vae():
     cfg = vo.VaeConfig(**G9_VAE)
     vae = AutoencoderKL(in_channels=3, out_channels=3, block_out_channels=cfg.block_out_channels,
                         layers_per_block=cfg.layers_per_block, down_block_types=("DownEncoderBlock2D",) * 4,
-                        up_block_types=("UpDecoderBlock2D",) * 4, latent_channels=16, norm_num_groups=4,
+                        up_block_types=("UpDecoderBlock2D",) * 4, latent_channels=16, norm_num_groups=cfg.norm_num_groups,
                         use_quant_conv=False, use_post_quant_conv=False, shift_factor=0.1159, scaling_factor=0.3611)
     sd = vo.seeded_state_dict(cfg, 900)
     assert sorted(vae.state_dict().keys()) == sorted(sd.keys()), "oracle VAE keys != reference keys"

@@ -90,13 +90,6 @@ def test_check_inputs_raises_like_the_reference():
     assert p.vae_scale_factor == 8 and p.tokenizer_max_length == 77 and p.default_sample_size == 128
 
 
-def test_mask_packing_matches_reference(golden):
-    g = golden("g6_layout")
-    p = _pipe()
-    mask, mil = p.prepare_mask_latents(g["mask.in"], torch.zeros(2, 16, 8, 12), 2, 16, 1, 64, 96, torch.float32, "cpu", None)
-    assert torch.equal(mask, g["mask.out"]) and mil.shape == (2, 24, 64)
-
-
 def test_randn_tensor_generator_semantics():
     a = randn_tensor((2, 3), generator=torch.Generator().manual_seed(1))
     b = randn_tensor((2, 3), generator=torch.Generator().manual_seed(1))

@@ -211,7 +211,7 @@ def test_prompt_strings():
 
 
 # ----------------------------------------------------------------------------- G9 VAE and the VAE-inclusive pipeline
-G9_VAE = dict(block_out_channels=(8, 16, 16, 16), layers_per_block=1, latent_channels=16, norm_num_groups=4)
+G9_VAE = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=1, latent_channels=16, norm_num_groups=16)
 
 
 def test_vae_encode_decode(golden):

@@ -16,7 +16,7 @@ from oracle import vae_oracle as vo
 BF = torch.bfloat16
 G3_CFG = fo.FluxConfig(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=64,
                        pooled_projection_dim=32)
-G9_VAE = dict(block_out_channels=(8, 16, 16, 16), layers_per_block=1, latent_channels=16, norm_num_groups=4)
+G9_VAE = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=1, latent_channels=16, norm_num_groups=16)
 SCHED = dict(use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15, base_image_seq_len=256, max_image_seq_len=4096,
              shift=3.0)
 

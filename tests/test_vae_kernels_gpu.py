@@ -65,28 +65,68 @@ def test_groupnorm_silu_nhwc(ops, C, groups, HW, silu):
     close(got.transpose(1, 2), ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
-def test_vae_hip_nhwc_path_matches_oracle():
-    """Whole encoder / decoder on the HIP NHWC path (widths 64 / 128 so every conv takes the MFMA kernel) against the
-    fp32 CPU oracle, and against the torch/MIOpen NCHW path of the same class."""
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 20, 24, 3, 64), (1, 9, 13, 16, 128), (1, 33, 17, 3, 128), (2, 8, 8, 32, 64)])
+def test_conv3x3_narrow_input(ops, variant, B, H, W, Cin, Cout):
+    """conv_in of the two VAE ends: Cin padded to 8 / 16 / 32 channels, K = 9 * Cin_p padded with zero weights to a multiple
+    of 64 (a K-tile spans several taps; taps >= 9 read the zero page)."""
+    x = rnd((B, Cin, H, W), 21).to(BF)
+    w = rnd((Cout, Cin, 3, 3), 22, 0.2).to(BF)
+    b = rnd((Cout,), 23).to(BF)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    cp = 8 if Cin <= 8 else 16 if Cin <= 16 else 32
+    xp = torch.zeros(B, H, W, cp, dtype=BF)
+    xp[..., :Cin] = x.permute(0, 2, 3, 1)
+    wp = torch.zeros(Cout, 3, 3, cp, dtype=BF)
+    wp[..., :Cin] = w.permute(0, 2, 3, 1)
+    kp = (9 * cp + 63) // 64 * 64
+    wk = torch.zeros(Cout, kp, dtype=BF)
+    wk[:, :9 * cp] = wp.reshape(Cout, 9 * cp)
+    got = ops.conv3x3_nhwc(xp.cuda(), wk.cuda(), b.cuda(), variant=variant)
+    close(got.permute(0, 3, 1, 2), ref.to(BF))
+
+
+def test_vae_nhwc_path_matches_oracle():
+    """Whole encoder / decoder on the HIP NHWC path against the fp32 CPU oracle -- including both narrow conv_in layers
+    and the mid-block attention (score GEMM -> row softmax -> P v GEMM); the NCHW tensor interface and the NHWC entry
+    points the pipeline uses must agree bit for bit."""
     from oracle import vae_oracle as vo
+    from textflux_amd import ops as o
     from textflux_amd.vae import AutoencoderKL
     kw = dict(block_out_channels=(64, 128, 128), layers_per_block=1, latent_channels=16, norm_num_groups=16)
     cfg = vo.VaeConfig(**kw)
     sd = vo.seeded_state_dict(cfg, 321)
     vae = AutoencoderKL(**kw).load_state_dict(sd, device="cuda")
-    assert vae.use_hip
     x = rnd((2, 3, 48, 40), 11).clamp(-1, 1)
     z = rnd((2, 16, 12, 10), 12)
     mean, std = vo.encode_moments(x, sd, cfg)
     post = vae.encode(x.to(BF).cuda()).latent_dist
     dec_ref = vo.decoder(z, sd, cfg)
     dec = vae.decode(z.to(BF).cuda(), return_dict=False)[0]
-    assert dec.shape == dec_ref.shape
+    assert dec.shape == dec_ref.shape and post.mean.shape == mean.shape
     close(post.mean, mean, max_rel=5e-2, mae_rel=1.5e-2)
+    close(post.std, std, max_rel=5e-2, mae_rel=1.5e-2)
     close(dec, dec_ref, max_rel=5e-2, mae_rel=1.5e-2)
-    vae.use_hip = False
-    dec_t = vae.decode(z.to(BF).cuda(), return_dict=False)[0]
-    e_hip = (dec.float().cpu() - dec_ref).abs().mean().item()
-    e_torch = (dec_t.float().cpu() - dec_ref).abs().mean().item()
-    print(f"decoder MAE vs fp32 oracle: HIP path {e_hip:.3e}, torch/MIOpen path {e_torch:.3e}")
-    assert e_hip < 2.0 * e_torch + 1e-3
+    mom = vae.encode_moments_nhwc(o.prep_image(x.to(BF).cuda(), None))
+    assert torch.equal(mom.permute(0, 3, 1, 2)[:, :16], post.mean)
+    img = vae.decode_nhwc(z.to(BF).permute(0, 2, 3, 1).contiguous().cuda())
+    assert torch.equal(img[..., :3].permute(0, 3, 1, 2), dec)
+
+
+def test_vae_rejects_configs_the_kernels_do_not_cover():
+    from textflux_amd.vae import AutoencoderKL
+    with pytest.raises(ValueError):
+        AutoencoderKL(block_out_channels=(8, 16, 16, 16), layers_per_block=1, norm_num_groups=4)
+
+
+def test_mid_block_attention_matches_fp32_softmax_attention():
+    """The VAE mid-block attention (one head of dim C) as GEMM -> row softmax -> GEMM, against fp32 attention on the same
+    bf16 q / k / v, at a token count that is not a tile multiple."""
+    from textflux_amd import ops as o
+    N, C = 35 * 29, 128
+    q, k, v = (rnd((N, C), 30 + i, 1.5).to(BF) for i in range(3))
+    ref = torch.softmax(q.float() @ k.float().T * C ** -0.5, -1) @ v.float()
+    s = o.gemm(q.cuda(), k.cuda(), None)
+    o.row_softmax_(s, C ** -0.5)
+    out = o.gemm(s, o.transpose(v.cuda()[None])[0], None)
+    close(out, ref.to(BF), max_rel=3e-2, mae_rel=6e-3)

@@ -106,6 +106,18 @@ SIGNATURES = {
                                  c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int, c_void_p]),
     "tfx_groupnorm_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                    c_float, c_int32, c_void_p]),
+    "tfx_any_negative": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "tfx_prep_image": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                               c_int32, c_int32, c_void_p, c_void_p]),
+    "tfx_pack_mask": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
+                              c_void_p]),
+    "tfx_vae_sample_pack": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
+                                    c_float, c_int64, c_int32, c_void_p]),
+    "tfx_unpack_latents": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float,
+                                   c_void_p]),
+    "tfx_postprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "tfx_transpose": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "tfx_row_softmax": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "tfx_set_option": (c_int, [c_char_p, c_int]),
     "tfx_prof_enable": (c_int, [c_int]),
     "tfx_prof_collect": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),

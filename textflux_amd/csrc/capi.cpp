@@ -304,8 +304,10 @@ int tfx_conv3x3_nhwc(const void* x, int32_t B, int32_t inH, int32_t inW, int32_t
   if (up != 1 && up != 2) return fail("tfx_conv3x3_nhwc: up must be 1 or 2");
   GemmArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.A = x; a.lda = Cin; a.W = w; a.ldw = 9 * (int64_t)Cin; a.bias = bias;
-  a.C = out; a.ldc = Cout; a.M = B * H * W; a.N = Cout; a.K = 9 * Cin; a.batch = 1;
+  // narrow inputs (Cin = 8 / 16 / 32): K = 9 * Cin padded with zero weights to a multiple of 64
+  const int K = Cin < 64 ? (9 * Cin + 63) / 64 * 64 : 9 * Cin;
+  a.A = x; a.lda = Cin; a.W = w; a.ldw = K; a.bias = bias;
+  a.C = out; a.ldc = Cout; a.M = B * H * W; a.N = Cout; a.K = K; a.batch = 1;
   a.epilogue = res ? EPI_BIAS_RES : EPI_BIAS;
   a.res = res; a.ldr = Cout;
   a.conv_cin = Cin; a.conv_inH = inH; a.conv_inW = inW; a.conv_H = H; a.conv_W = W;
@@ -317,6 +319,46 @@ int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* 
                        int64_t HW, int32_t C, int32_t groups, float eps, int32_t silu, tfx_stream stream) {
   if (!x || !out || !gamma || !beta || !workspace) return fail("tfx_groupnorm_nhwc: null pointer");
   return groupnorm_silu_nhwc(x, out, gamma, beta, workspace, B, HW, C, groups, eps, silu != 0, S(stream));
+}
+
+int tfx_any_negative(const void* x, int32_t dtype, int64_t n, int32_t* flag, tfx_stream stream) {
+  if (!x || !flag) return fail("tfx_any_negative: null pointer");
+  return any_negative(x, dtype, n, flag, S(stream));
+}
+int tfx_prep_image(const void* img, int32_t img_dtype, const void* mask, int32_t mask_dtype, void* out, int32_t B, int32_t C,
+                   int32_t H, int32_t W, int32_t mask_batch, int32_t norm_mode, int32_t binarize, const int32_t* neg_flag,
+                   tfx_stream stream) {
+  if (!img || !out) return fail("tfx_prep_image: null pointer");
+  return prep_image(img, img_dtype, mask, mask_dtype, out, B, C, H, W, mask_batch, norm_mode, binarize, neg_flag, S(stream));
+}
+int tfx_pack_mask(const void* mask, int32_t mask_dtype, void* out, int32_t B, int32_t H, int32_t W, int32_t mask_batch,
+                  int32_t binarize, int64_t ld, int32_t col0, tfx_stream stream) {
+  if (!mask || !out) return fail("tfx_pack_mask: null pointer");
+  return pack_mask(mask, mask_dtype, out, B, H, W, mask_batch, binarize, ld, col0, S(stream));
+}
+int tfx_vae_sample_pack(const void* moments, const void* eps, int32_t eps_dtype, void* out, int32_t B, int32_t h, int32_t w,
+                        int32_t L, float shift, float scale, int64_t ld, int32_t col0, tfx_stream stream) {
+  if (!moments || !out) return fail("tfx_vae_sample_pack: null pointer");
+  return sample_pack(moments, eps, eps_dtype, out, B, h, w, L, shift, scale, ld, col0, S(stream));
+}
+int tfx_unpack_latents(const void* latents, int64_t ld, void* out, int32_t B, int32_t h, int32_t w, int32_t L, float shift,
+                       float scale, tfx_stream stream) {
+  if (!latents || !out) return fail("tfx_unpack_latents: null pointer");
+  return unpack_latents(latents, ld, out, B, h, w, L, shift, scale, S(stream));
+}
+int tfx_postprocess(const void* x, void* out, int32_t B, int64_t HW, int32_t Cs, int32_t C, int32_t mode, int32_t denorm,
+                    tfx_stream stream) {
+  if (!x || !out) return fail("tfx_postprocess: null pointer");
+  return postprocess(x, out, B, HW, Cs, C, mode, denorm, S(stream));
+}
+int tfx_transpose(const void* in, int64_t ldi, int64_t in_bstride, void* out, int64_t ldo, int64_t out_bstride, int32_t N,
+                  int32_t C, int32_t batch, tfx_stream stream) {
+  if (!in || !out) return fail("tfx_transpose: null pointer");
+  return transpose_bf16(in, ldi, in_bstride, out, ldo, out_bstride, N, C, batch, S(stream));
+}
+int tfx_row_softmax(void* s, int64_t ld, int32_t rows, int32_t N, float scale, tfx_stream stream) {
+  if (!s) return fail("tfx_row_softmax: null pointer");
+  return row_softmax(s, ld, rows, N, scale, S(stream));
 }
 
 int tfx_set_option(const char* name, int value) {

@@ -41,6 +41,7 @@ struct GemmParams {
   const bf16_t* gate; int64_t gate_bs;
   const bf16_t* res; int64_t ldr, r_bs;
   int cin, inH, inW, oH, oW, cstride, cup, cpad;   // implicit 3x3 convolution (cin > 0), see GemmArgs
+  int csh;                                          // log2(cin) when cin < 64 (narrow-input mode), else 0
   const bf16_t* zero;
   const float* a_scale; int64_t as_bs; const float* w_scale;   // fp8 kernel only
   float* ws; int sk;                                             // split-K: fp32 partials [sk][batch][M][N], slices
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
           const int tap = k / p.cin, ci = k - tap * p.cin, dy = tap / 3, dx = tap - 3 * dy;
           const int pix = m % (p.oH * p.oW), bb = m / (p.oH * p.oW), y = pix / p.oW, x = pix - y * p.oW;
           const int yy = y * p.cstride - p.cpad + dy, xx = x * p.cstride - p.cpad + dx;
-          if (yy >= 0 && xx >= 0 && yy < (p.inH << p.cup) && xx < (p.inW << p.cup))
+          if (tap < 9 && yy >= 0 && xx >= 0 && yy < (p.inH << p.cup) && xx < (p.inW << p.cup))
             av = bf2f(A[((int64_t)(bb * p.inH + (yy >> p.cup)) * p.inW + (xx >> p.cup)) * p.cin + ci]);
         } else {
           av = bf2f(A[(int64_t)m * p.lda + k]);
@@ -235,9 +236,24 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     const uint32_t setoff = (tile & 1) * (isx[q] ? 16384u : 32768u);
     constexpr int kAux = GLDS_AUX;
     if (CONV && isx[q]) {
+      const int vh = p.inH << p.cup, vw = p.inW << p.cup;
+      if (p.csh) {
+        // narrow inputs (Cin = 8 / 16 / 32: conv_in of the VAE ends): a 64-wide K-tile spans 64 / Cin taps, so the tap
+        // is a per-lane quantity of the lane's 16-byte chunk; K is padded to a multiple of 64 and taps >= 9 read zeros
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int e = kt * 64 + goff[q][j], tap = e >> p.csh, ci = e & (p.cin - 1);
+          const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+          const int yy = (cyx[q][j] >> 16) - 1 + dy, xx = (cyx[q][j] & 0xffff) - 1 + dx;
+          const bool inside = tap < 9 && (unsigned)yy < (unsigned)vh && (unsigned)xx < (unsigned)vw;
+          const bf16_t* src = inside ? p.A + ((int64_t)(cpix[q][j] + (yy >> p.cup) * p.inW + (xx >> p.cup)) * p.cin + ci)
+                                     : p.zero + goff[q][j];
+          glds16<kAux>(src, smem, ok ? ldst[q][j] + setoff : dummy);
+        }
+        return;
+      }
       // K index -> (tap, channel block): a 64-wide K-tile never straddles a tap because Cin % 64 == 0
       const int k0 = kt * 64, tap = k0 / p.cin, ci0 = k0 - tap * p.cin, dy = tap / 3, dx = tap - 3 * dy;
-      const int vh = p.inH << p.cup, vw = p.inW << p.cup;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int yy = (cyx[q][j] >> 16) - 1 + dy, xx = (cyx[q][j] & 0xffff) - 1 + dx;
@@ -934,13 +950,16 @@ static GemmParams make_params(const GemmArgs& a) {
   p.res = (const bf16_t*)a.res; p.ldr = a.ldr; p.r_bs = a.r_bstride;
   p.cin = a.conv_cin; p.inH = a.conv_inH; p.inW = a.conv_inW; p.oH = a.conv_H; p.oW = a.conv_W;
   p.cstride = a.conv_stride; p.cup = a.conv_up_shift; p.cpad = a.conv_pad_lo; p.zero = (const bf16_t*)a.zero_page;
+  p.csh = a.conv_cin == 8 ? 3 : a.conv_cin == 16 ? 4 : a.conv_cin == 32 ? 5 : 0;
   p.a_scale = a.a_scale; p.as_bs = a.a_scale_bstride; p.w_scale = a.w_scale;
   p.ws = nullptr; p.sk = 1;
   return p;
 }
 
 static bool conv_ok(const GemmArgs& a) {
-  return a.conv_cin % 64 == 0 && a.K == 9 * a.conv_cin && a.batch == 1 && a.zero_page && (uintptr_t)a.zero_page % 16 == 0 &&
+  const bool wide = a.conv_cin % 64 == 0 && a.K == 9 * a.conv_cin;
+  const bool narrow = (a.conv_cin == 8 || a.conv_cin == 16 || a.conv_cin == 32) && a.K == (9 * a.conv_cin + 63) / 64 * 64;
+  return (wide || narrow) && a.batch == 1 && a.zero_page && (uintptr_t)a.zero_page % 16 == 0 &&
          a.conv_H > 0 && a.conv_W > 0 && (a.conv_inH << a.conv_up_shift) < 32768 && (a.conv_inW << a.conv_up_shift) < 32768 &&
          (int64_t)a.M * 1 == (int64_t)a.conv_H * a.conv_W * (a.M / (a.conv_H * a.conv_W)) && a.M % (a.conv_H * a.conv_W) == 0;
 }

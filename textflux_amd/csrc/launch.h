@@ -95,6 +95,19 @@ int add_bf16(const void* a, const void* b, void* out, int64_t n, hipStream_t st)
 int scatter_cols(const void* src, void* dst, int64_t rows, int C, int64_t ld, int col0, hipStream_t st);
 int copy_rows(const void* src, int64_t sld, int64_t sbs, void* dst, int64_t dld, int64_t dbs, int rows, int cols,
               int batch, hipStream_t st);
+// image / latent layout kernels around the VAE and the helpers of its mid-block attention (imageops.hip)
+int any_negative(const void* x, int dtype, int64_t n, int* flag, hipStream_t st);
+int prep_image(const void* img, int img_dtype, const void* mask, int mask_dtype, void* out, int B, int C, int H, int W,
+               int mask_b, int norm_mode, int binarize, const int* neg_flag, hipStream_t st);
+int pack_mask(const void* mask, int mask_dtype, void* out, int B, int H, int W, int mask_b, int binarize, int64_t ld, int col0,
+              hipStream_t st);
+int sample_pack(const void* moments, const void* eps, int eps_dtype, void* out, int B, int h, int w, int L, float shift,
+                float scale, int64_t ld, int col0, hipStream_t st);
+int unpack_latents(const void* lat, int64_t ld, void* out, int B, int h, int w, int L, float shift, float scale, hipStream_t st);
+int postprocess(const void* x, void* out, int B, int64_t HW, int Cs, int C, int mode, int denorm, hipStream_t st);
+int transpose_bf16(const void* in, int64_t ldi, int64_t ibs, void* out, int64_t ldo, int64_t obs, int N, int C, int batch,
+                   hipStream_t st);
+int row_softmax(void* s, int64_t ld, int rows, int N, float scale, hipStream_t st);
 int select_step(const void* table, void* cur, int64_t per_step_elems, int* step_ptr, hipStream_t st);
 int advance_step(int* step_ptr, hipStream_t st);
 

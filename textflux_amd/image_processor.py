@@ -1,7 +1,12 @@
-"""Host-side image pre/post-processing of the Fill pipeline (PIL / numpy / torch in, torch out), restating
-VaeImageProcessor (reference: diffusers/src/diffusers/image_processor.py: preprocess :587-716, postprocess :718-771,
-binarize :523-538, denormalize :227-239, pt_to_numpy :196-209, numpy_to_pil :133-154).  Stays in Python by design
-("host-side PIL/numpy; keep in Python")."""
+"""Image pre/post-processing of the Fill pipeline, restating VaeImageProcessor (reference:
+diffusers/src/diffusers/image_processor.py: preprocess :587-716, postprocess :718-771, binarize :523-538, denormalize
+:227-239, pt_to_numpy :196-209, numpy_to_pil :133-154).
+
+Two layers: `to_raw()` is the host part that has to stay on the host (PIL decoding / resizing, list handling) and returns
+the still un-normalised pixels -- uint8 for PIL inputs --; the arithmetic (value / 255, 2x - 1, binarise, image * (1 - mask),
+the bf16 cast and the NHWC layout) then runs on the device in `tfx_prep_image` / `tfx_pack_mask` (pipeline.py).
+`preprocess()` / `postprocess()` keep the reference's all-host tensor interface (used by callers that want the tensors, and
+as the CPU-testable statement of the same arithmetic)."""
 from __future__ import annotations
 
 from typing import List, Optional, Union
@@ -55,6 +60,45 @@ class VaeImageProcessor:
         image[image < 0.5] = 0
         image[image >= 0.5] = 1
         return image
+
+    # -- host half of the device path ------------------------------------------------------------------------
+    def to_raw(self, image, height: Optional[int] = None, width: Optional[int] = None) -> torch.Tensor:
+        """Same input handling as `preprocess` (formats, lists, resize, RGB / grayscale conversion) WITHOUT the arithmetic:
+        returns uint8 [B, H, W, C] ([B, H, W] for grayscale) for PIL inputs, float32 [B, C, H, W] for numpy / torch
+        inputs.  Normalisation / binarisation are left to the device kernels."""
+        if self.do_convert_grayscale and isinstance(image, (torch.Tensor, np.ndarray)) and image.ndim == 3:
+            if isinstance(image, torch.Tensor):
+                image = image.unsqueeze(1)
+            else:
+                image = np.expand_dims(image, axis=0 if image.shape[-1] == 1 else -1)
+        if not isinstance(image, list):
+            image = [image]
+        first = image[0]
+        if isinstance(first, PIL.Image.Image):
+            if self.do_resize:
+                height, width = self.get_default_height_width(first, height, width)
+                image = [self._resize(i, height, width) for i in image]
+            if self.do_convert_rgb:
+                image = [i.convert("RGB") for i in image]
+            elif self.do_convert_grayscale:
+                image = [i.convert("L") for i in image]
+            arr = [np.array(i) for i in image]
+            if any(a.dtype != np.uint8 for a in arr):   # 16-bit / float PIL modes: the all-host arithmetic
+                return self.numpy_to_pt(self.pil_to_numpy(image))
+            return torch.from_numpy(np.stack(arr, axis=0))
+        if isinstance(first, np.ndarray):
+            image = np.concatenate(image, axis=0) if first.ndim == 4 else np.stack(image, axis=0)
+            image = self.numpy_to_pt(image)
+        elif isinstance(first, torch.Tensor):
+            image = torch.cat(image, dim=0) if first.ndim == 4 else torch.stack(image, dim=0)
+            if self.do_convert_grayscale and image.ndim == 3:
+                image = image.unsqueeze(1)
+        else:
+            raise ValueError("Input is in incorrect format. Currently, we only support PIL.Image.Image, np.ndarray, torch.Tensor")
+        height, width = self.get_default_height_width(image, height, width)
+        if self.do_resize and tuple(image.shape[-2:]) != (height, width):
+            image = self._resize(image, height, width)
+        return image.float()
 
     # -- preprocess ----------------------------------------------------------------------------------------
     def preprocess(self, image, height: Optional[int] = None, width: Optional[int] = None) -> torch.Tensor:

@@ -325,3 +325,118 @@ def groupnorm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     L.check(L.lib().tfx_groupnorm_nhwc(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), B,
                                        HW, C, groups, eps, 1 if silu else 0, _stream()), "groupnorm_nhwc")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# pixel / latent layout steps around the VAE (imageops.hip)
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.uint8: 2}
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype not in _DT:
+        raise TypeError(f"unsupported dtype {t.dtype} (float32, bfloat16 or uint8)")
+    return _DT[t.dtype]
+
+
+def any_negative(x: torch.Tensor, flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32 device flag, set when x has a negative element (no host sync)."""
+    _chk_dev(x, flag)
+    x = x.contiguous()
+    if flag is None:
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    L.check(L.lib().tfx_any_negative(x.data_ptr(), _dt(x), x.numel(), flag.data_ptr(), _stream()), "any_negative")
+    return flag
+
+
+def prep_image(img: torch.Tensor, mask: Optional[torch.Tensor] = None, norm_mode: int = 0, binarize: bool = True,
+               neg_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Encoder input [B, H, W, 8] bf16 NHWC = bf16(norm(img) * (1 - mask)).  img: [B, C, H, W] float32 / bfloat16, or
+    [B, H, W, C] uint8 (value / 255); mask: [Bm, 1, H, W] / [Bm, H, W] float32 or uint8, Bm in {1, B}."""
+    _chk_dev(img, mask, neg_flag)
+    img = img.contiguous()
+    if img.dtype == torch.uint8:
+        B, H, W, Cc = img.shape
+    else:
+        B, Cc, H, W = img.shape
+    mb = 1
+    if mask is not None:
+        mask = mask.contiguous()
+        mb = mask.shape[0]
+        assert mask.numel() == mb * H * W, "mask must be [Bm, 1, H, W] or [Bm, H, W] at the image size"
+    out = torch.empty(B, H, W, 8, dtype=BF16, device=img.device)
+    L.check(L.lib().tfx_prep_image(img.data_ptr(), _dt(img), _p(mask), _dt(mask) if mask is not None else 0, out.data_ptr(),
+                                   B, Cc, H, W, mb, norm_mode, 1 if binarize else 0, _p(neg_flag), _stream()), "prep_image")
+    return out
+
+
+def pack_mask(mask: torch.Tensor, out: torch.Tensor, col0: int, B: int, H: int, W: int, binarize: bool = True) -> torch.Tensor:
+    """out[b, :, col0 : col0 + 256] = packed mask (out: [B, S, ld] bf16)."""
+    _chk_dev(mask, out)
+    mask = mask.contiguous()
+    mb = mask.shape[0]
+    assert mask.numel() == mb * H * W and out.dtype == BF16 and out.is_contiguous()
+    L.check(L.lib().tfx_pack_mask(mask.data_ptr(), _dt(mask), out.data_ptr(), B, H, W, mb, 1 if binarize else 0,
+                                  out.shape[-1], col0, _stream()), "pack_mask")
+    return out
+
+
+def vae_sample_pack(moments: torch.Tensor, eps: Optional[torch.Tensor], out: torch.Tensor, col0: int, shift: float,
+                    scale: float) -> torch.Tensor:
+    """moments [B, h, w, 2L] NHWC bf16, eps [B, L, h, w] (None: the mode) -> out[b, :, col0 : col0 + 4L]."""
+    _chk_dev(moments, eps, out)
+    B, h, w, L2 = moments.shape
+    assert moments.is_contiguous() and moments.dtype == BF16 and out.dtype == BF16 and out.is_contiguous()
+    if eps is not None:
+        eps = eps.contiguous()
+        assert eps.shape == (B, L2 // 2, h, w)
+    L.check(L.lib().tfx_vae_sample_pack(moments.data_ptr(), _p(eps), _dt(eps) if eps is not None else 1, out.data_ptr(), B, h,
+                                        w, L2 // 2, shift, scale, out.shape[-1], col0, _stream()), "vae_sample_pack")
+    return out
+
+
+def unpack_latents(lat: torch.Tensor, h: int, w: int, shift: float, scale: float) -> torch.Tensor:
+    """lat [B, (h/2)(w/2), 4L] bf16 -> z [B, h, w, L] NHWC bf16 = lat / scale + shift."""
+    _chk_dev(lat)
+    assert lat.dtype == BF16 and lat.stride(-1) == 1 and lat.dim() == 3
+    B, S, C4 = lat.shape
+    assert S == (h // 2) * (w // 2) and lat.stride(0) == S * lat.stride(1)
+    out = torch.empty(B, h, w, C4 // 4, dtype=BF16, device=lat.device)
+    L.check(L.lib().tfx_unpack_latents(lat.data_ptr(), lat.stride(1), out.data_ptr(), B, h, w, C4 // 4, shift, scale,
+                                       _stream()), "unpack_latents")
+    return out
+
+
+def postprocess(x: torch.Tensor, C: int, mode: str, denorm: bool = True) -> torch.Tensor:
+    """x [B, H, W, Cs] NHWC bf16 -> "pt": [B, C, H, W] bf16 | "np": [B, H, W, C] f32 | "u8": [B, H, W, C] uint8 |
+    "pt32": [B, C, H, W] f32."""
+    _chk_dev(x)
+    assert x.is_contiguous() and x.dtype == BF16
+    B, H, W, Cs = x.shape
+    code = {"pt": 0, "np": 1, "u8": 2, "pt32": 3}[mode]
+    if code in (0, 3):
+        out = torch.empty(B, C, H, W, dtype=BF16 if code == 0 else torch.float32, device=x.device)
+    else:
+        out = torch.empty(B, H, W, C, dtype=torch.float32 if code == 1 else torch.uint8, device=x.device)
+    L.check(L.lib().tfx_postprocess(x.data_ptr(), out.data_ptr(), B, H * W, Cs, C, code, 1 if denorm else 0, _stream()),
+            "postprocess")
+    return out
+
+
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[B, N, C] -> [B, C, N] (bf16)."""
+    _chk_dev(x, out)
+    assert x.dim() == 3 and x.dtype == BF16 and x.stride(-1) == 1
+    B, N, Cc = x.shape
+    if out is None:
+        out = torch.empty(B, Cc, N, dtype=BF16, device=x.device)
+    L.check(L.lib().tfx_transpose(x.data_ptr(), x.stride(1), x.stride(0), out.data_ptr(), out.stride(1), out.stride(0), N, Cc,
+                                  B, _stream()), "transpose")
+    return out
+
+
+def row_softmax_(s: torch.Tensor, scale: float) -> torch.Tensor:
+    """In place softmax(scale * s) over the last dim of a 2-D bf16 matrix."""
+    _chk_dev(s)
+    assert s.dim() == 2 and s.dtype == BF16 and s.stride(1) == 1
+    L.check(L.lib().tfx_row_softmax(s.data_ptr(), s.stride(0), s.shape[0], s.shape[1], scale, _stream()), "row_softmax")
+    return s

@@ -336,33 +336,75 @@ class FluxFillPipeline:
 
     def prepare_mask_latents(self, mask, masked_image, batch_size, num_channels_latents, num_images_per_prompt, height,
                              width, dtype, device, generator):
-        """P:1505-1583."""
+        """P:1505-1583, same arguments and results ((mask [B,S,256], masked_image_latents [B,S,64])); the arithmetic runs in
+        the layout kernels (tfx_prep_image -> VAE encoder -> tfx_vae_sample_pack, tfx_pack_mask)."""
         height = 2 * (int(height) // (self.vae_scale_factor * 2))
         width = 2 * (int(width) // (self.vae_scale_factor * 2))
-        if masked_image.shape[1] == num_channels_latents:
-            mil = masked_image
+        dev = self._execution_device
+        total = batch_size * num_images_per_prompt
+        if masked_image.shape[1] == num_channels_latents:      # already latents: only shift / scale / pack (P:1525-1530)
+            mil = (masked_image.to(dev, BF16) - self.vae.config.shift_factor) * self.vae.config.scaling_factor
+            mil = self._pack_latents(mil, mil.shape[0], num_channels_latents, height, width)
         else:
-            mil = self.vae.encode(masked_image).latent_dist.sample(generator=generator)
-        mil = (mil - self.vae.config.shift_factor) * self.vae.config.scaling_factor
-        mil = mil.to(device=device, dtype=dtype)
-        batch_size = batch_size * num_images_per_prompt
-        if mask.shape[0] < batch_size:
-            if not batch_size % mask.shape[0] == 0:
+            x8 = ops.prep_image(masked_image.to(dev), None, norm_mode=0)
+            mil = self._sample_and_pack(self.vae.encode_moments_nhwc(x8), generator, dtype, dev)
+        mk = torch.empty(mask.shape[0], mil.shape[1], self.vae_scale_factor ** 2 * 4, dtype=BF16, device=dev)
+        ops.pack_mask(mask.to(dev, torch.float32), mk, 0, mask.shape[0], mask.shape[-2], mask.shape[-1], binarize=False)
+        if mk.shape[0] < total:
+            if not total % mk.shape[0] == 0:
                 raise ValueError("The passed mask and the required batch size don't match. Masks are supposed to be duplicated to"
-                                 f" a total batch size of {batch_size}, but {mask.shape[0]} masks were passed.")
-            mask = mask.repeat(batch_size // mask.shape[0], 1, 1, 1)
-        if mil.shape[0] < batch_size:
-            if not batch_size % mil.shape[0] == 0:
+                                 f" a total batch size of {total}, but {mk.shape[0]} masks were passed.")
+            mk = mk.repeat(total // mk.shape[0], 1, 1)
+        if mil.shape[0] < total:
+            if not total % mil.shape[0] == 0:
                 raise ValueError("The passed images and the required batch size don't match. Images are supposed to be duplicated"
-                                 f" to a total batch size of {batch_size}, but {mil.shape[0]} images were passed.")
-            mil = mil.repeat(batch_size // mil.shape[0], 1, 1, 1)
-        mil = self._pack_latents(mil, batch_size, num_channels_latents, height, width)
-        mask = mask[:, 0, :, :]
-        mask = mask.view(batch_size, height, self.vae_scale_factor, width, self.vae_scale_factor)
-        mask = mask.permute(0, 2, 4, 1, 3)
-        mask = mask.reshape(batch_size, self.vae_scale_factor * self.vae_scale_factor, height, width)
-        mask = self._pack_latents(mask, batch_size, self.vae_scale_factor * self.vae_scale_factor, height, width)
-        return mask.to(device=device, dtype=dtype), mil
+                                 f" to a total batch size of {total}, but {mil.shape[0]} images were passed.")
+            mil = mil.repeat(total // mil.shape[0], 1, 1)
+        return mk.to(device=device, dtype=dtype), mil.to(device=device, dtype=dtype)
+
+    def _sample_and_pack(self, moments, generator, dtype, dev, out=None, col0=0):
+        """Posterior sample + (z - shift) * scale + 2x2 patchify in one kernel; eps is drawn exactly as the reference's
+        `latent_dist.sample(generator)` draws it (randn_tensor of the NCHW latent shape in the pipeline dtype, P:1528)."""
+        B, h, w, C2 = moments.shape
+        eps = randn_tensor((B, C2 // 2, h, w), generator=generator, device=dev, dtype=dtype)
+        if out is None:
+            out = torch.empty(B, (h // 2) * (w // 2), 2 * C2, dtype=BF16, device=dev)
+        c = self.vae.config
+        return ops.vae_sample_pack(moments, eps.to(dev), out, col0, c.shift_factor, c.scaling_factor)
+
+    def _encode_conditioning(self, image, mask_image, height, width, batch_size, num_images_per_prompt, dtype, device, generator):
+        """image + mask_image (PIL / numpy / torch, as the reference accepts them) -> masked_image_latents [B, S, 320] =
+        [VAE latents of image * (1 - mask) | packed mask] (P:2027-2046).  Host work: decoding / resizing only
+        (VaeImageProcessor.to_raw); everything else is device kernels on NHWC tensors."""
+        dev = self._execution_device
+        raw = self.image_processor.to_raw(image, height=height, width=width)
+        rawm = self.mask_processor.to_raw(mask_image, height=height, width=width)
+        u8 = raw.dtype == torch.uint8
+        H, W = (raw.shape[1], raw.shape[2]) if u8 else (raw.shape[2], raw.shape[3])
+        if not u8 and raw.shape[1] == self.vae.config.latent_channels:
+            return None, H, W                                     # `image` already holds latents: reference-shaped path
+        Hm, Wm = (rawm.shape[1], rawm.shape[2]) if rawm.dtype == torch.uint8 else (rawm.shape[2], rawm.shape[3])
+        if (Hm, Wm) != (H, W):
+            raise ValueError(f"image ({H}x{W}) and mask ({Hm}x{Wm}) sizes differ after preprocessing")
+        raw, rawm = raw.to(dev), rawm.to(dev)
+        if u8:
+            x8 = ops.prep_image(raw, rawm, norm_mode=1)
+        else:
+            flag = ops.any_negative(raw) if self.image_processor.do_normalize else None
+            x8 = ops.prep_image(raw, rawm, norm_mode=2 if flag is not None else 0, neg_flag=flag)
+        B = x8.shape[0]
+        total = batch_size * num_images_per_prompt
+        moments = self.vae.encode_moments_nhwc(x8)
+        S = (H // 16) * (W // 16)
+        cond = torch.empty(B, S, 4 * self.vae.config.latent_channels + 256, dtype=BF16, device=dev)
+        self._sample_and_pack(moments, generator, dtype, dev, out=cond, col0=0)
+        ops.pack_mask(rawm, cond, 4 * self.vae.config.latent_channels, B, H, W, binarize=True)
+        if B < total:
+            if total % B:
+                raise ValueError("The passed images and the required batch size don't match. Images are supposed to be duplicated"
+                                 f" to a total batch size of {total}, but {B} images were passed.")
+            cond = cond.repeat(total // B, 1, 1)
+        return cond, H, W
 
     def check_inputs(self, prompt, prompt_2, height, width, prompt_embeds=None, pooled_prompt_embeds=None,
                      callback_on_step_end_tensor_inputs=None, max_sequence_length=None, image=None, mask_image=None,
@@ -529,6 +571,27 @@ class FluxFillPipeline:
             progress_bar.update()
         return latents
 
+    def _decode_to_output(self, latents, height, width, output_type):
+        """P:2126-2129 + VaeImageProcessor.postprocess: un-patchify, z / scale + shift, VAE decode, denormalise, and the
+        output layout, all on NHWC device tensors; only the finished uint8 / float32 image crosses to the host."""
+        if output_type not in ("pt", "np", "pil"):
+            raise ValueError(f"unknown output_type {output_type}")
+        c = self.vae.config
+        h = 2 * (int(height) // (self.vae_scale_factor * 2))
+        w = 2 * (int(width) // (self.vae_scale_factor * 2))
+        z = ops.unpack_latents(latents.to(self._execution_device, BF16).contiguous(), h, w, c.shift_factor, c.scaling_factor)
+        img = self.vae.decode_nhwc(z)
+        denorm = self.image_processor.do_normalize
+        if output_type == "pt":
+            return ops.postprocess(img, c.out_channels, "pt", denorm)
+        if output_type == "np":
+            return ops.postprocess(img, c.out_channels, "np", denorm).cpu().numpy()
+        import PIL.Image
+        u8 = ops.postprocess(img, c.out_channels, "u8", denorm).cpu().numpy()
+        if u8.shape[-1] == 1:
+            return [PIL.Image.fromarray(a.squeeze(), mode="L") for a in u8]
+        return [PIL.Image.fromarray(a) for a in u8]
+
     @torch.no_grad()
     def __call__(self, prompt: Union[str, List[str]] = None, prompt_2: Optional[Union[str, List[str]]] = None,
                  image=None, mask_image=None, masked_image_latents: Optional[torch.Tensor] = None,
@@ -569,15 +632,16 @@ class FluxFillPipeline:
         if masked_image_latents is not None:
             masked_image_latents = masked_image_latents.to(latents.device)
         else:
-            image = self.image_processor.preprocess(image, height=height, width=width)
-            mask_image = self.mask_processor.preprocess(mask_image, height=height, width=width)
-            masked_image = image * (1 - mask_image)
-            masked_image = masked_image.to(device=device, dtype=prompt_embeds.dtype)
-            height, width = image.shape[-2:]
-            mask, masked_image_latents = self.prepare_mask_latents(
-                mask_image, masked_image, batch_size, num_channels_latents, num_images_per_prompt, height, width,
-                prompt_embeds.dtype, device, generator)
-            masked_image_latents = torch.cat((masked_image_latents, mask), dim=-1)
+            masked_image_latents, height, width = self._encode_conditioning(
+                image, mask_image, height, width, batch_size, num_images_per_prompt, prompt_embeds.dtype, device, generator)
+            if masked_image_latents is None:    # `image` was given as VAE latents (P:1525): the reference-shaped sequence
+                image = self.image_processor.preprocess(image, height=height, width=width)
+                mask_image = self.mask_processor.preprocess(mask_image, height=height, width=width)
+                masked_image = (image * (1 - mask_image)).to(device=device, dtype=prompt_embeds.dtype)
+                mask, masked_image_latents = self.prepare_mask_latents(
+                    mask_image, masked_image, batch_size, num_channels_latents, num_images_per_prompt, height, width,
+                    prompt_embeds.dtype, device, generator)
+                masked_image_latents = torch.cat((masked_image_latents, mask), dim=-1)
         sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps) if sigmas is None else sigmas
         image_seq_len = latents.shape[1]
         sc = self.scheduler.config
@@ -600,10 +664,7 @@ class FluxFillPipeline:
         if output_type == "latent":
             image = latents
         else:
-            latents = self._unpack_latents(latents, height, width, self.vae_scale_factor)
-            latents = (latents / self.vae.config.scaling_factor) + self.vae.config.shift_factor
-            image = self.vae.decode(latents, return_dict=False)[0]
-            image = self.image_processor.postprocess(image, output_type=output_type)
+            image = self._decode_to_output(latents, height, width, output_type)
         self.maybe_free_model_hooks()
         if not return_dict:
             return (image,)

@@ -1,14 +1,19 @@
-"""FLUX AutoencoderKL for the two ends of the path (masked-image encode, final decode).
+"""FLUX AutoencoderKL for the two ends of the path (masked-image encode, final decode) on the gfx950 kernels.
 
 Reference: AutoencoderKL.encode/decode D/models/autoencoders/autoencoder_kl.py:263-332 and the blocks cited in
-oracle/vae_oracle.py.  Two execution paths over the same weights (reference state-dict keys, so the HF
-`vae/diffusion_pytorch_model.safetensors` loads as is):
-* HIP / NHWC (default whenever every block width is a multiple of 64, i.e. the FLUX VAE 128/256/512): activations stay
-  NHWC bf16; every 3x3 convolution is an implicit GEMM on the MFMA kernel (`tfx_conv3x3_nhwc`: nearest-2x upsample and
-  the (0,1,0,1)-padded stride-2 downsample are folded into its gather, the residual add into its epilogue), GroupNorm+SiLU
-  is `tfx_groupnorm_nhwc`, 1x1 shortcuts and the mid-block attention projections are plain `tfx_gemm_bf16` calls.  Still
-  through torch: conv_in (3 or 16 input channels), the single-head dim-512 mid-block softmax (F.scaled_dot_product_attention).
-* torch / NCHW (tiny test configurations whose widths are not multiples of 64): F.conv2d / F.group_norm via MIOpen.
+oracle/vae_oracle.py.  Weights keep the reference's state-dict keys (the HF `vae/diffusion_pytorch_model.safetensors`
+loads as is).  ONE execution path: activations are NHWC bf16 from the first to the last kernel;
+* every 3x3 convolution is an implicit GEMM on the MFMA kernel (`tfx_conv3x3_nhwc`: the nearest-2x upsample and the
+  (0,1,0,1)-padded stride-2 downsample are folded into its gather, the residual add into its epilogue); the two `conv_in`
+  layers (3 / 16 input channels) use its narrow-input form (channels padded to 8 / 16, K padded to 128 / 192);
+* GroupNorm(+SiLU) is `tfx_groupnorm_nhwc`; 1x1 shortcuts and the mid-block's q/k/v/out projections are `tfx_gemm_bf16`;
+* the mid-block attention (ONE head of dim 512 over h*w tokens, AttnProcessor2_0 D/models/attention_processor.py:2799-2881)
+  runs as scores = q k^T (MFMA GEMM) -> `tfx_row_softmax` (fp32 statistics) -> P v (MFMA GEMM against v^T from
+  `tfx_transpose`), one image at a time through a reused [N, N] bf16 score buffer;
+* the pipeline hands over / takes back NHWC tensors through `encode_moments_nhwc` / `decode_nhwc` (imageops.hip kernels on
+  either side); `encode` / `decode` keep the reference's NCHW tensor interface on top of the same path.
+Configurations the kernels do not cover (block widths that are not multiples of 64) raise at load time: there is no
+torch / MIOpen fallback.
 """
 from __future__ import annotations
 
@@ -18,7 +23,8 @@ from types import SimpleNamespace
 from typing import Dict, Optional, Tuple
 
 import torch
-import torch.nn.functional as F
+
+from . import ops
 
 
 class _Config(SimpleNamespace):
@@ -27,9 +33,11 @@ class _Config(SimpleNamespace):
 
 
 class DiagonalGaussianDistribution:
-    """mean / logvar split, logvar clamped to [-30, 20] (D/models/autoencoders/vae.py:781-802)."""
+    """mean / logvar split, logvar clamped to [-30, 20] (D/models/autoencoders/vae.py:781-802).  Interface object of the
+    NCHW `encode()`; the pipeline itself samples + packs in one kernel (`tfx_vae_sample_pack`)."""
 
     def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
         self.mean, logvar = torch.chunk(parameters, 2, dim=1)
         self.logvar = torch.clamp(logvar, -30.0, 20.0)
         self.std = torch.exp(0.5 * self.logvar)
@@ -43,6 +51,14 @@ class DiagonalGaussianDistribution:
         return self.mean
 
 
+def _narrow(cin: int) -> int:
+    """Channel count a narrow (< 64) conv input is padded to."""
+    for c in (8, 16, 32):
+        if cin <= c:
+            return c
+    raise ValueError(f"conv input width {cin} is not supported by the gfx950 conv kernel (<= 32 or a multiple of 64)")
+
+
 class AutoencoderKL:
     def __init__(self, in_channels: int = 3, out_channels: int = 3, block_out_channels: Tuple[int, ...] = (128, 256, 512, 512),
                  layers_per_block: int = 2, latent_channels: int = 16, norm_num_groups: int = 32,
@@ -51,14 +67,23 @@ class AutoencoderKL:
                               block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
                               latent_channels=latent_channels, norm_num_groups=norm_num_groups,
                               scaling_factor=scaling_factor, shift_factor=shift_factor)
+        bad = [ch for ch in self.config.block_out_channels
+               if ch % 64 or (ch // norm_num_groups) % 4 or 256 % (ch // 8) or ch % norm_num_groups]
+        if bad or in_channels > 8 or out_channels > 8 or latent_channels % 8 or latent_channels > 32:
+            raise ValueError(f"AutoencoderKL config outside the gfx950 kernels' range: block widths {bad or '-'} must be "
+                             "multiples of 64 with (width / groups) % 4 == 0; in/out channels <= 8; latent channels 8/16/24/32")
         self.sd: Dict[str, torch.Tensor] = {}
+        self.hw: Dict[str, torch.Tensor] = {}
         self.dtype, self.device = torch.bfloat16, torch.device("cpu")
-        self.use_hip, self.hw = False, {}
+        self._scores: Optional[torch.Tensor] = None
 
+    # ---- weights ------------------------------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor], device="cuda", dtype=torch.bfloat16):
+        if dtype != torch.bfloat16:
+            raise ValueError("the HIP VAE computes in bf16")
         self.sd = {k: v.to(device=device, dtype=dtype) for k, v in sd.items()}
         self.dtype, self.device = dtype, torch.device(device)
-        self._prep_hip()
+        self._prep()
         return self
 
     def init_random_(self, seed: int = 0, device="cuda", dtype=torch.bfloat16):
@@ -85,152 +110,131 @@ class AutoencoderKL:
         keys = ("in_channels", "out_channels", "block_out_channels", "layers_per_block", "latent_channels",
                 "norm_num_groups", "scaling_factor", "shift_factor")
         m = cls(**{k: cfg[k] for k in keys if k in cfg})
-        return m.load_state_dict(load_file(os.path.join(root, "diffusion_pytorch_model.safetensors")), device, torch_dtype)
+        sd = load_file(os.path.join(root, "diffusion_pytorch_model.safetensors"))
+        missing = [k for k in m._shapes() if k not in sd]
+        if missing:
+            raise RuntimeError(f"VAE checkpoint is missing {len(missing)} tensors, e.g. {missing[:3]}")
+        return m.load_state_dict(sd, device, torch_dtype or torch.bfloat16)
 
     def to(self, device=None, dtype=None):
         if self.sd and (device is not None or dtype is not None):
             self.load_state_dict(self.sd, device or self.device, dtype or self.dtype)
         return self
 
-    # ---- HIP / NHWC path ---------------------------------------------------------------------------------------
-    def _prep_hip(self):
-        c = self.config
-        cpg_ok = all((ch // c.norm_num_groups) % 4 == 0 and 256 % (ch // 8) == 0 for ch in c.block_out_channels)
-        self.use_hip = (self.device.type == "cuda" and self.dtype == torch.bfloat16 and cpg_ok
-                        and all(ch % 64 == 0 for ch in c.block_out_channels))
-        self.hw: Dict[str, torch.Tensor] = {}
-        if not self.use_hip:
-            return
+    def _prep(self):
+        """Kernel-side weight layouts: 3x3 filters as [Cout, 3, 3, Cin] (KRSC) rows -- narrow inputs channel-padded and
+        K-padded with zeros, conv_out's 3 filters padded to 8 --, 1x1 shortcuts as matrices."""
+        self.hw = {}
         for k, v in self.sd.items():
-            if k.endswith(".weight") and v.dim() == 4:
-                if v.shape[2] == 3 and v.shape[1] % 64 == 0:
-                    w = v.permute(0, 2, 3, 1).contiguous()                   # [Cout, 3, 3, Cin]  (KRSC)
-                    if w.shape[0] % 8:                                       # conv_out: pad Cout 3 -> 8 (zero filters)
-                        pad = 8 - w.shape[0] % 8
-                        w = torch.cat([w, torch.zeros(pad, *w.shape[1:], dtype=w.dtype, device=w.device)], 0)
-                        b = self.sd[k[:-7] + ".bias"]
-                        self.hw[k[:-7] + ".bias"] = torch.cat([b, torch.zeros(pad, dtype=b.dtype, device=b.device)], 0)
-                    self.hw[k] = w
-                elif v.shape[2] == 1:
-                    self.hw[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()   # 1x1 shortcut as a matrix
+            if not (k.endswith(".weight") and v.dim() == 4):
+                continue
+            name = k[:-7]
+            if v.shape[2] == 1:
+                self.hw[k] = v.reshape(v.shape[0], v.shape[1]).contiguous()
+                continue
+            w = v.permute(0, 2, 3, 1).contiguous()                       # [Cout, 3, 3, Cin]
+            cout, cin = w.shape[0], w.shape[3]
+            if cin % 64:
+                cp = _narrow(cin)
+                wp = torch.zeros(cout, 3, 3, cp, dtype=w.dtype, device=w.device)
+                wp[..., :cin] = w
+                kp = (9 * cp + 63) // 64 * 64
+                w = torch.zeros(cout, kp, dtype=w.dtype, device=w.device)
+                w[:, :9 * cp] = wp.reshape(cout, 9 * cp)
+            if cout % 8:
+                pad = 8 - cout % 8
+                w = torch.cat([w, torch.zeros(pad, *w.shape[1:], dtype=w.dtype, device=w.device)], 0)
+                b = self.sd[name + ".bias"]
+                self.hw[name + ".bias"] = torch.cat([b, torch.zeros(pad, dtype=b.dtype, device=b.device)], 0)
+            self.hw[k] = w.contiguous()
 
-    def _hconv(self, x, name, **kw):
-        from . import ops
+    # ---- building blocks ----------------------------------------------------------------------------------------
+    def _conv(self, x, name, **kw):
         return ops.conv3x3_nhwc(x, self.hw[name + ".weight"], self.hw.get(name + ".bias", self.sd[name + ".bias"]), **kw)
 
-    def _hgn(self, x, name, silu=True):
-        from . import ops
+    def _gn(self, x, name, silu=True):
         return ops.groupnorm_nhwc(x, self.sd[name + ".weight"], self.sd[name + ".bias"], self.config.norm_num_groups, silu=silu)
 
-    def _hres(self, x, p):
-        from . import ops
-        h = self._hconv(self._hgn(x, p + ".norm1"), p + ".conv1")
-        h = self._hgn(h, p + ".norm2")
+    def _res(self, x, p):
+        h = self._conv(self._gn(x, p + ".norm1"), p + ".conv1")
+        h = self._gn(h, p + ".norm2")
         if p + ".conv_shortcut.weight" in self.sd:
             B, H, W, C = x.shape
             x = ops.gemm(x.view(B * H * W, C), self.hw[p + ".conv_shortcut.weight"], self.sd[p + ".conv_shortcut.bias"]).view(B, H, W, -1)
-        return self._hconv(h, p + ".conv2", res=x)
-
-    def _hmid(self, x, p):
-        from . import ops
-        x = self._hres(x, p + ".resnets.0")
-        B, H, W, C = x.shape
-        a = p + ".attentions.0"
-        tok = x.view(B, H * W, C)
-        h = self._hgn(tok, a + ".group_norm", silu=False)
-        q, k, v = (ops.gemm(h, self.sd[f"{a}.{n}.weight"], self.sd[f"{a}.{n}.bias"]) for n in ("to_q", "to_k", "to_v"))
-        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0].contiguous()   # one head of dim C
-        x = ops.gemm(o, self.sd[a + ".to_out.0.weight"], self.sd[a + ".to_out.0.bias"], epilogue=ops.EPI_BIAS_RES,
-                     res=tok).view(B, H, W, C)
-        return self._hres(x, p + ".resnets.1")
-
-    def _encoder_hip(self, x):
-        c = self.config
-        h = F.conv2d(x, self.sd["encoder.conv_in.weight"], self.sd["encoder.conv_in.bias"], padding=1)
-        h = h.permute(0, 2, 3, 1).contiguous()
-        n = len(c.block_out_channels)
-        for i in range(n):
-            for j in range(c.layers_per_block):
-                h = self._hres(h, f"encoder.down_blocks.{i}.resnets.{j}")
-            if i != n - 1:
-                h = self._hconv(h, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, pad_lo=0)
-        h = self._hmid(h, "encoder.mid_block")
-        h = self._hconv(self._hgn(h, "encoder.conv_norm_out"), "encoder.conv_out")
-        return h.permute(0, 3, 1, 2).contiguous()
-
-    def _decoder_hip(self, z):
-        c = self.config
-        h = F.conv2d(z, self.sd["decoder.conv_in.weight"], self.sd["decoder.conv_in.bias"], padding=1)
-        h = h.permute(0, 2, 3, 1).contiguous()
-        h = self._hmid(h, "decoder.mid_block")
-        n = len(c.block_out_channels)
-        for i in range(n):
-            for j in range(c.layers_per_block + 1):
-                h = self._hres(h, f"decoder.up_blocks.{i}.resnets.{j}")
-            if i != n - 1:
-                h = self._hconv(h, f"decoder.up_blocks.{i}.upsamplers.0.conv", up=2)
-        h = self._hconv(self._hgn(h, "decoder.conv_norm_out"), "decoder.conv_out")
-        return h[..., : c.out_channels].permute(0, 3, 1, 2).contiguous()
-
-    # ---- building blocks (torch ops on the ROCm device) ------------------------------------------------------
-    def _conv(self, x, name, stride=1, padding=1):
-        return F.conv2d(x, self.sd[name + ".weight"], self.sd[name + ".bias"], stride=stride, padding=padding)
-
-    def _gn(self, x, name):
-        return F.group_norm(x, self.config.norm_num_groups, self.sd[name + ".weight"], self.sd[name + ".bias"], eps=1e-6)
-
-    def _resnet(self, x, p):
-        h = self._conv(F.silu(self._gn(x, p + ".norm1")), p + ".conv1")
-        h = self._conv(F.silu(self._gn(h, p + ".norm2")), p + ".conv2")
-        if p + ".conv_shortcut.weight" in self.sd:
-            x = self._conv(x, p + ".conv_shortcut", padding=0)
-        return x + h
+        return self._conv(h, p + ".conv2", res=x)
 
     def _mid(self, x, p):
-        x = self._resnet(x, p + ".resnets.0")
-        B, C, H, W = x.shape
+        x = self._res(x, p + ".resnets.0")
+        B, H, W, C = x.shape
+        N = H * W
         a = p + ".attentions.0"
-        h = self._gn(x.view(B, C, H * W), a + ".group_norm").transpose(1, 2)
-        q, k, v = (F.linear(h, self.sd[f"{a}.{n}.weight"], self.sd[f"{a}.{n}.bias"]) for n in ("to_q", "to_k", "to_v"))
-        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
-        o = F.linear(o, self.sd[a + ".to_out.0.weight"], self.sd[a + ".to_out.0.bias"])
-        x = o.transpose(-1, -2).reshape(B, C, H, W) + x
-        return self._resnet(x, p + ".resnets.1")
+        tok = x.view(B, N, C)
+        h = self._gn(tok, a + ".group_norm", silu=False)
+        q, k, v = (ops.gemm(h, self.sd[f"{a}.{n}.weight"], self.sd[f"{a}.{n}.bias"]) for n in ("to_q", "to_k", "to_v"))
+        vt = ops.transpose(v)                                            # [B, C, N]
+        if self._scores is None or self._scores.numel() < N * N:
+            self._scores = None                                          # release before growing
+            self._scores = torch.empty(N * N, dtype=torch.bfloat16, device=x.device)
+        s = self._scores[:N * N].view(N, N)
+        o = torch.empty(B, N, C, dtype=torch.bfloat16, device=x.device)
+        for b in range(B):
+            ops.gemm(q[b], k[b], None, out=s)                            # scores [N, N] (bf16, as the math SDPA path)
+            ops.row_softmax_(s, C ** -0.5)
+            ops.gemm(s, vt[b], None, out=o[b])
+        x = ops.gemm(o, self.sd[a + ".to_out.0.weight"], self.sd[a + ".to_out.0.bias"], epilogue=ops.EPI_BIAS_RES,
+                     res=tok).view(B, H, W, C)
+        return self._res(x, p + ".resnets.1")
 
-    def _encoder(self, x):
+    # ---- NHWC entry points (what the pipeline uses) ----------------------------------------------------------------
+    @torch.no_grad()
+    def encode_moments_nhwc(self, x8: torch.Tensor) -> torch.Tensor:
+        """x8 [B, H, W, 8] NHWC bf16 (tfx_prep_image) -> posterior moments [B, H/8, W/8, 2 * latent] NHWC (mean | logvar)."""
         c = self.config
-        h = self._conv(x, "encoder.conv_in")
+        h = self._conv(x8, "encoder.conv_in")
         n = len(c.block_out_channels)
         for i in range(n):
             for j in range(c.layers_per_block):
-                h = self._resnet(h, f"encoder.down_blocks.{i}.resnets.{j}")
+                h = self._res(h, f"encoder.down_blocks.{i}.resnets.{j}")
             if i != n - 1:
-                h = self._conv(F.pad(h, (0, 1, 0, 1)), f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, padding=0)
+                h = self._conv(h, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, pad_lo=0)
         h = self._mid(h, "encoder.mid_block")
-        return self._conv(F.silu(self._gn(h, "encoder.conv_norm_out")), "encoder.conv_out")
+        return self._conv(self._gn(h, "encoder.conv_norm_out"), "encoder.conv_out")
 
-    def _decoder(self, z):
+    @torch.no_grad()
+    def decode_nhwc(self, z: torch.Tensor) -> torch.Tensor:
+        """z [B, h, w, latent] NHWC bf16 -> image [B, 8h, 8w, 8] NHWC bf16 (first out_channels channels valid)."""
         c = self.config
-        h = self._conv(z, "decoder.conv_in")
+        if z.shape[-1] != _narrow(c.latent_channels):
+            zp = torch.zeros(*z.shape[:-1], _narrow(c.latent_channels), dtype=z.dtype, device=z.device)
+            zp[..., : z.shape[-1]] = z
+            z = zp
+        h = self._conv(z.contiguous(), "decoder.conv_in")
         h = self._mid(h, "decoder.mid_block")
         n = len(c.block_out_channels)
         for i in range(n):
             for j in range(c.layers_per_block + 1):
-                h = self._resnet(h, f"decoder.up_blocks.{i}.resnets.{j}")
+                h = self._res(h, f"decoder.up_blocks.{i}.resnets.{j}")
             if i != n - 1:
-                h = self._conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), f"decoder.up_blocks.{i}.upsamplers.0.conv")
-        return self._conv(F.silu(self._gn(h, "decoder.conv_norm_out")), "decoder.conv_out")
+                h = self._conv(h, f"decoder.up_blocks.{i}.upsamplers.0.conv", up=2)
+        return self._conv(self._gn(h, "decoder.conv_norm_out"), "decoder.conv_out")
 
+    # ---- the reference's NCHW tensor interface -------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
-        x = x.to(self.device, self.dtype)
-        post = DiagonalGaussianDistribution(self._encoder_hip(x) if self.use_hip else self._encoder(x))
+        x = x.to(self.device)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        mom = self.encode_moments_nhwc(ops.prep_image(x, None, norm_mode=0))
+        B, h, w, C2 = mom.shape
+        post = DiagonalGaussianDistribution(ops.transpose(mom.view(B, h * w, C2)).view(B, C2, h, w))
         return SimpleNamespace(latent_dist=post) if return_dict else (post,)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None):
-        z = z.to(self.device, self.dtype)
-        out = self._decoder_hip(z) if self.use_hip else self._decoder(z)
+        z = z.to(self.device, self.dtype).contiguous()
+        B, L, h, w = z.shape
+        out = self.decode_nhwc(ops.transpose(z.view(B, L, h * w)).view(B, h, w, L))
+        out = ops.postprocess(out, self.config.out_channels, "pt", denorm=False)
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
     def _shapes(self):
