@@ -57,6 +57,11 @@ typedef struct tfx_gemm_args {
 } tfx_gemm_args;
 int tfx_gemm_bf16(const tfx_gemm_args* args, int variant, tfx_stream stream);
 
+/* Same operands, C = fp32 raw accumulators [batch][M, N] (ldc / c_bstride in floats, C 16-byte aligned); bias must be
+ * NULL and epilogue 0.  Used where a product must reach its consumer unrounded: the q k^T scores of the VAE mid-block
+ * attention (D/models/attention_processor.py:2858-2862) on their way to tfx_row_softmax. */
+int tfx_gemm_bf16_f32(const tfx_gemm_args* args, tfx_stream stream);
+
 /* ---- fp8 (OCP e4m3) variant of the same Linear, BASELINE config 5 "fp8 weights (CDNA4 fp8 MFMA)"; no reference
  *      counterpart (the reference computes in bf16).  A [batch][M, K] and W [N, K] hold one e4m3 byte per element
  *      (lda / ldw / a_bstride count elements = bytes), C = (A . W^T) * a_scale[b][m] * w_scale[n] + bias with the same
@@ -215,10 +220,12 @@ int tfx_unpack_latents(const void* latents, int64_t ld, void* out, int32_t B, in
 int tfx_postprocess(const void* x, void* out, int32_t B, int64_t HW, int32_t Cs, int32_t C, int32_t mode, int32_t denorm,
                     tfx_stream stream);
 /* helpers of the VAE mid-block attention (one head of dim C over h*w tokens, AttnProcessor2_0,
- * D/models/attention_processor.py:2799-2881): out[b][c, n] = in[b][n, c]; p = softmax(scale * s) over rows, in place. */
+ * D/models/attention_processor.py:2799-2881): out[b][c, n] = in[b][n, c]; p[r, :N] = bf16(softmax(scale * s[r, :N])) with
+ * s fp32 (row stride lds) from tfx_gemm_bf16_f32 and p bf16 (row stride ldp), fp32 statistics -- what a flash kernel
+ * keeps in registers, here through HBM because one head of dim 512 does not fit the 128-wide attention kernel. */
 int tfx_transpose(const void* in, int64_t ldi, int64_t in_bstride, void* out, int64_t ldo, int64_t out_bstride, int32_t N,
                   int32_t C, int32_t batch, tfx_stream stream);
-int tfx_row_softmax(void* s, int64_t ld, int32_t rows, int32_t N, float scale, tfx_stream stream);
+int tfx_row_softmax(const float* s, int64_t lds, void* p, int64_t ldp, int32_t rows, int32_t N, float scale, tfx_stream stream);
 
 /* ---- tuning knobs (no reference counterpart).  "attention_waves" selects the attention kernel: 10 (default) = one
  *      512-thread workgroup of 256 query rows per CU with the softmax bookkeeping on the matrix pipe (pre-scaled Q, lazy

@@ -22,6 +22,16 @@ def rnd(shape, seed, scale=1.0):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
+def dev_scalar(t: torch.Tensor, op: str, c: float) -> torch.Tensor:
+    """bf16 tensor (op) Python scalar as the reference's DEVICE kernels evaluate it: the scalar stays fp32 (opmath), a
+    division becomes a multiply by the fp32 reciprocal, the result is rounded to bf16 once.  (torch's CPU kernels round
+    the scalar to bf16 first; the kernels follow the GPU semantics -- see imageops.hip.)"""
+    x, cf = t.float(), torch.tensor(c, dtype=torch.float32)
+    r = {"sub": lambda: x - cf, "add": lambda: x + cf, "mul": lambda: x * cf,
+         "div": lambda: x * (torch.tensor(1.0) / cf)}[op]()
+    return r.to(BF)
+
+
 def ulp_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """Distance in bf16 representation steps (sign-magnitude -> ordered integers)."""
     def key(t):
@@ -84,7 +94,7 @@ def test_sample_pack_matches_bf16_reference_chain(ops):
     mean, logvar = mom.chunk(2, 1)
     std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))            # bf16 tensor ops = the reference's rounding points
     z = mean + std * eps
-    ref = po.pack_latents((z - 0.1159) * 0.3611)
+    ref = po.pack_latents(dev_scalar(dev_scalar(z, "sub", 0.1159), "mul", 0.3611))
     out = torch.zeros(B, (h // 2) * (w // 2), 320, dtype=BF, device="cuda")
     ops.vae_sample_pack(mom.permute(0, 2, 3, 1).contiguous().cuda(), eps.cuda(), out, 0, 0.1159, 0.3611)
     d = ulp_diff(out[..., :64], ref)
@@ -93,13 +103,13 @@ def test_sample_pack_matches_bf16_reference_chain(ops):
     # mode (no eps): exact
     out2 = torch.zeros(B, (h // 2) * (w // 2), 64, dtype=BF, device="cuda")
     ops.vae_sample_pack(mom.permute(0, 2, 3, 1).contiguous().cuda(), None, out2, 0, 0.1159, 0.3611)
-    assert torch.equal(out2.cpu(), po.pack_latents((mean - 0.1159) * 0.3611))
+    assert torch.equal(out2.cpu(), po.pack_latents(dev_scalar(dev_scalar(mean, "sub", 0.1159), "mul", 0.3611)))
 
 
 def test_unpack_latents_matches_reference_chain(ops, golden):
     g = golden("g6_layout")
     lat = rnd((2, 24, 64), 7).to(BF)
-    ref = po.unpack_latents(lat, 64, 96) / 0.3611 + 0.1159            # P:2126-2127 on bf16 tensors
+    ref = dev_scalar(dev_scalar(po.unpack_latents(lat, 64, 96), "div", 0.3611), "add", 0.1159)      # P:2126-2127
     got = ops.unpack_latents(lat.cuda(), 8, 12, 0.1159, 0.3611)
     assert got.shape == (2, 8, 12, 16)
     assert torch.equal(got.cpu(), ref.permute(0, 2, 3, 1))
@@ -127,9 +137,10 @@ def test_postprocess_modes(ops, denorm):
 def test_transpose_and_row_softmax(ops):
     x = rnd((3, 100, 72), 9).to(BF)
     assert torch.equal(ops.transpose(x.cuda()).cpu(), x.transpose(1, 2))
-    for N in (96, 1000, 4096):
-        s = rnd((37, N), 10, 3.0).to(BF)
-        ref = torch.softmax(s.float() * 0.0442, dim=-1)
-        got = ops.row_softmax_(s.clone().cuda(), 0.0442).float().cpu()
-        assert (got - ref).abs().max().item() <= 2 ** -8 * ref.max().item() + 1e-7
-        assert abs(got.sum(-1) - 1).max().item() < 5e-3
+    for N in (96, 1001, 4096):
+        s = rnd((37, N), 10, 30.0)
+        ref = torch.softmax(s * 0.0442, dim=-1)
+        out = torch.zeros(37, N + 8, dtype=BF, device="cuda")
+        got = ops.row_softmax(s.cuda(), 0.0442, out).float().cpu()
+        assert (got[:, :N] - ref).abs().max().item() <= 2 ** -8 * ref.max().item() + 1e-7
+        assert torch.count_nonzero(got[:, N:]).item() == 0 and abs(got.sum(-1) - 1).max().item() < 5e-3

@@ -126,7 +126,27 @@ def test_mid_block_attention_matches_fp32_softmax_attention():
     N, C = 35 * 29, 128
     q, k, v = (rnd((N, C), 30 + i, 1.5).to(BF) for i in range(3))
     ref = torch.softmax(q.float() @ k.float().T * C ** -0.5, -1) @ v.float()
-    s = o.gemm(q.cuda(), k.cuda(), None)
-    o.row_softmax_(s, C ** -0.5)
-    out = o.gemm(s, o.transpose(v.cuda()[None])[0], None)
-    close(out, ref.to(BF), max_rel=3e-2, mae_rel=6e-3)
+    s = o.gemm_f32(q.cuda(), k.cuda())
+    assert s.dtype == torch.float32
+    close(s, q.float() @ k.float().T, max_rel=1e-5, mae_rel=1e-5)     # fp32 accumulators, unrounded
+    Np = (N + 63) // 64 * 64
+    pw = torch.zeros(N, Np, dtype=BF, device="cuda")
+    o.row_softmax(s, C ** -0.5, pw)
+    vt = torch.zeros(C, Np, dtype=BF, device="cuda")
+    o.transpose(v.cuda()[None], out=vt[None, :, :N])
+    out = o.gemm(pw, vt, None)
+    close(out, ref.to(BF), max_rel=1.5e-2, mae_rel=3e-3)
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(300, 520, 128, 1), (1015, 1015, 256, 2), (256, 264, 64, 1)])
+def test_gemm_fp32_output(M, N, K, batch):
+    """Raw fp32 accumulators out of the persistent MFMA kernel (K % 128 == 0) and the generic kernel (K = 64), ragged
+    M / N, row-strided output."""
+    from textflux_amd import ops as o
+    a, w = rnd((batch, M, K), 40).to(BF), rnd((N, K), 41).to(BF)
+    ld = (N + 7) // 8 * 8 + 8
+    buf = torch.full((batch, M, ld), 7.0, dtype=torch.float32, device="cuda")
+    o.gemm_f32(a.cuda(), w.cuda(), out=buf[:, :, :N])
+    ref = a.float() @ w.float().T
+    assert (buf[:, :, :N].cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert torch.all(buf[:, :, N:] == 7.0)

@@ -79,6 +79,7 @@ SIGNATURES = {
     "tfx_last_error": (c_char_p, []),
     "tfx_query_arch": (c_int, [c_char_p, c_int]),
     "tfx_gemm_bf16": (c_int, [C.POINTER(GemmArgs), c_int, c_void_p]),
+    "tfx_gemm_bf16_f32": (c_int, [C.POINTER(GemmArgs), c_void_p]),
     "tfx_gemm_fp8": (c_int, [C.POINTER(GemmArgs), c_void_p, c_int64, c_void_p, c_void_p]),
     "tfx_ln_modulate_fp8": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_int64, c_int32, c_int32, c_int32, c_float, c_void_p]),
@@ -117,7 +118,7 @@ SIGNATURES = {
                                    c_void_p]),
     "tfx_postprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "tfx_transpose": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
-    "tfx_row_softmax": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "tfx_row_softmax": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "tfx_set_option": (c_int, [c_char_p, c_int]),
     "tfx_prof_enable": (c_int, [c_int]),
     "tfx_prof_collect": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),

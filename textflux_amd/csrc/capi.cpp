@@ -198,6 +198,19 @@ int tfx_gemm_bf16(const tfx_gemm_args* g, int variant, tfx_stream stream) {
   return variant < 0 ? gemm_bf16(a, S(stream)) : gemm_bf16_variant(a, variant, S(stream));
 }
 
+int tfx_gemm_bf16_f32(const tfx_gemm_args* g, tfx_stream stream) {
+  if (!g) return fail("tfx_gemm_bf16_f32: null args");
+  if (!g->A || !g->W || !g->C) return fail("tfx_gemm_bf16_f32: null matrix pointer");
+  GemmArgs a;
+  a.A = g->A; a.lda = g->lda; a.a_bstride = g->a_bstride;
+  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias;
+  a.C = g->C; a.ldc = g->ldc; a.c_bstride = g->c_bstride;
+  a.M = g->M; a.N = g->N; a.K = g->K; a.batch = g->batch;
+  a.epilogue = g->epilogue; a.gelu_from_col = 0;
+  a.gate = nullptr; a.gate_bstride = 0; a.res = nullptr; a.ldr = 0; a.r_bstride = 0;
+  return gemm_bf16_f32out(a, S(stream));
+}
+
 int tfx_gemm_fp8(const tfx_gemm_args* g, const float* a_scale, int64_t a_scale_bstride, const float* w_scale,
                  tfx_stream stream) {
   if (!g) return fail("tfx_gemm_fp8: null args");
@@ -356,9 +369,9 @@ int tfx_transpose(const void* in, int64_t ldi, int64_t in_bstride, void* out, in
   if (!in || !out) return fail("tfx_transpose: null pointer");
   return transpose_bf16(in, ldi, in_bstride, out, ldo, out_bstride, N, C, batch, S(stream));
 }
-int tfx_row_softmax(void* s, int64_t ld, int32_t rows, int32_t N, float scale, tfx_stream stream) {
-  if (!s) return fail("tfx_row_softmax: null pointer");
-  return row_softmax(s, ld, rows, N, scale, S(stream));
+int tfx_row_softmax(const float* s, int64_t lds, void* p, int64_t ldp, int32_t rows, int32_t N, float scale, tfx_stream stream) {
+  if (!s || !p) return fail("tfx_row_softmax: null pointer");
+  return row_softmax(s, lds, p, ldp, rows, N, scale, S(stream));
 }
 
 int tfx_set_option(const char* name, int value) {

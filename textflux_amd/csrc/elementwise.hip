@@ -282,10 +282,10 @@ constexpr int GN_CHUNK_PIX = 1024;
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
                                                          int64_t HW, int C, int groups, int nchunk) {
-  __shared__ float acc[64][2];
+  // per-thread partials -> LDS -> one thread per (group, statistic) adds them in thread order: bit-reproducible (shared
+  // atomics would add in arrival order and make the whole VAE vary from run to run in the last bits)
+  __shared__ float tp[256][4];
   const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
-  if (tid < 128) acc[tid >> 1][tid & 1] = 0.f;
-  __syncthreads();
   const int cpr = C >> 3;                       // 16-byte chunks per pixel
   const int cpg = C / groups;                   // channels per group: 4, 8 or 16
   const int64_t p0 = (int64_t)ch * GN_CHUNK_PIX;
@@ -298,11 +298,18 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s0 += v[i]; q0 += v[i] * v[i]; s1 += v[4 + i]; q1 += v[4 + i] * v[4 + i]; }
   }
-  const int g0 = (c8 * 8) / cpg, g1 = (c8 * 8 + 4) / cpg;
-  atomicAdd(&acc[g0][0], s0); atomicAdd(&acc[g0][1], q0);
-  atomicAdd(&acc[g1][0], s1); atomicAdd(&acc[g1][1], q1);
+  tp[tid][0] = s0; tp[tid][1] = q0; tp[tid][2] = s1; tp[tid][3] = q1;
   __syncthreads();
-  if (tid < 2 * groups) part[(((int64_t)b * nchunk + ch) * groups + (tid >> 1)) * 2 + (tid & 1)] = acc[tid >> 1][tid & 1];
+  if (tid < 2 * groups) {
+    const int g = tid >> 1, which = tid & 1;
+    float acc = 0.f;
+    for (int t = 0; t < 256; ++t) {
+      const int cc = (t % cpr) * 8;
+      if (cc / cpg == g) acc += tp[t][which];
+      if ((cc + 4) / cpg == g) acc += tp[t][2 + which];
+    }
+    part[(((int64_t)b * nchunk + ch) * groups + g) * 2 + which] = acc;
+  }
 }
 
 __global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, int nchunk, int groups,

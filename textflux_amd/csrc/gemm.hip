@@ -45,6 +45,7 @@ struct GemmParams {
   const bf16_t* zero;
   const float* a_scale; int64_t as_bs; const float* w_scale;   // fp8 kernel only
   float* ws; int sk;                                             // split-K: fp32 partials [sk][batch][M][N], slices
+  int64_t ws_ld, ws_bs;                                           // row / (slice, batch) strides of ws in floats (fp32-output mode: ldc / c_bstride)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + tx * 4 + j;
       if (n >= p.N) continue;
+      if (p.ws) { p.ws[b * p.ws_bs + (int64_t)m * p.ws_ld + n] = acc[i][j]; continue; }   // fp32-output mode (raw accumulators)
       float v = acc[i][j] + (p.bias ? bf2f(p.bias[n]) : 0.f);
       if (EPI == EPI_BIAS_GELU) { if (n >= p.gelu_from) v = gelu_tanh(v); }
       if (EPI == EPI_BIAS_GATE_RES) {
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       int le = lane;
       asm volatile("" : "+v"(le));
-      float* wsp = p.ws + ((int64_t)(cur.slice * p.batch + cur.b) * p.M) * p.N;
+      float* wsp = p.ws + (int64_t)(cur.slice * p.batch + cur.b) * p.ws_bs;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const int m = cur.m0 + g * 128 + mi * 32 + (le & 31);
@@ -721,9 +723,14 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
             const int n = cur.n0 + wc * 64 + nj * 32 + qd * 8 + (le >> 5) * 4;
-            if (m < p.M && n < p.N)
-              *reinterpret_cast<f32x4*>(wsp + (int64_t)m * p.N + n) =
+            if (m < p.M && n + 3 < p.N) {
+              *reinterpret_cast<f32x4*>(wsp + (int64_t)m * p.ws_ld + n) =
                   f32x4{acc[mi][nj][qd * 4], acc[mi][nj][qd * 4 + 1], acc[mi][nj][qd * 4 + 2], acc[mi][nj][qd * 4 + 3]};
+            } else if (m < p.M) {   // ragged right edge (fp32-output mode only: the split path has N % 8 == 0)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) wsp[(int64_t)m * p.ws_ld + n + e] = acc[mi][nj][qd * 4 + e];
+            }
           }
       }
       if (!has_next) break;
@@ -952,7 +959,7 @@ static GemmParams make_params(const GemmArgs& a) {
   p.cstride = a.conv_stride; p.cup = a.conv_up_shift; p.cpad = a.conv_pad_lo; p.zero = (const bf16_t*)a.zero_page;
   p.csh = a.conv_cin == 8 ? 3 : a.conv_cin == 16 ? 4 : a.conv_cin == 32 ? 5 : 0;
   p.a_scale = a.a_scale; p.as_bs = a.a_scale_bstride; p.w_scale = a.w_scale;
-  p.ws = nullptr; p.sk = 1;
+  p.ws = nullptr; p.sk = 1; p.ws_ld = a.N; p.ws_bs = (int64_t)a.M * a.N;
   return p;
 }
 
@@ -1108,6 +1115,45 @@ int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
 }
 
 int gemm_bf16(const GemmArgs& a, hipStream_t st) { return gemm_bf16_variant(a, fast_ok(a) ? 1 : 0, st); }
+
+// ---- fp32 output (raw accumulators, no epilogue): C [batch][M, N] floats with row stride ldc.  The score GEMM of the
+// VAE mid-block attention: q k^T must reach the softmax unrounded.  The persistent kernel in its (tile, slice) form with
+// ONE slice writes exactly that; shapes it does not take (K % 128 != 0) go to the generic kernel.
+int gemm_bf16_f32out(const GemmArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return 0;
+  if (a.K <= 0) return fail("gemm_f32out: K must be positive");
+  if (a.epilogue != EPI_BIAS || a.bias) return fail("gemm_f32out: raw accumulators only (no bias / epilogue)");
+  if (a.conv_cin > 0) return fail("gemm_f32out: no convolution mode");
+  if ((uintptr_t)a.C % 16 || a.ldc % 4 || a.c_bstride % 4) return fail("gemm_f32out: C must be 16-byte aligned, ldc / c_bstride multiples of 4");
+  GemmParams p = make_params(a);
+  p.ws = (float*)a.C; p.sk = 1; p.ws_ld = a.ldc; p.ws_bs = a.c_bstride;
+  GemmArgs chk = a;
+  chk.C = const_cast<void*>(a.A);   // alignment of the fp32 C was checked above; the remaining fast-path conditions are operand-side
+  chk.ldc = 8; chk.c_bstride = 8;
+  if (fast_ok(chk) && persist_ok(p)) {
+    static int grid = 0;
+    if (!grid) {
+      int dev = 0, cus = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+      const void* fn = (const void*)gemm8pp_kernel<EPI_BIAS, 2, false, true>;
+      hipFuncAttributes fa;
+      (void)hipFuncGetAttributes(&fa, fn);
+      (void)hipGetLastError();
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess)
+        return fail("gemm_f32out: cannot raise dynamic LDS limit");
+      grid = cus & ~7;
+    }
+    const bool prof = prof_on(st);
+    if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
+    gemm8pp_kernel<EPI_BIAS, 2, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+    if (prof) prof_end(0, st);
+  } else {
+    dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch);
+    gemm_generic_kernel<EPI_BIAS><<<grid, 256, 0, st>>>(p);
+  }
+  return check_launch("gemm_f32out");
+}
 
 // ---- fp8 (e4m3 x e4m3 -> fp32) path: the persistent kernel only
 template <int EPI>

@@ -8,8 +8,11 @@
 //   postprocess     IP:718-771   denormalise, clamp, -> NCHW bf16 ("pt") / NHWC fp32 ("np") / NHWC uint8 ("pil")
 // plus two helpers of the VAE mid-block attention (single head of dim C, D/models/attention_processor.py:2799-2881):
 //   transpose       v [N, C] -> v^T [C, N] so that P @ v runs on the MFMA GEMM (C = A @ W^T)
-//   row_softmax     softmax(scale * s) over rows of the bf16 score matrix, fp32 statistics
+//   row_softmax     bf16 softmax(scale * s) over rows of the fp32 score matrix (tfx_gemm_bf16_f32), fp32 statistics
 // Every bf16 rounding point of the reference's op chain is kept (each torch op on bf16 tensors rounds its result).
+// Python-scalar operands (shift_factor, scaling_factor) follow the semantics of the reference's DEVICE kernels: the scalar
+// stays fp32 (opmath) and `tensor / scalar` is a multiply by the fp32 reciprocal -- torch's CPU kernels round the scalar to
+// bf16 first and divide, so a bf16 CPU run of the reference differs from its GPU run in exactly these two places.
 #include "common.h"
 #include "launch.h"
 
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void sample_pack_kernel(const bf16_t* __restri
   *reinterpret_cast<u32x4*>(out + bt * ld + col0 + g * 8) = pack8(v);
 }
 
-// latents [B, S, 4L] -> z NHWC [B, h, w, L] = bf16(bf16(lat / scale) + shift); z[b, y, x, c] <- col c*4 + (y&1)*2 + (x&1)
+// latents [B, S, 4L] -> z NHWC [B, h, w, L] = bf16(bf16(lat * (1 / scale)) + shift); z[b, y, x, c] <- col c*4 + (y&1)*2 + (x&1)
 // of token (y>>1, x>>1).  One thread = one pixel x 8 channels.
 __global__ __launch_bounds__(256) void unpack_latents_kernel(const bf16_t* __restrict__ lat, int64_t ld, bf16_t* __restrict__ out,
                                                              int B, int h, int w, int L, float shift, float scale) {
@@ -146,9 +149,10 @@ __global__ __launch_bounds__(256) void unpack_latents_kernel(const bf16_t* __res
   const int y = (int)((p / w) % h);
   const int b = (int)(p / ((int64_t)w * h));
   const bf16_t* row = lat + ((int64_t)b * (h / 2) * (w / 2) + (int64_t)(y >> 1) * (w / 2) + (x >> 1)) * ld + (y & 1) * 2 + (x & 1);
+  const float inv_scale = __fdiv_rn(1.0f, scale);
   float v[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = round_bf(__fdiv_rn(bf2f(row[(g * 8 + e) * 4]), scale)) + shift;
+  for (int e = 0; e < 8; ++e) v[e] = round_bf(__fmul_rn(bf2f(row[(g * 8 + e) * 4]), inv_scale)) + shift;
   *reinterpret_cast<u32x4*>(out + i * 8) = pack8(v);
 }
 
@@ -183,13 +187,15 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     if (c0 + r < C && n0 + tx < N) out[b * obs + (int64_t)(c0 + r) * ldo + n0 + tx] = tile[tx][r];
 }
 
-// p[r, :] = bf16( softmax(scale * s[r, :]) ) in place, fp32 statistics, one 256-thread block per row (rows stay in L2
-// between the three passes).
-__global__ __launch_bounds__(256) void row_softmax_kernel(bf16_t* __restrict__ s, int64_t ld, int N, float scale_log2e) {
+// p[r, :N] = bf16( softmax(scale * s[r, :N]) ): fp32 scores in (row stride lds), bf16 weights out (row stride ldp), fp32
+// statistics, one 256-thread block per row (the row stays in L2 between the three passes).
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ s, int64_t lds, bf16_t* __restrict__ pout,
+                                                          int64_t ldp, int N, float scale_log2e) {
   __shared__ float red[4];
-  bf16_t* row = s + (int64_t)blockIdx.x * ld;
+  const float* row = s + (int64_t)blockIdx.x * lds;
+  bf16_t* prow = pout + (int64_t)blockIdx.x * ldp;
   const int tid = threadIdx.x;
-  const bool vec = (N % 8 == 0) && (ld % 8 == 0) && ((uintptr_t)s % 16 == 0);
+  const bool vec = (N % 8 == 0) && (lds % 4 == 0) && (ldp % 8 == 0) && ((uintptr_t)s % 16 == 0) && ((uintptr_t)pout % 16 == 0);
   auto block_reduce = [&](float v, bool is_max) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -201,16 +207,21 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(bf16_t* __restrict__ s
     __syncthreads();
     return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
   };
+  auto ld8 = [&](int c, float* f) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row + c * 8), b = *reinterpret_cast<const f32x4*>(row + c * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+  };
   float mx = -INFINITY;
   if (vec) {
     for (int c = tid; c < N / 8; c += 256) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(row + c * 8), f);
+      ld8(c, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) mx = fmaxf(mx, f[e]);
     }
   } else {
-    for (int c = tid; c < N; c += 256) mx = fmaxf(mx, bf2f(row[c]));
+    for (int c = tid; c < N; c += 256) mx = fmaxf(mx, row[c]);
   }
   mx = block_reduce(mx, true);
   const float mc = mx * scale_log2e;
@@ -218,25 +229,25 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(bf16_t* __restrict__ s
   if (vec) {
     for (int c = tid; c < N / 8; c += 256) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(row + c * 8), f);
+      ld8(c, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f(f[e] * scale_log2e - mc);
     }
   } else {
-    for (int c = tid; c < N; c += 256) sum += __builtin_amdgcn_exp2f(bf2f(row[c]) * scale_log2e - mc);
+    for (int c = tid; c < N; c += 256) sum += __builtin_amdgcn_exp2f(row[c] * scale_log2e - mc);
   }
   sum = block_reduce(sum, false);
   const float inv = 1.0f / sum;
   if (vec) {
     for (int c = tid; c < N / 8; c += 256) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(row + c * 8), f);
+      ld8(c, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_exp2f(f[e] * scale_log2e - mc) * inv;
-      *reinterpret_cast<u32x4*>(row + c * 8) = pack8(f);
+      *reinterpret_cast<u32x4*>(prow + c * 8) = pack8(f);
     }
   } else {
-    for (int c = tid; c < N; c += 256) row[c] = f2bf(__builtin_amdgcn_exp2f(bf2f(row[c]) * scale_log2e - mc) * inv);
+    for (int c = tid; c < N; c += 256) prow[c] = f2bf(__builtin_amdgcn_exp2f(row[c] * scale_log2e - mc) * inv);
   }
 }
 
@@ -327,9 +338,9 @@ int transpose_bf16(const void* in, int64_t ldi, int64_t ibs, void* out, int64_t 
   return check_launch("transpose");
 }
 
-int row_softmax(void* s, int64_t ld, int rows, int N, float scale, hipStream_t st) {
+int row_softmax(const float* s, int64_t lds, void* p, int64_t ldp, int rows, int N, float scale, hipStream_t st) {
   if (rows <= 0 || N <= 0) return 0;
-  row_softmax_kernel<<<rows, 256, 0, st>>>((bf16_t*)s, ld, N, scale * 1.4426950408889634f);
+  row_softmax_kernel<<<rows, 256, 0, st>>>(s, lds, (bf16_t*)p, ldp, N, scale * 1.4426950408889634f);
   return check_launch("row_softmax");
 }
 

@@ -57,6 +57,7 @@ void set_gemm_place(int v);
 void set_gemm_splitk(int v);
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
+int gemm_bf16_f32out(const GemmArgs& a, hipStream_t st);     // C = fp32 raw accumulators [batch][M, N] (ldc, c_bstride in floats)
 int gemm_fp8(const GemmArgs& a, hipStream_t st);             // persistent MFMA kernel on e4m3 operands (K % 256 == 0)
 // per-row absmax quantisation bf16 -> e4m3: out = x / scale, scale = absmax / 448 (1 for an all-zero row)
 // LayerNorm + modulation whose output is written as the e4m3 quantisation of the bf16 row (fp8 mode; == ln_modulate followed
@@ -107,7 +108,7 @@ int unpack_latents(const void* lat, int64_t ld, void* out, int B, int h, int w, 
 int postprocess(const void* x, void* out, int B, int64_t HW, int Cs, int C, int mode, int denorm, hipStream_t st);
 int transpose_bf16(const void* in, int64_t ldi, int64_t ibs, void* out, int64_t ldo, int64_t obs, int N, int C, int batch,
                    hipStream_t st);
-int row_softmax(void* s, int64_t ld, int rows, int N, float scale, hipStream_t st);
+int row_softmax(const float* s, int64_t lds, void* p, int64_t ldp, int rows, int N, float scale, hipStream_t st);
 int select_step(const void* table, void* cur, int64_t per_step_elems, int* step_ptr, hipStream_t st);
 int advance_step(int* step_ptr, hipStream_t st);
 

@@ -434,9 +434,34 @@ def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
     return out
 
 
-def row_softmax_(s: torch.Tensor, scale: float) -> torch.Tensor:
-    """In place softmax(scale * s) over the last dim of a 2-D bf16 matrix."""
-    _chk_dev(s)
-    assert s.dim() == 2 and s.dtype == BF16 and s.stride(1) == 1
-    L.check(L.lib().tfx_row_softmax(s.data_ptr(), s.stride(0), s.shape[0], s.shape[1], scale, _stream()), "row_softmax")
-    return s
+def row_softmax(s: torch.Tensor, scale: float, out: torch.Tensor) -> torch.Tensor:
+    """out[:, :N] = bf16(softmax(scale * s)) over the last dim; s [R, N] fp32 (row-strided), out [R, >= N] bf16."""
+    _chk_dev(s, out)
+    assert s.dim() == 2 and s.dtype == torch.float32 and s.stride(1) == 1
+    assert out.dim() == 2 and out.dtype == BF16 and out.stride(1) == 1 and out.shape[0] == s.shape[0] and out.shape[1] >= s.shape[1]
+    L.check(L.lib().tfx_row_softmax(s.data_ptr(), s.stride(0), out.data_ptr(), out.stride(0), s.shape[0], s.shape[1], scale,
+                                    _stream()), "row_softmax")
+    return out
+
+
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = a[b] @ w.T as fp32 raw accumulators (no bias / epilogue).  a [M, K] or [B, M, K] bf16, w [N, K] bf16,
+    out [.., M, N] fp32 (row-strided views allowed)."""
+    _chk_dev(a, w, out)
+    assert a.dtype == BF16 and w.dtype == BF16 and w.dim() == 2 and w.stride(1) == 1
+    ap, lda, abs_, M, batch = _rows_view(a)
+    N, K = w.shape
+    assert a.shape[-1] == K
+    if out is None:   # rows padded to a multiple of 4 floats (16-byte aligned vector stores)
+        out = torch.empty(*a.shape[:-1], (N + 3) // 4 * 4, dtype=torch.float32, device=a.device)[..., :N]
+    assert out.dtype == torch.float32
+    cp, ldc, cbs, M2, b2 = _rows_view(out)
+    assert (M2, b2) == (M, batch) and out.shape[-1] == N
+    g = L.GemmArgs()
+    g.A, g.lda, g.a_bstride = ap, lda, abs_
+    g.W, g.ldw, g.bias = w.data_ptr(), w.stride(0), None
+    g.C, g.ldc, g.c_bstride = cp, ldc, cbs
+    g.M, g.N, g.K, g.batch = M, N, K, batch
+    g.epilogue = EPI_BIAS
+    L.check(L.lib().tfx_gemm_bf16_f32(C.byref(g), _stream()), "gemm_f32")
+    return out

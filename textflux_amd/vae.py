@@ -8,8 +8,8 @@ loads as is).  ONE execution path: activations are NHWC bf16 from the first to t
   layers (3 / 16 input channels) use its narrow-input form (channels padded to 8 / 16, K padded to 128 / 192);
 * GroupNorm(+SiLU) is `tfx_groupnorm_nhwc`; 1x1 shortcuts and the mid-block's q/k/v/out projections are `tfx_gemm_bf16`;
 * the mid-block attention (ONE head of dim 512 over h*w tokens, AttnProcessor2_0 D/models/attention_processor.py:2799-2881)
-  runs as scores = q k^T (MFMA GEMM) -> `tfx_row_softmax` (fp32 statistics) -> P v (MFMA GEMM against v^T from
-  `tfx_transpose`), one image at a time through a reused [N, N] bf16 score buffer;
+  runs as fp32 scores = q k^T (`tfx_gemm_bf16_f32`) -> `tfx_row_softmax` (fp32 in, bf16 weights out) -> P v (MFMA GEMM
+  against v^T from `tfx_transpose`), one image at a time through reused [N, N] score / weight buffers;
 * the pipeline hands over / takes back NHWC tensors through `encode_moments_nhwc` / `decode_nhwc` (imageops.hip kernels on
   either side); `encode` / `decode` keep the reference's NCHW tensor interface on top of the same path.
 Configurations the kernels do not cover (block widths that are not multiples of 64) raise at load time: there is no
@@ -75,7 +75,7 @@ class AutoencoderKL:
         self.sd: Dict[str, torch.Tensor] = {}
         self.hw: Dict[str, torch.Tensor] = {}
         self.dtype, self.device = torch.bfloat16, torch.device("cpu")
-        self._scores: Optional[torch.Tensor] = None
+        self._scores = None     # (fp32 scores [N, Np], bf16 softmax weights [N, Np]) of the mid-block attention, reused
 
     # ---- weights ------------------------------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor], device="cuda", dtype=torch.bfloat16):
@@ -171,16 +171,21 @@ class AutoencoderKL:
         tok = x.view(B, N, C)
         h = self._gn(tok, a + ".group_norm", silu=False)
         q, k, v = (ops.gemm(h, self.sd[f"{a}.{n}.weight"], self.sd[f"{a}.{n}.bias"]) for n in ("to_q", "to_k", "to_v"))
-        vt = ops.transpose(v)                                            # [B, C, N]
-        if self._scores is None or self._scores.numel() < N * N:
-            self._scores = None                                          # release before growing
-            self._scores = torch.empty(N * N, dtype=torch.bfloat16, device=x.device)
-        s = self._scores[:N * N].view(N, N)
+        # scores stay fp32 between the two GEMMs (a flash kernel would keep them in registers); token counts are padded to
+        # a multiple of 64 with zero weights / zero v^T columns so that the P v product takes the MFMA kernel for any h * w
+        Np = (N + 63) // 64 * 64
+        vt = torch.zeros(B, C, Np, dtype=torch.bfloat16, device=x.device) if Np != N else torch.empty(B, C, N, dtype=torch.bfloat16, device=x.device)
+        ops.transpose(v, out=vt[:, :, :N])
+        if self._scores is None or self._scores[0].shape != (N, Np):
+            self._scores = None                                          # release before re-allocating
+            self._scores = (torch.empty(N, Np, dtype=torch.float32, device=x.device),
+                            torch.zeros(N, Np, dtype=torch.bfloat16, device=x.device))
+        s, pw = self._scores
         o = torch.empty(B, N, C, dtype=torch.bfloat16, device=x.device)
         for b in range(B):
-            ops.gemm(q[b], k[b], None, out=s)                            # scores [N, N] (bf16, as the math SDPA path)
-            ops.row_softmax_(s, C ** -0.5)
-            ops.gemm(s, vt[b], None, out=o[b])
+            ops.gemm_f32(q[b], k[b], out=s[:, :N])
+            ops.row_softmax(s[:, :N], C ** -0.5, pw)
+            ops.gemm(pw, vt[b], None, out=o[b])
         x = ops.gemm(o, self.sd[a + ".to_out.0.weight"], self.sd[a + ".to_out.0.bias"], epilogue=ops.EPI_BIAS_RES,
                      res=tok).view(B, H, W, C)
         return self._res(x, p + ".resnets.1")
