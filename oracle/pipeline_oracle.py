@@ -93,6 +93,7 @@ def denoise(
     amo_c: float = 2.0,
     sched_cfg: Optional[dict] = None,
     model_fn: Optional[Callable] = None,
+    max_steps: Optional[int] = None,   # stop after this many steps of the num_inference_steps schedule (full-size tests)
 ) -> Tuple[Tensor, List[Tensor]]:
     """Steps 4-7 of FluxFillPipeline.__call__ with `latents=`/`masked_image_latents=`/`prompt_embeds=` injected
     and output_type='latent' (P:2012-2116).  Returns (final latents, per-step latents)."""
@@ -111,6 +112,8 @@ def denoise(
     fwd = model_fn or (lambda **kw: fo.transformer_forward(sd, cfg, **kw))
     traj = []
     for i, t in enumerate(timesteps):
+        if max_steps is not None and i >= max_steps:
+            break
         timestep = t.expand(B).to(latents.dtype)
         noise_pred = fwd(
             hidden_states=torch.cat((latents, masked_image_latents.to(latents.dtype)), dim=2),

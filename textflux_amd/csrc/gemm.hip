@@ -569,8 +569,10 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
         else go[q][j] = min(row, p.N - 1 - t.n0) * (int)p.ldw * ESZ + clog * 16;
       }
   };
-  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
-  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  // num_records = 2^32 - 1: the whole 32-bit offset range persist_ok admits is in bounds (with 2^31 - 1 every byte of an
+  // operand beyond 2 GiB read as zero: samples 6, 7 of the [8, 8704, 7 D] projection buffer at 2048 x 1024, batch 8)
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)0xffffffffu, 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)0xffffffffu, 0x00020000);
 
   // request item q of K-tile kt of the tile with origins (xo, wo) and lane offsets go into buffer set `set`
   auto stage = [&](int q, const int (&go)[4][2], uint32_t xo, uint32_t wo, int kt, int set) {
@@ -988,8 +990,8 @@ static bool fast_ok(const GemmArgs& a) {
 // one-tile kernel.
 static bool persist_ok(const GemmParams& p) {
   return p.cin == 0 && p.K % 128 == 0 &&
-         ((int64_t)(p.batch - 1) * p.a_bs + (int64_t)p.tm * 256 * p.lda) * 2 < (1ll << 32) &&
-         (int64_t)p.tn * 256 * p.ldw * 2 < (1ll << 32);
+         ((int64_t)(p.batch - 1) * p.a_bs + (int64_t)p.tm * 256 * p.lda) * 2 < (1ll << 32) - 65536 &&
+         (int64_t)p.tn * 256 * p.ldw * 2 < (1ll << 32) - 65536;
 }
 
 template <int ABL>
