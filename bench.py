@@ -99,6 +99,7 @@ def main():
     a = ap.parse_args()
 
     from textflux_amd import distributed as tdist
+    tdist.respawn_under_torchrun(a.gpus, __file__, sys.argv[1:])   # bare `python bench.py --gpus N`: one rank per GPU
     from textflux_amd import ops
     from textflux_amd.pipeline import FluxFillPipeline
     from textflux_amd.schedulers import FlowMatchEulerDiscreteScheduler, StochasticRFOvershotDiscreteScheduler
@@ -110,7 +111,8 @@ def main():
         name, _, val = kv.partition("=")
         ops.set_option(name, int(val))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus} "
+                         "(or without a launcher: bench.py re-executes itself under torch.distributed.run)")
     dev = torch.device("cuda", local)
     B, H, W, n = a.batch, a.height, a.width, a.denoise_steps
     S = (H // 16) * (W // 16)
@@ -168,6 +170,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = tdist.max_over_ranks(time.perf_counter() - t0, dev)
     ops.prof_enable(False)
+    seen = tdist.ranks_seen(dev)   # ranks that answered an RCCL all-reduce
 
     if rank == 0:
         gemm_ms, gemm_fl, gemm_n = ops.prof_collect(2 if a.fp8 else 0)   # fp8 run: the e4m3 GEMM launches are the dominant kernel
@@ -204,6 +207,7 @@ def main():
                                    + ("" if full else f" [REDUCED MODEL {a.layers} - not a valid headline]")
                                    + (" [fp8 linears: BASELINE config 5 precision, not the bf16 headline]" if a.fp8 else ""),
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, conditioning broadcast over RCCL)"},
+            "rccl_ranks_seen": seen,
             "sec_per_img_per_gpu": elapsed / (B * a.steps),
             "dit_algorithmic_tflops_per_gpu": dit_flops(S) * n * B * a.steps / elapsed / 1e12 if full else None,
             "roofline": {"bound": "mfma", "kernel": "tfx::gemm8pp_kernel (persistent MFMA GEMM, all epilogues; + gemm8p_kernel for K % 128 != 0)", "achieved": achieved,
@@ -215,8 +219,7 @@ def main():
         }
         rec["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(H, W, n)   # rank 0 at N = 1 only
         print(json.dumps(rec), flush=True)
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+    tdist.shutdown()
 
 
 if __name__ == "__main__":

@@ -27,11 +27,14 @@ TRANSFORMER = os.environ.get("TEXTFLUX_TRANSFORMER", "./models/textflux-beta/tra
 PIPE = None
 
 
-def load_flux_pipeline():
+def load_flux_pipeline(text_encoders: bool = True):
+    """run_inference.py:44-57.  text_encoders=False (batch driver, ranks > 0) skips T5 / CLIP: those ranks receive their
+    prompt embeddings from rank 0."""
     global PIPE
     if PIPE is None:
         transformer = FluxTransformer2DModel.from_pretrained(TRANSFORMER, torch_dtype=torch.bfloat16)
-        PIPE = FluxFillPipeline.from_pretrained(BASE, transformer=transformer, torch_dtype=torch.bfloat16).to("cuda")
+        skip = {} if text_encoders else dict(text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None)
+        PIPE = FluxFillPipeline.from_pretrained(BASE, transformer=transformer, torch_dtype=torch.bfloat16, **skip).to("cuda")
     return PIPE
 
 

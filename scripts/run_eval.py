@@ -1,52 +1,47 @@
 #!/usr/bin/env python3
-"""Batch driver: shards a JSON list of {image, mask, text} items over the GPUs of one node.
+"""Batch driver CLI: shards a JSON list of {image, mask, text} items over the GPUs of one node.
 
-Counterpart of the reference's scripts/run_eval.py (:76-247: one process per GPU, a multiprocessing Manager queue, every
-replica loads its own copy and encodes its own prompts).  Here: one process per GPU launched by torchrun, contiguous
-static shards (`shard_range`), defaults as the reference (30 steps, guidance 30, seed 42, strip ratio 0.15625 as passed by
-batch_eval.sh).  Launch:  python -m torch.distributed.run --nproc-per-node 8 scripts/run_eval.py --items items.json --out out/
+Counterpart of the reference's scripts/run_eval.py (:76-247, flags :201-213).  The work is done by
+textflux_amd/batch_driver.py: same-geometry batches (default 8 per pipeline call), prompts encoded once on rank 0 and
+scattered over RCCL, every rank writes its own crops.  Defaults as the reference (30 steps, guidance 30, seed 42; strip
+ratio 0.15625 as passed by batch_eval.sh).  Launch with one process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/run_eval.py \
+        --items items.json --out out/          (or:  python scripts/run_eval.py --gpus 8 ...  which re-executes itself so)
 """
 import argparse
 import json
 import os
 import sys
 
-import torch
-from PIL import Image
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import run_inference as ri
-from textflux_amd import distributed as tdist
-from textflux_amd import glyph
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--items", required=True, help="JSON list of {image, mask, text} (text: string, lines = text lines)")
+    ap.add_argument("--items", required=True, help="JSON list of {image, mask, text} (text: string or path, lines = text lines)")
     ap.add_argument("--out", required=True)
     ap.add_argument("--num_inference_steps", type=int, default=30)
     ap.add_argument("--guidance_scale", type=float, default=30)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--batch_size", type=int, default=8, help="same-geometry images per pipeline call")
+    ap.add_argument("--gpus", type=int, default=None, help="spawn this many ranks (ignored under torchrun)")
     a = ap.parse_args()
+    from textflux_amd import distributed as tdist
+    tdist.respawn_under_torchrun(a.gpus, __file__, sys.argv[1:])
     rank, world, local = tdist.init_from_env()
+    import run_inference as ri
+    from textflux_amd import batch_driver
     with open(a.items) as f:
         items = json.load(f)
     os.makedirs(a.out, exist_ok=True)
-    pipe = ri.load_flux_pipeline()
-    done = 0
-    for i in tdist.shard_range(len(items), rank, world):
-        it = items[i]
-        try:
-            scene, mask = Image.open(it["image"]).convert("RGB"), Image.open(it["mask"]).convert("RGB")
-            words = glyph.read_words_from_text(it["text"])
-            combined, cmask, meta = glyph.compose(scene, mask, words)
-            full = ri.run_inference(combined, cmask, it["text"], a.num_inference_steps, a.guidance_scale, a.seed, pipe=pipe)
-            full.crop(glyph.crop_box(full.size, meta)).save(os.path.join(a.out, f"{i:06d}.png"))
-            done += 1
-        except Exception as e:  # per-item failures do not stop the shard (reference :195-198)
-            print(f"[rank {rank}] item {i} failed: {e}")
-    tdist.barrier()
-    print(f"[rank {rank}] {done} images written")
+    pipe = ri.load_flux_pipeline(text_encoders=(rank == 0))     # ranks > 0 receive their embeddings from rank 0
+    pipe.enable_hip_graph(True)
+    res = batch_driver.run_items(items, pipe, a.out, batch_size=a.batch_size, num_inference_steps=a.num_inference_steps,
+                                 guidance_scale=a.guidance_scale, seed=a.seed, device=f"cuda:{local}")
+    print(f"[rank {rank}] {len(res['done'])} images written" + (f"; {len(res['all_done'])}/{len(items)} in total, "
+          f"{res['batches']} batches in {res['rounds']} rounds" if rank == 0 else ""))
+    tdist.shutdown()
 
 
 if __name__ == "__main__":

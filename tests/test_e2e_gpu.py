@@ -1,0 +1,133 @@
+"""Loader + caller end to end on the GPU: a synthetic HF-layout pipeline directory (sharded transformer,
+VAE, scheduler config, tiny CLIP / T5 text encoders with real tokenizer files, a LoRA file) is read back by the same entry
+points the reference's scripts use -- run_inference.load_flux_pipeline() / run_inference(), run_inference_lora.
+load_flux_pipeline(), and the batch driver behind scripts/run_eval.py -- and the generated image is compared with the CPU
+oracle's FluxFillPipeline restatement (oracle/pipeline_oracle.fill_pipeline) fed the same prompt embeddings and RNG draws."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import pipeline_oracle as po
+from oracle import vae_oracle as vo
+from tests.helpers import tiny_checkpoint as tc
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def env(tmp_path_factory):
+    import run_inference as ri
+    root = str(tmp_path_factory.mktemp("flux_fill_dev"))
+    lora_dir = str(tmp_path_factory.mktemp("textflux_lora"))
+    sd, vsd = tc.write_pipeline_dir(root)
+    merged = tc.write_lora(lora_dir, sd)
+    ri.BASE, ri.TRANSFORMER, ri.PIPE = root, os.path.join(root, "transformer"), None
+    rb = lambda d: {k: v.to(BF).float() for k, v in d.items()}      # what the files hold
+    return dict(root=root, lora=lora_dir, sd=rb(sd), vsd=rb(vsd), merged=rb(merged), ri=ri)
+
+
+def _scene(seed=0, w=256, h=128):
+    rng = np.random.default_rng(seed)
+    scene = Image.fromarray((rng.random((h, w, 3)) * 255).astype(np.uint8))
+    m = np.zeros((h, w), np.uint8)
+    m[h // 4: 3 * h // 4, w // 8: 7 * w // 8] = 255
+    return scene, Image.fromarray(m).convert("RGB")
+
+
+def _oracle_image(env, pipe, combined, cmask, words, steps, seed, sd):
+    """The oracle's __call__ on the same composed inputs, the pipeline's own prompt embeddings and the same two draws."""
+    from textflux_amd import glyph
+    from textflux_amd.pipeline import randn_tensor
+    w, h = glyph.pipe_size(combined)
+    img = torch.from_numpy(np.array(combined.resize((w, h)).convert("RGB")).astype(np.float32) / 255.0).permute(2, 0, 1)[None]
+    msk = torch.from_numpy(np.array(cmask.resize((w, h)).convert("L")).astype(np.float32) / 255.0)[None, None]
+    with torch.no_grad():
+        pe, pooled, _ = pipe.encode_prompt(prompt=glyph.PROMPT_TEMPLATE2, prompt_2=glyph.generate_prompt(words), max_sequence_length=512)
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    lat = randn_tensor((1, 16, h // 8, w // 8), generator=gen, device=torch.device("cuda"), dtype=BF)     # P:1825, first draw
+    eps = randn_tensor((1, 16, h // 8, w // 8), generator=gen, device=torch.device("cuda"), dtype=BF)     # P:1528, second draw
+    vcfg = vo.VaeConfig(**tc.VAE_KW)
+    return po.fill_pipeline(sd, tc.TR_CFG, env["vsd"], vcfg, img, msk, pe.float().cpu(), pooled.float().cpu(),
+                            lat.float().cpu(), eps.float().cpu(), steps, 30.0, output_type="np")[0].numpy()
+
+
+def test_run_inference_from_checkpoint_directory_matches_oracle(env):
+    from textflux_amd import glyph
+    ri = env["ri"]
+    ri.PIPE = None
+    scene, mask = _scene()
+    combined, cmask, meta = glyph.compose(scene, mask, ["HELLO"])
+    out = ri.run_inference(combined, cmask, "HELLO", num_steps=3, guidance_scale=30, seed=42)
+    pipe = ri.load_flux_pipeline()
+    assert pipe.text_encoder is not None and pipe.text_encoder_2 is not None and pipe.tokenizer_2 is not None
+    assert out.size == glyph.pipe_size(combined)
+    ref = _oracle_image(env, pipe, combined, cmask, ["HELLO"], 3, 42, env["sd"])
+    err = np.abs(np.asarray(out).astype(np.float32) / 255.0 - ref).mean()
+    print(f"run_inference image MAE vs oracle: {err:.3e}")
+    assert err < 2e-2
+    crop = out.crop(glyph.crop_box(out.size, meta))
+    assert crop.size[0] == scene.size[0] and abs(crop.size[1] - scene.size[1]) <= 16
+
+
+def test_lora_pipeline_from_checkpoint_directory(env):
+    import run_inference_lora as rl
+    from textflux_amd import glyph
+    ri = env["ri"]
+    ri.PIPE = None
+    rl.LORA = env["lora"]
+    pipe = rl.load_flux_pipeline()
+    D = pipe.transformer.inner_dim
+    got = pipe.transformer.w["d0.qkv_img.w"][2 * D:3 * D].float().cpu()
+    want, base = env["merged"]["transformer_blocks.0.attn.to_q.weight"], env["sd"]["transformer_blocks.0.attn.to_q.weight"]
+    assert (got - want).abs().max().item() <= 2 ** -7 * want.abs().max().item() and (got - base).abs().mean().item() > 1e-3
+    scene, mask = _scene(1)
+    combined, cmask, _ = glyph.compose(scene, mask, ["LoRA"])
+    out = ri.run_inference(combined, cmask, "LoRA", num_steps=3, guidance_scale=30, seed=7, pipe=pipe)
+    ref = _oracle_image(env, pipe, combined, cmask, ["LoRA"], 3, 7, env["merged"])
+    ref0 = _oracle_image(env, pipe, combined, cmask, ["LoRA"], 3, 7, env["sd"])
+    a = np.asarray(out).astype(np.float32) / 255.0
+    e_m, e_0 = np.abs(a - ref).mean(), np.abs(a - ref0).mean()
+    print(f"LoRA pipeline image MAE vs merged oracle {e_m:.3e}, vs unmerged oracle {e_0:.3e}")
+    assert e_m < 2e-2 and e_m < e_0
+    ri.PIPE = None
+
+
+def test_batch_driver_matches_single_image_calls(env, tmp_path):
+    """scripts/run_eval.py's engine (textflux_amd/batch_driver.run_items) on the real pipeline: same-geometry items go
+    through ONE batched call with per-item generators, and reproduce the single-image run_inference results."""
+    from textflux_amd import batch_driver, glyph
+    ri = env["ri"]
+    ri.PIPE = None
+    pipe = ri.load_flux_pipeline()
+    items, singles = [], []
+    for i, word in enumerate(["ALPHA", "BETA", "GAMMA"]):
+        scene, mask = _scene(10 + i)
+        sp, mp = str(tmp_path / f"s{i}.png"), str(tmp_path / f"m{i}.png")
+        scene.save(sp)
+        mask.save(mp)
+        items.append(dict(image=sp, mask=mp, text=word))
+        combined, cmask, meta = glyph.compose(scene, mask, [word])
+        full = ri.run_inference(combined, cmask, word, num_steps=3, guidance_scale=30, seed=42, pipe=pipe)
+        singles.append(np.asarray(full.crop(glyph.crop_box(full.size, meta))).astype(np.float32))
+    out_dir = tmp_path / "out"
+    os.makedirs(out_dir)
+    calls = []
+    real_call = pipe.__class__.__call__
+    pipe.__class__.__call__ = lambda self, *a, **k: (calls.append(len(k["image"]) if isinstance(k.get("image"), list) else 1), real_call(self, *a, **k))[1]
+    try:
+        res = batch_driver.run_items(items, pipe, str(out_dir), batch_size=2, num_inference_steps=3, guidance_scale=30.0, seed=42)
+    finally:
+        pipe.__class__.__call__ = real_call
+    assert res["all_done"] == [0, 1, 2] and calls == [2, 1]
+    for i in range(3):
+        got = np.asarray(Image.open(out_dir / f"{i:06d}.png")).astype(np.float32)
+        assert got.shape == singles[i].shape
+        d = np.abs(got - singles[i]).mean() / 255.0
+        print(f"item {i}: batched vs single-image MAE {d:.3e}")
+        assert d < 5e-3
+    ri.PIPE = None

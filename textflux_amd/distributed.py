@@ -29,6 +29,38 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def respawn_under_torchrun(n_gpus: Optional[int], script: str, argv: Sequence[str]) -> None:
+    """`python script.py --gpus N` without a launcher: replace this process by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> script.py argv`
+    (one rank per GPU over RCCL).  No-op under torchrun (RANK / WORLD_SIZE set) and for N <= 1."""
+    if n_gpus is None or n_gpus <= 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ):
+        return
+    import socket
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(script), *argv]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes on this driver
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def ranks_seen(device) -> int:
+    """Number of ranks that take part in a collective on the default group (1 without a group): sum of ones."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+def shutdown() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def shard_range(n_items: int, rank: int, world: int) -> range:
     """Contiguous, balanced shard of `n_items` work items for `rank` (first n % world ranks get one extra)."""
     q, r = divmod(n_items, world)

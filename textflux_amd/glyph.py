@@ -3,7 +3,7 @@
 Own counterpart of the reference harness (run_inference.py:19-40 prompts, :118-181 single-line strip, :217-376 multi-line
 render, :378-384 concat direction, :409-467 concat + crop).  Geometry and strings are pinned by the known answers of
 SURVEY.md Appendix F (tests/test_host_logic.py); glyph *pixels* are not (the reference's TTF and cv2 are absent here:
-region detection uses scipy.ndimage connected components + axis-aligned boxes instead of cv2.minAreaRect).
+the three OpenCV primitives of the multi-line path are restated on numpy / scipy, see below).
 """
 from __future__ import annotations
 
@@ -74,29 +74,168 @@ def render_single_line(scene: Image.Image, words: Sequence[str], font_path: Opti
     return draw_glyph(load_font(font_path), " ".join(words), w, strip_h), strip_h
 
 
-def mask_regions(mask: Image.Image, min_area: int = 16) -> List[Tuple[int, int, int, int]]:
-    """Bounding boxes (l, t, r, b) of the white regions of the mask, reading order (top-to-bottom, left-to-right)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# Multi-line mode: one text line per mask region, rendered along the region's minimum-area rectangle
+# (reference: render_glyph_multi run_inference.py:330-376, draw_glyph2 :217-328).  The reference leans on OpenCV for three
+# geometric primitives; cv2 is not available here, so they are restated on numpy / scipy with OpenCV's conventions:
+#   findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + boundingRect  -> 8-connected components of the NON-ZERO mask pixels
+#       (nested components inside another component's hole are not separated out -- RETR_EXTERNAL would drop them);
+#   minAreaRect  -> rotating calipers over the convex hull of the component's pixels, angle in (0, 90] and (w, h) assigned as
+#       OpenCV >= 4.5.1 does (requirements.txt does not pin opencv-python; an axis-aligned 100 x 50 box is ((cx, cy), (50, 100), 90));
+#   boxPoints    -> the four corners of that rectangle.
+# Everything after the geometry (angle rule, vertical detection, character spacing, font sizing, PIL drawing, rotation,
+# compositing) follows the reference line by line.  Pixel parity remains unpinned (no cv2, no TTF here: SURVEY a19).
+def mask_regions(mask: Image.Image, min_area: int = 50):
+    """[(x, y, w, h, points)] per region, sorted top-to-bottom then left-to-right (:336-344); points = [n, 2] (x, y) pixel
+    coordinates of the region."""
     from scipy import ndimage
-    m = np.array(mask.convert("L")) > 127
-    lab, n = ndimage.label(m)
-    boxes = []
-    for sl in ndimage.find_objects(lab):
+    m = np.array(mask.convert("L")) != 0
+    lab, n = ndimage.label(m, structure=np.ones((3, 3), dtype=bool))
+    regions = []
+    for idx, sl in enumerate(ndimage.find_objects(lab), start=1):
         if sl is None:
             continue
-        t, b, l, r = sl[0].start, sl[0].stop, sl[1].start, sl[1].stop
-        if (b - t) * (r - l) >= min_area:
-            boxes.append((l, t, r, b))
-    boxes.sort(key=lambda bx: (bx[1], bx[0]))
-    return boxes
+        y0, y1, x0, x1 = sl[0].start, sl[0].stop, sl[1].start, sl[1].stop
+        w, h = x1 - x0, y1 - y0
+        if w * h < min_area:
+            continue
+        ys, xs = np.nonzero(lab[sl] == idx)
+        regions.append((x0, y0, w, h, np.stack([xs + x0, ys + y0], axis=1)))
+    regions.sort(key=lambda r: (r[1], r[0]))
+    return regions
+
+
+def min_area_rect(points: np.ndarray):
+    """((cx, cy), (w, h), angle_deg) of the minimum-area enclosing rectangle, OpenCV >= 4.5.1 conventions."""
+    pts = np.unique(np.asarray(points, dtype=np.float64), axis=0)
+    if len(pts) >= 3:
+        try:
+            from scipy.spatial import ConvexHull
+            hull = pts[ConvexHull(pts).vertices]
+        except Exception:      # degenerate (collinear) point sets
+            hull = pts
+    else:
+        hull = pts
+    best = None
+    n = len(hull)
+    for i in range(n):
+        e = hull[(i + 1) % n] - hull[i]
+        ln = np.hypot(*e)
+        if ln == 0:
+            continue
+        u = e / ln
+        v = np.array([-u[1], u[0]])
+        pu, pv = hull @ u, hull @ v
+        wu, wv = pu.max() - pu.min(), pv.max() - pv.min()
+        if best is None or wu * wv < best[0] - 1e-9:
+            c = u * (pu.max() + pu.min()) / 2 + v * (pv.max() + pv.min()) / 2
+            best = (wu * wv, u, v, wu, wv, c)
+    if best is None:           # a single point / no extent
+        c = pts.mean(0)
+        return (float(c[0]), float(c[1])), (0.0, 0.0), 90.0
+    _, u, v, wu, wv, c = best
+    # the side whose direction angle (atan2(dy, dx), y down) falls in (0, 90] carries the width
+    cand = []
+    for d, ext_d, ext_o in ((u, wu, wv), (-u, wu, wv), (v, wv, wu), (-v, wv, wu)):
+        ang = np.degrees(np.arctan2(d[1], d[0]))
+        if 0.0 < ang <= 90.0 + 1e-9:
+            cand.append((ang, ext_d, ext_o))
+    ang, w, h = max(cand) if cand else (90.0, wv, wu)
+    return (float(c[0]), float(c[1])), (float(w), float(h)), float(min(ang, 90.0))
+
+
+def box_points(rect) -> np.ndarray:
+    (cx, cy), (w, h), ang = rect
+    a = np.radians(ang)
+    b, c = np.cos(a) * 0.5, np.sin(a) * 0.5
+    p0 = (cx - c * h - b * w, cy + b * h - c * w)
+    p1 = (cx + c * h - b * w, cy - b * h - c * w)
+    p2 = (2 * cx - p0[0], 2 * cy - p0[1])
+    p3 = (2 * cx - p1[0], 2 * cy - p1[1])
+    return np.array([p0, p1, p2, p3], dtype=np.float32)
+
+
+def insert_spaces(text: str, num_spaces: int) -> str:
+    return text if len(text) <= 1 else (" " * num_spaces).join(list(text))
+
+
+def draw_glyph2(font, text: str, polygon: np.ndarray, vertAng: int = 10, scale: float = 1, width: int = 512, height: int = 512,
+                add_space: bool = True, scale_factor: int = 2, rotate_resample=Image.BICUBIC,
+                downsample_resample=Image.Resampling.LANCZOS) -> np.ndarray:
+    """RGBA numpy image [height, width, 4] with `text` rendered along the polygon's minimum-area rectangle (:217-328)."""
+    big_w, big_h = width * scale_factor, height * scale_factor
+    rect = min_area_rect(polygon * scale_factor * scale)
+    box = box_points(rect).astype(np.intp)
+    w, h = rect[1]
+    angle = rect[2]
+    if angle < -45:
+        angle += 90
+    angle = -angle
+    if w < h:
+        angle += 90
+    vert = False
+    if abs(angle) % 90 < vertAng or abs(90 - abs(angle) % 90) % 90 < vertAng:
+        _w = max(box[:, 0]) - min(box[:, 0])
+        _h = max(box[:, 1]) - min(box[:, 1])
+        if _h >= _w:
+            vert = True
+            angle = 0
+    big_img = Image.new("RGBA", (big_w, big_h), (0, 0, 0, 0))
+    tmp_draw = ImageDraw.Draw(Image.new("RGB", big_img.size, "white"))
+    _, _, _tw, _th = tmp_draw.textbbox((0, 0), text, font=font)
+    text_w = 0 if _th == 0 else min(float(w), float(h)) * (_tw / _th)
+    if text_w <= max(w, h):
+        if len(text) > 1 and not vert and add_space:
+            i = 1
+            for i in range(1, 100):
+                _, _, tw2, th2 = tmp_draw.textbbox((0, 0), insert_spaces(text, i), font=font)
+                if th2 != 0 and min(w, h) * (tw2 / th2) > max(w, h):
+                    break
+            text = insert_spaces(text, i - 1)
+        font_size = min(w, h) * 0.80
+    else:
+        shrink = 0.75 if vert else 0.85
+        font_size = min(w, h) / (text_w / max(w, h)) * shrink if text_w != 0 else min(w, h) * 0.80
+    try:
+        new_font = font.font_variant(size=max(int(font_size), 1))
+    except Exception:          # PIL's built-in bitmap font has no variants
+        new_font = font
+    left, top, right, bottom = new_font.getbbox(text)
+    text_width, text_height = right - left, bottom - top
+    layer = Image.new("RGBA", big_img.size, (0, 0, 0, 0))
+    draw_layer = ImageDraw.Draw(layer)
+    cx, cy = rect[0]
+    if not vert:
+        draw_layer.text((cx - text_width // 2, cy - text_height // 2 - top), text, font=new_font, fill=(255, 255, 255, 255))
+    else:
+        _w_ = max(box[:, 0]) - min(box[:, 0])
+        x_s = min(box[:, 0]) + _w_ // 2 - text_height // 2
+        y_s = min(box[:, 1])
+        for ch in text:
+            draw_layer.text((x_s, y_s), ch, font=new_font, fill=(255, 255, 255, 255))
+            _, _t, _, _b = new_font.getbbox(ch)
+            y_s += _b
+    rotated = layer.rotate(angle, expand=True, center=(cx, cy), resample=rotate_resample)
+    xo = int((big_img.width - rotated.width) // 2)
+    yo = int((big_img.height - rotated.height) // 2)
+    big_img.paste(rotated, (xo, yo), rotated)
+    return np.array(big_img.resize((width, height), downsample_resample))
 
 
 def render_multiline(scene: Image.Image, mask: Image.Image, texts: Sequence[str], font_path: Optional[str] = None):
-    """One text line per mask region, drawn at the region's position on a black canvas of the scene's size."""
-    canvas = Image.new("RGB", scene.size, "black")
-    font = load_font(font_path)
-    for (l, t, r, b), text in zip(mask_regions(mask), texts):
-        canvas.paste(draw_glyph(font, text, max(r - l, 1), max(b - t, 1)), (l, t))
-    return canvas
+    """render_glyph_multi (:330-376): region i gets text line i, composited onto a transparent-black canvas."""
+    render = Image.new("RGBA", scene.size, (0, 0, 0, 0))
+    base_font = load_font(font_path, 40)
+    for i, region in enumerate(mask_regions(mask)):
+        if i >= len(texts):
+            break
+        text = texts[i].strip()
+        if not text:
+            continue
+        rgba = draw_glyph2(base_font, text, region[4], vertAng=10, scale=1, width=scene.size[0], height=scene.size[1],
+                           add_space=True, scale_factor=1)
+        render = Image.alpha_composite(render, Image.fromarray(rgba, mode="RGBA"))
+    return render.convert("RGB")
 
 
 def choose_concat_direction(height: int, width: int) -> str:
