@@ -175,6 +175,39 @@ typedef struct tfx_dit_desc {
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
 
+/* Caller-owned workspace of tfx_dit_forward for one problem size, as ONE allocation: total bytes, and the byte offsets
+ * (256-byte aligned) of its parts in off[0..5] = hid, xn, y, q8, q8_scale, gemm_workspace (q8 / q8_scale only when
+ * flags bit 2 (fp8 linears) is set, else -1); *gemm_workspace_bytes = size of the split-K scratch (64 MiB).  Host-side
+ * arithmetic only, no GPU needed.  ("never allocate persistent memory except through an explicit
+ * workspace the Python side owns".) */
+int64_t tfx_workspace_bytes(int32_t B, int32_t S, int32_t T, int32_t D, int32_t flags);
+int tfx_workspace_layout(int32_t B, int32_t S, int32_t T, int32_t D, int32_t flags, int64_t* off, int64_t* gemm_workspace_bytes);
+
+/* ---- one denoising step = modulation rows of step *step_ptr -> tfx_dit_forward -> scheduler update -> ++*step_ptr, and
+ *      its capture into a hipGraph (D/pipelines/flux/pipeline_flux_fill.py:2077-2116: the loop body; the reference issues
+ *      ~4.5 k launches per step from Python, here a step is ONE hipGraphLaunch).  The step index lives on the device, so the
+ *      same graph serves every step: mod_table [n_steps][B][mod_len] (tfx_dit_desc.mod must point at mod_cur, which the step
+ *      refreshes from the table), coef as for tfx_euler_step / tfx_amo_step (sampler 0 / 1), noise fp32 [B*S, out_channels]
+ *      (AMO only; rewritten by the caller between replays), latents [B*S, out_channels] updated in place and mirrored into
+ *      columns [0, out_channels) of dit.xin.
+ *      tfx_dit_step_run: the eager form (call it at least once before capturing: first launches size LDS limits).
+ *      tfx_dit_step_capture: records the same launches on `stream` (must not be the NULL stream) in thread-local capture
+ *      mode and instantiates them; tfx_dit_step_replay launches the instantiated graph; tfx_graph_destroy frees it.
+ *      All pointers of the descriptor are baked into the graph: they must stay valid (and unmoved) while it is replayed. */
+typedef struct tfx_step_desc {
+  tfx_dit_desc dit;
+  const void* mod_table; void* mod_cur; int64_t mod_step_elems;   /* elements per step = B * mod_len */
+  int32_t* step_ptr;
+  void* latents;
+  const float* coef; const float* noise;
+  int32_t sampler;                                                 /* 0 Euler, 1 AMO */
+} tfx_step_desc;
+typedef void* tfx_graph;
+int tfx_dit_step_run(const tfx_step_desc* step, tfx_stream stream);
+int tfx_dit_step_capture(const tfx_step_desc* step, tfx_stream stream, tfx_graph* out);
+int tfx_dit_step_replay(tfx_graph graph, tfx_stream stream);
+int tfx_graph_destroy(tfx_graph graph);
+
 /* ---- VAE ends (AutoencoderKL, D/models/autoencoders/autoencoder_kl.py:263-332) on NHWC bf16 activations -------------
  * 3x3 convolution as an implicit GEMM on the MFMA kernel (ResnetBlock2D convs D/models/resnet.py:327-366, Upsample2D
  * nearest-2x + conv D/models/upsampling.py:142-192 with up = 2, Downsample2D pad (0,1,0,1) stride 2

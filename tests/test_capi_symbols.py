@@ -42,12 +42,27 @@ def test_null_arguments_are_rejected_without_a_gpu(lib):
     assert lib.tfx_joint_attention(None, None) != 0
 
 
+def test_workspace_layout_is_host_arithmetic(lib):
+    import ctypes as C
+    off, gws = (C.c_int64 * 6)(), C.c_int64()
+    B, S, T, D = 8, 4096, 512, 3072
+    assert lib.tfx_workspace_layout(B, S, T, D, 0, off, C.byref(gws)) == 0
+    N = S + T
+    assert list(off)[:3] == [0, B * N * D * 2, 2 * B * N * D * 2] and off[3] == off[4] == -1 and gws.value == 64 << 20
+    assert off[5] == 2 * B * N * D * 2 + B * N * 7 * D * 2
+    assert lib.tfx_workspace_bytes(B, S, T, D, 0) == off[5] + gws.value
+    assert lib.tfx_workspace_layout(B, S, T, D, 4, off, C.byref(gws)) == 0 and off[3] > 0 and off[4] == off[3] + B * N * 5 * D
+    assert all(o % 256 == 0 for o in off) and lib.tfx_workspace_bytes(0, S, T, D, 0) == -1
+    assert lib.tfx_dit_step_run(None, None) != 0 and lib.tfx_dit_step_replay(None, None) != 0 and lib.tfx_graph_destroy(None) == 0
+
+
 def test_struct_layouts_match_the_header(tmp_path):
     """sizeof/offsetof as gcc sees include/textflux_hip.h == the ctypes mirror in textflux_amd/_lib.py."""
     import ctypes as C
     import subprocess
     structs = {"tfx_gemm_args": L.GemmArgs, "tfx_attn_args": L.AttnArgs, "tfx_linear": L.Linear,
-               "tfx_double_block": L.DoubleBlock, "tfx_single_block": L.SingleBlock, "tfx_dit_desc": L.DitDesc}
+               "tfx_double_block": L.DoubleBlock, "tfx_single_block": L.SingleBlock, "tfx_dit_desc": L.DitDesc,
+               "tfx_step_desc": L.StepDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "textflux_hip.h"', 'int main(void){']
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -73,6 +73,11 @@ class DitDesc(C.Structure):
     ]
 
 
+class StepDesc(C.Structure):
+    _fields_ = [("dit", DitDesc), ("mod_table", c_void_p), ("mod_cur", c_void_p), ("mod_step_elems", c_int64),
+                ("step_ptr", c_void_p), ("latents", c_void_p), ("coef", c_void_p), ("noise", c_void_p), ("sampler", c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/textflux_hip.h declares must appear here (tests check it)
 SIGNATURES = {
     "tfx_version": (c_char_p, []),
@@ -103,6 +108,12 @@ SIGNATURES = {
     "tfx_select_step": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "tfx_advance_step": (c_int, [c_void_p, c_void_p]),
     "tfx_dit_forward": (c_int, [C.POINTER(DitDesc), c_void_p]),
+    "tfx_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "tfx_workspace_layout": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, C.POINTER(c_int64), C.POINTER(c_int64)]),
+    "tfx_dit_step_run": (c_int, [C.POINTER(StepDesc), c_void_p]),
+    "tfx_dit_step_capture": (c_int, [C.POINTER(StepDesc), c_void_p, C.POINTER(c_void_p)]),
+    "tfx_dit_step_replay": (c_int, [c_void_p, c_void_p]),
+    "tfx_graph_destroy": (c_int, [c_void_p]),
     "tfx_conv3x3_nhwc": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                  c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int, c_void_p]),
     "tfx_groupnorm_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,

@@ -397,6 +397,91 @@ int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launc
   return prof_collect(kind, total_ms, total_flops, launches);
 }
 
+static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+int tfx_workspace_layout(int32_t B, int32_t Sn, int32_t T, int32_t D, int32_t flags, int64_t* off, int64_t* gemm_ws_bytes) {
+  if (B <= 0 || Sn <= 0 || T < 0 || D <= 0 || !off) return fail("tfx_workspace_layout: bad arguments");
+  const int64_t N = (int64_t)Sn + T, hid = align256(B * N * D * 2), y = align256(B * N * 7 * (int64_t)D * 2);
+  const bool fp8 = (flags & 4) != 0;
+  const int64_t q8 = fp8 ? align256(B * N * 5 * (int64_t)D) : 0, q8s = fp8 ? align256(B * N * 4) : 0, gws = 64ll << 20;
+  int64_t o = 0;
+  off[0] = o; o += hid;
+  off[1] = o; o += hid;
+  off[2] = o; o += y;
+  off[3] = fp8 ? o : -1; o += q8;
+  off[4] = fp8 ? o : -1; o += q8s;
+  off[5] = o;
+  if (gemm_ws_bytes) *gemm_ws_bytes = gws;
+  return 0;
+}
+int64_t tfx_workspace_bytes(int32_t B, int32_t Sn, int32_t T, int32_t D, int32_t flags) {
+  int64_t off[6], gws = 0;
+  if (tfx_workspace_layout(B, Sn, T, D, flags, off, &gws)) return -1;
+  return off[5] + gws;
+}
+
+namespace {
+struct StepGraph { hipGraph_t graph; hipGraphExec_t exec; };
+
+int step_check(const tfx_step_desc* s) {
+  if (!s) return fail("tfx_dit_step: null descriptor");
+  if (!s->mod_table || !s->mod_cur || !s->step_ptr || !s->latents || !s->coef) return fail("tfx_dit_step: null pointer in descriptor");
+  if (s->dit.mod != s->mod_cur) return fail("tfx_dit_step: dit.mod must point at mod_cur (the rows the step selects)");
+  if (s->sampler != 0 && s->sampler != 1) return fail("tfx_dit_step: sampler must be 0 (Euler) or 1 (AMO)");
+  if (s->sampler == 1 && !s->noise) return fail("tfx_dit_step: the AMO sampler needs a noise buffer");
+  if (!s->dit.out) return fail("tfx_dit_step: dit.out is null");
+  return 0;
+}
+
+int step_enqueue(const tfx_step_desc& s, hipStream_t st) {
+  TRY(select_step(s.mod_table, s.mod_cur, s.mod_step_elems, s.step_ptr, st));
+  TRY(tfx_dit_forward(&s.dit, (tfx_stream)st));
+  const int64_t rows = (int64_t)s.dit.B * s.dit.S;
+  TRY(sched_step(s.sampler == 1, s.dit.out, s.latents, const_cast<void*>(s.dit.xin), s.dit.in_channels, s.dit.out_channels, rows,
+                 s.coef, s.step_ptr, 0, s.noise, st));
+  return advance_step(s.step_ptr, st);
+}
+}  // namespace
+
+int tfx_dit_step_run(const tfx_step_desc* s, tfx_stream stream) {
+  TRY(step_check(s));
+  return step_enqueue(*s, S(stream));
+}
+
+int tfx_dit_step_capture(const tfx_step_desc* s, tfx_stream stream, tfx_graph* out) {
+  TRY(step_check(s));
+  if (!out) return fail("tfx_dit_step_capture: null output handle");
+  if (!stream) return fail("tfx_dit_step_capture: the NULL stream cannot be captured; pass a created stream");
+  hipStream_t st = S(stream);
+  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return fail("tfx_dit_step_capture: hipStreamBeginCapture: %s", hipGetErrorString(e));
+  const int rc = step_enqueue(*s, st);
+  hipGraph_t g = nullptr;
+  e = hipStreamEndCapture(st, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }    // last error already set by the failing launcher
+  if (e != hipSuccess || !g) return fail("tfx_dit_step_capture: hipStreamEndCapture: %s", hipGetErrorString(e));
+  hipGraphExec_t x = nullptr;
+  e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); return fail("tfx_dit_step_capture: hipGraphInstantiate: %s", hipGetErrorString(e)); }
+  *out = new StepGraph{g, x};
+  return 0;
+}
+
+int tfx_dit_step_replay(tfx_graph graph, tfx_stream stream) {
+  if (!graph) return fail("tfx_dit_step_replay: null graph");
+  const hipError_t e = hipGraphLaunch(((StepGraph*)graph)->exec, S(stream));
+  if (e != hipSuccess) return fail("tfx_dit_step_replay: hipGraphLaunch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int tfx_graph_destroy(tfx_graph graph) {
+  if (!graph) return 0;
+  StepGraph* g = (StepGraph*)graph;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+  return 0;
+}
+
 int tfx_dit_forward(const tfx_dit_desc* d, tfx_stream stream) {
   if (!d) return fail("tfx_dit_forward: null descriptor");
   if (!d->xin || !d->mod || !d->hid || !d->xn || !d->y || !d->out || !d->cos_tab || !d->sin_tab)

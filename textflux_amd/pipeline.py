@@ -499,57 +499,64 @@ class FluxFillPipeline:
         return self
 
     def _graph_loop(self, ses, mod, latents, coef, is_amo, amo_noise, n, progress_bar):
+        """The loop as ONE captured step graph replayed n - 1 times (C ABI: tfx_dit_step_run / _capture / _replay; the
+        hipGraph API is driven by the library, not by torch).  Capture needs a non-NULL stream: the loop runs on the
+        session's side stream, fenced against the caller's current stream on both sides."""
+        import ctypes as C
+        from . import _lib as L
         dev = latents.device
-        B = latents.shape[0]
         gb = ses.graph_buffers(n, coef.numel(), latents.shape)
         gb["mod_table"][:n].copy_(mod)
         gb["coef"][:coef.numel()].copy_(coef.reshape(-1))
         gb["lat"].copy_(latents)
         gb["step"].zero_()
         internal_noise = is_amo and amo_noise is None
+        sd = ses.step_desc(gb, is_amo)
+        ses._mod_keepalive = gb["mod_cur"]
+        lib = L.lib()
+        cur = torch.cuda.current_stream(dev)
+        side = ses.graph_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            st = side.cuda_stream
 
-        def one_step():
-            ops.select_step_(gb["mod_table"], gb["mod_cur"], gb["step"])
-            v = ses.run(gb["mod_cur"])
-            if is_amo:
+            def feed_noise(i):
                 if internal_noise:
-                    gb["noise"].normal_()   # global device RNG, as the reference's randn_tensor(generator=None)
-                ops.amo_step_(v, gb["lat"], gb["coef"], gb["noise"], step_ptr=gb["step"], xin=ses.xin)
-            else:
-                ops.euler_step_(v, gb["lat"], gb["coef"], step_ptr=gb["step"], xin=ses.xin)
-            ops.advance_step_(gb["step"])
+                    gb["noise"].normal_()      # global device RNG, as the reference's randn_tensor(generator=None); not captured
+                elif is_amo:
+                    gb["noise"].copy_(amo_noise[i].to(dev, torch.float32))
 
-        if is_amo and not internal_noise:
-            gb["noise"].copy_(amo_noise[0].to(dev, torch.float32))
-        one_step()                                   # eager step 0: also warms every kernel before capture
-        progress_bar.update()
-        key = (is_amo, internal_noise)
-        g = ses.graphs.get(key)
-        if g is None:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            saved = [gb[k].clone() for k in ("lat", "step")] + [ses.xin.clone()]
-            try:
-                # thread_local: a collective watchdog thread (RCCL) touching the runtime must not invalidate the capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    one_step()
-            except RuntimeError as e:   # capture refused (driver / runtime state): same kernels, launched eagerly
-                warnings.warn(f"hipGraph capture of the denoising step failed ({e}); running the step loop eagerly")
-                torch.cuda.synchronize()
-                g = False
-            # capture does not execute, but keep the state explicit in case a backend replays during instantiate
-            gb["lat"].copy_(saved[0]); gb["step"].copy_(saved[1]); ses.xin.copy_(saved[2])
-            ses.graphs[key] = g
-        for i in range(1, n):
-            if is_amo and not internal_noise:
-                gb["noise"].copy_(amo_noise[i].to(dev, torch.float32))
-            if g is False:
-                one_step()
-            else:
-                g.replay()
+            feed_noise(0)
+            L.check(lib.tfx_dit_step_run(C.byref(sd), st), "dit_step_run")     # eager step 0: also warms every kernel
             progress_bar.update()
+            key = (is_amo,)
+            g = ses.graphs.get(key)
+            if g is None:
+                side.synchronize()
+                saved = [gb[k].clone() for k in ("lat", "step")] + [ses.xin.clone()]
+                h = C.c_void_p()
+                rc = lib.tfx_dit_step_capture(C.byref(sd), st, C.byref(h))
+                if rc != 0:     # capture refused (driver / runtime state): same kernels, launched eagerly
+                    warnings.warn(f"hipGraph capture of the denoising step failed ({lib.tfx_last_error().decode()}); "
+                                  "running the step loop eagerly")
+                    g = False
+                else:
+                    g = h.value
+                # capture does not execute; keep the state explicit anyway
+                gb["lat"].copy_(saved[0]); gb["step"].copy_(saved[1]); ses.xin.copy_(saved[2])
+                ses.graphs[key] = g
+            for i in range(1, n):
+                feed_noise(i)
+                if g is False:
+                    L.check(lib.tfx_dit_step_run(C.byref(sd), st), "dit_step_run")
+                else:
+                    L.check(lib.tfx_dit_step_replay(g, st), "dit_step_replay")
+                progress_bar.update()
+            out = gb["lat"].clone()
+        out.record_stream(cur)
+        cur.wait_stream(side)
         self.scheduler._step_index = n
-        return gb["lat"].clone()
+        return out
 
     def _generic_loop(self, latents, masked_image_latents, prompt_embeds, pooled, text_ids, latent_image_ids, timesteps,
                       guidance, callback_on_step_end, callback_tensor_inputs, progress_bar):

@@ -345,8 +345,23 @@ class DitSession:
         e = lambda *shape: torch.empty(*shape, dtype=BF16, device=dev)
         self.xin = e(B, S, c.in_channels)
         self.ctx0 = e(B, T, D)
-        self.hid, self.xn, self.y = e(B, N, D), e(B, N, D), e(B, N, 7 * D)
         self.out = e(B, S, model.out_channels)
+        # the engine's workspace is ONE allocation laid out by the library (tfx_workspace_layout): hid | xn | y | q8 | ...
+        self.fp8 = bool(model.w8)
+        flags = 4 if self.fp8 else 0
+        off, gws = (C.c_int64 * 6)(), C.c_int64()
+        L.check(L.lib().tfx_workspace_layout(B, S, T, D, flags, off, C.byref(gws)), "workspace_layout")
+        total = L.lib().tfx_workspace_bytes(B, S, T, D, flags)
+        self.workspace = torch.empty(total, dtype=torch.uint8, device=dev)
+
+        def carve(o, shape, dtype):
+            n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+            return self.workspace[o:o + n].view(dtype).view(*shape)
+
+        self.hid, self.xn, self.y = carve(off[0], (B, N, D), BF16), carve(off[1], (B, N, D), BF16), carve(off[2], (B, N, 7 * D), BF16)
+        self.q8 = carve(off[3], (B, N, 5 * D), torch.uint8) if self.fp8 else None
+        self.q8_scale = carve(off[4], (B, N), torch.float32) if self.fp8 else None
+        self.gemm_ws = carve(off[5], (gws.value // 4,), torch.float32)
         # RoPE tables: allocated ONCE per session and refreshed in place -- captured step graphs bake these pointers
         # into the kernel arguments, so a new ids layout for the same (B, S, T) must not move them
         self.cos = torch.empty(N, c.attention_head_dim, dtype=torch.float32, device=dev)
@@ -361,9 +376,6 @@ class DitSession:
             return L.Linear(w[name + ".w"].data_ptr(), w[name + ".b"].data_ptr(), q[0].data_ptr() if q else None,
                             q[1].data_ptr() if q else None)
 
-        self.fp8 = bool(w8)
-        self.q8 = torch.empty(B, N, 5 * D, dtype=torch.uint8, device=dev) if self.fp8 else None
-        self.q8_scale = torch.empty(B, N, dtype=torch.float32, device=dev) if self.fp8 else None
         self._dbl = (L.DoubleBlock * max(1, c.num_layers))()
         for i in range(c.num_layers):
             b = self._dbl[i]
@@ -390,10 +402,35 @@ class DitSession:
             d.q8, d.q8_scale = self.q8.data_ptr(), self.q8_scale.data_ptr()
         # scratch for the split-K path of few-tile GEMMs (text stream, small batch x resolution): fp32 partials of at most
         # slices x tiles <= 256 tiles of 256 x 256, i.e. 64 MiB whatever the problem size
-        self.gemm_ws = torch.empty(256 * 256 * 256, dtype=torch.float32, device=dev)
         d.gemm_workspace, d.gemm_workspace_bytes = self.gemm_ws.data_ptr(), self.gemm_ws.numel() * 4
-        self.graphs = {}
+        self.graphs = {}        # (sampler, ...) -> C-level step graph handle (tfx_dit_step_capture)
         self._gb = None
+        self._gstream = None    # side stream the step graphs are captured / replayed on
+
+    def __del__(self):
+        try:
+            for g in self.graphs.values():
+                if g:
+                    L.lib().tfx_graph_destroy(g)
+        except Exception:
+            pass
+
+    def graph_stream(self) -> "torch.cuda.Stream":
+        if self._gstream is None:
+            self._gstream = torch.cuda.Stream(device=self.model.device)
+        return self._gstream
+
+    def step_desc(self, gb, is_amo: bool) -> "L.StepDesc":
+        """tfx_step_desc of one denoising step over the persistent graph buffers `gb` (graph_buffers())."""
+        d = self.desc
+        d.mod, d.mod_bstride = gb["mod_cur"].data_ptr(), gb["mod_cur"].stride(0)
+        d.first_block, d.last_block, d.flags = 0, -1, (4 if self.fp8 else 0)
+        sd = L.StepDesc()
+        sd.dit = d
+        sd.mod_table, sd.mod_cur, sd.mod_step_elems = gb["mod_table"].data_ptr(), gb["mod_cur"].data_ptr(), gb["mod_cur"].numel()
+        sd.step_ptr, sd.latents = gb["step"].data_ptr(), gb["lat"].data_ptr()
+        sd.coef, sd.noise, sd.sampler = gb["coef"].data_ptr(), gb["noise"].data_ptr() if is_amo else None, 1 if is_amo else 0
+        return sd
 
     def set_conditioning(self, prompt_embeds: torch.Tensor, txt_ids: torch.Tensor, img_ids: torch.Tensor) -> None:
         """context_embedder(prompt_embeds) -> ctx0; RoPE tables for cat(txt_ids, img_ids)."""
@@ -414,6 +451,9 @@ class DitSession:
         gb = self._gb
         if gb is None or gb["mod_table"].shape[0] < n_steps or gb["coef"].numel() < n_coef:
             dev = self.model.device
+            for g in self.graphs.values():
+                if g:
+                    L.lib().tfx_graph_destroy(g)
             self.graphs = {}
             gb = self._gb = dict(
                 mod_table=torch.empty(n_steps, self.B, self.model.mod_len, dtype=BF16, device=dev),
