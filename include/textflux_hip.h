@@ -260,6 +260,27 @@ int tfx_transpose(const void* in, int64_t ldi, int64_t in_bstride, void* out, in
                   int32_t C, int32_t batch, tfx_stream stream);
 int tfx_row_softmax(const float* s, int64_t lds, void* p, int64_t ldp, int32_t rows, int32_t N, float scale, tfx_stream stream);
 
+/* ---- text encoders of encode_prompt (P:1411-1503: CLIP-L pooled output of `prompt`, T5-XXL sequence of `prompt_2`).  The
+ *      reference calls third-party `transformers` (pinned 4.43.3: models/t5/modeling_t5.py T5Stack / T5Block / T5Attention /
+ *      T5LayerNorm / T5DenseGatedActDense; models/clip/modeling_clip.py CLIPTextTransformer / CLIPEncoderLayer / CLIPAttention /
+ *      CLIPMLP); the Linear layers run on tfx_gemm_bf16 / tfx_gemm_bf16_f32, LayerNorm on tfx_ln_modulate, and: */
+/* softmax(scale * q k^T + bias) v for heads of dim 64 and N <= 512 keys (tfx_attn_args with 64-wide heads: element (b, n, h, d)
+ * at base + b*bstride + n*ld + h*64 + d).  rel_bias: NULL or fp32 [H, 2N-1], bias(h, query, key) = rel_bias[h][key - query +
+ * N - 1] (T5Attention.compute_bias: a function of key - query only); causal != 0 masks key > query (CLIP). */
+int tfx_attention64(const tfx_attn_args* args, const float* rel_bias, int32_t causal, tfx_stream stream);
+/* T5LayerNorm: out[r, :] = bf16(w * bf16(x[r, :] * rsqrt(mean(x[r, :]^2) + eps))); x f32 (x_dtype 0) or bf16 (1). */
+int tfx_rmsnorm(const void* x, int32_t x_dtype, int64_t ldx, const void* w, void* out, int64_t ldo, int64_t rows, int32_t D,
+                float eps, tfx_stream stream);
+/* out[i, :] = table[ids[i], :] (bf16 rows of D elements, ids int64 clamped to [0, vocab)): nn.Embedding. */
+int tfx_gather_rows(const void* table, const int64_t* ids, void* out, int64_t n, int32_t D, int64_t vocab, tfx_stream stream);
+/* fp32 residual stream of T5 under torch_dtype = bf16 (`wo` is kept in fp32, bf16 + fp32 promotes): mode 0 x += y (bf16),
+ * 1 x += y (f32), 2 x = y (bf16 -> f32). */
+int tfx_add_into_f32(float* x, const void* y, int64_t n, int32_t mode, tfx_stream stream);
+/* mode 0: out = a * b (T5DenseGatedActDense: gelu(wi_0 x) * wi_1 x), mode 1: out = a * sigmoid(1.702 a) (CLIP quick_gelu);
+ * bf16 [rows, cols] with row strides. */
+int tfx_mul_act(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int32_t cols,
+                int32_t mode, tfx_stream stream);
+
 /* ---- tuning knobs (no reference counterpart).  "attention_waves" selects the attention kernel: 10 (default) = one
  *      512-thread workgroup of 256 query rows per CU with the softmax bookkeeping on the matrix pipe (pre-scaled Q, lazy
  *      reference maximum subtracted by an extra MFMA k-step, row sums from a ones-block of the PV MFMA); 8 = the same

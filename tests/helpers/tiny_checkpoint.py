@@ -20,7 +20,7 @@ from safetensors.torch import save_file
 from oracle import flux_oracle as fo
 from oracle import vae_oracle as vo
 
-TR_CFG = fo.FluxConfig(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32)
+TR_CFG = fo.FluxConfig(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=128)
 VAE_KW = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=1, latent_channels=16, norm_num_groups=16)
 SCHED = dict(_class_name="FlowMatchEulerDiscreteScheduler", num_train_timesteps=1000, shift=3.0, use_dynamic_shifting=True,
              base_shift=0.5, max_shift=1.15, base_image_seq_len=256, max_image_seq_len=4096)
@@ -74,12 +74,18 @@ def write_tokenizers(root):
 def write_text_encoders(root, clip_vocab, t5_vocab, seed=0):
     from transformers import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
     torch.manual_seed(seed)
-    clip = CLIPTextModel(CLIPTextConfig(vocab_size=clip_vocab, hidden_size=32, intermediate_size=64, num_hidden_layers=2,
-                                        num_attention_heads=2, max_position_embeddings=77, projection_dim=32,
-                                        bos_token_id=clip_vocab - 2, eos_token_id=clip_vocab - 1, pad_token_id=clip_vocab - 1)).eval()
-    t5 = T5EncoderModel(T5Config(vocab_size=t5_vocab, d_model=64, d_kv=16, d_ff=128, num_layers=2, num_heads=4,
+    # heads of dim 64 in both (the real CLIP-L / T5-XXL geometry the HIP attention kernel is written for); CLIP pools at the
+    # largest token id (eos_token_id = 2: the legacy convention of FLUX's text_encoder config)
+    clip = CLIPTextModel(CLIPTextConfig(vocab_size=clip_vocab, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                        num_attention_heads=2, max_position_embeddings=77, projection_dim=64,
+                                        hidden_act="quick_gelu", bos_token_id=clip_vocab - 2, eos_token_id=2,
+                                        pad_token_id=clip_vocab - 1)).eval()
+    t5 = T5EncoderModel(T5Config(vocab_size=t5_vocab, d_model=64, d_kv=64, d_ff=128, num_layers=2, num_heads=2,
                                  feed_forward_proj="gated-gelu", relative_attention_num_buckets=32,
                                  relative_attention_max_distance=128)).eval()
+    for m in (clip, t5):
+        for prm in m.parameters():
+            prm.data.add_(torch.randn_like(prm) * 0.05)
     clip.save_pretrained(os.path.join(root, "text_encoder"), safe_serialization=True)
     t5.save_pretrained(os.path.join(root, "text_encoder_2"), safe_serialization=True)
     return clip, t5

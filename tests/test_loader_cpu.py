@@ -27,7 +27,7 @@ def test_sharded_transformer_loads_like_a_flat_state_dict(ckpt):
     assert len(split) >= 50         # the layout really does separate weights from their biases
     m = FluxTransformer2DModel.from_pretrained(root, subfolder="transformer", device="cpu")
     ref = FluxTransformer2DModel.from_config(dict(num_layers=2, num_single_layers=2, num_attention_heads=2, in_channels=384,
-                                                  out_channels=64, joint_attention_dim=64, pooled_projection_dim=32,
+                                                  out_channels=64, joint_attention_dim=64, pooled_projection_dim=128,
                                                   guidance_embeds=True)).load_state_dict(sd, device="cpu")
     assert m.w.keys() == ref.w.keys()
     for k in m.w:

@@ -130,6 +130,11 @@ SIGNATURES = {
     "tfx_postprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "tfx_transpose": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "tfx_row_softmax": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "tfx_attention64": (c_int, [C.POINTER(AttnArgs), c_void_p, c_int32, c_void_p]),
+    "tfx_rmsnorm": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_float, c_void_p]),
+    "tfx_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p]),
+    "tfx_add_into_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "tfx_mul_act": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
     "tfx_set_option": (c_int, [c_char_p, c_int]),
     "tfx_prof_enable": (c_int, [c_int]),
     "tfx_prof_collect": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),

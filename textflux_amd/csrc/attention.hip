@@ -775,7 +775,7 @@ void set_attention_debug(void* p) {
 }
 static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
-void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12) ? nw : 16; }
+void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20) ? nw : 16; }
 
 int joint_attention(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.H <= 0 || a.N <= 0) return 0;
@@ -783,6 +783,13 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     return fail("attention: strides must be multiples of 8 elements (q,k,v) / 4 (o)");
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 || (uintptr_t)a.o % 8)
     return fail("attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
+  if (g_attn_waves == 20 && !g_attn_abl) {   // half-tile software-pipelined kernel
+    const bool prof = prof_on(st);
+    if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
+    const int rc = joint_attention_hp(a, st);
+    if (prof) prof_end(1, st);
+    return rc ? rc : check_launch("joint_attention");
+  }
   const int NW = (g_attn_waves == 16 || g_attn_waves == 9 || g_attn_waves == 10) ? 8 : g_attn_waves == 12 ? 4 : g_attn_waves;
   const bool pp = g_attn_waves == 16;
   const int qblk = NW * 32;

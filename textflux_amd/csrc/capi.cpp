@@ -374,11 +374,39 @@ int tfx_row_softmax(const float* s, int64_t lds, void* p, int64_t ldp, int32_t r
   return row_softmax(s, lds, p, ldp, rows, N, scale, S(stream));
 }
 
+int tfx_attention64(const tfx_attn_args* g, const float* rel_bias, int32_t causal, tfx_stream stream) {
+  if (!g || !g->q || !g->k || !g->v || !g->o) return fail("tfx_attention64: null pointer");
+  AttnArgs a;
+  a.q = g->q; a.k = g->k; a.v = g->v; a.o = g->o;
+  a.ldq = g->ldq; a.ldk = g->ldk; a.ldv = g->ldv; a.ldo = g->ldo;
+  a.q_bstride = g->q_bstride; a.k_bstride = g->k_bstride; a.v_bstride = g->v_bstride; a.o_bstride = g->o_bstride;
+  a.B = g->B; a.H = g->H; a.N = g->N; a.scale = g->scale;
+  return attention64(a, rel_bias, causal, S(stream));
+}
+int tfx_rmsnorm(const void* x, int32_t x_dtype, int64_t ldx, const void* w, void* out, int64_t ldo, int64_t rows, int32_t D,
+                float eps, tfx_stream stream) {
+  if (!x || !w || !out) return fail("tfx_rmsnorm: null pointer");
+  return rmsnorm(x, x_dtype, ldx, w, out, ldo, rows, D, eps, S(stream));
+}
+int tfx_gather_rows(const void* table, const int64_t* ids, void* out, int64_t n, int32_t D, int64_t vocab, tfx_stream stream) {
+  if (!table || !ids || !out) return fail("tfx_gather_rows: null pointer");
+  return gather_rows(table, ids, out, n, D, vocab, S(stream));
+}
+int tfx_add_into_f32(float* x, const void* y, int64_t n, int32_t mode, tfx_stream stream) {
+  if (!x || !y) return fail("tfx_add_into_f32: null pointer");
+  return add_into_f32(x, y, n, mode, S(stream));
+}
+int tfx_mul_act(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int32_t cols,
+                int32_t mode, tfx_stream stream) {
+  if (!a || !out) return fail("tfx_mul_act: null pointer");
+  return mul_act(a, lda, b, ldb, out, ldo, rows, cols, mode, S(stream));
+}
+
 int tfx_set_option(const char* name, int value) {
   if (!name) return fail("tfx_set_option: null name");
   if (!std::strcmp(name, "attention_waves")) {
-    if (value != 4 && value != 8 && value != 9 && value != 10 && value != 12 && value != 16)
-      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves) or 16 (ping-pong)");
+    if (value != 4 && value != 8 && value != 9 && value != 10 && value != 12 && value != 16 && value != 20)
+      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves), 16 (ping-pong) or 20 (half-tile pipelined)");
     set_attention_waves(value);
     return 0;
   }

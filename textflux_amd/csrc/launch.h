@@ -76,6 +76,7 @@ struct AttnArgs {
   float scale;
 };
 int joint_attention(const AttnArgs& a, hipStream_t st);
+int joint_attention_hp(const AttnArgs& a, hipStream_t st);   // half-tile software-pipelined kernel (attention_hp.hip)
 void set_attention_ablation(int a);
 void set_attention_debug(void* p);
 void set_attention_waves(int nw);  // 8 (one 512-thread workgroup per CU) or 4 (two independent 256-thread workgroups)
@@ -109,6 +110,14 @@ int postprocess(const void* x, void* out, int B, int64_t HW, int Cs, int C, int 
 int transpose_bf16(const void* in, int64_t ldi, int64_t ibs, void* out, int64_t ldo, int64_t obs, int N, int C, int batch,
                    hipStream_t st);
 int row_softmax(const float* s, int64_t lds, void* p, int64_t ldp, int rows, int N, float scale, hipStream_t st);
+// text-encoder kernels (textenc.hip)
+int attention64(const AttnArgs& a, const float* rel_bias, int causal, hipStream_t st);
+int rmsnorm(const void* x, int x_dtype, int64_t ldx, const void* w, void* out, int64_t ldo, int64_t rows, int D, float eps,
+            hipStream_t st);
+int gather_rows(const void* table, const int64_t* ids, void* out, int64_t n, int D, int64_t vocab, hipStream_t st);
+int add_into_f32(float* x, const void* y, int64_t n, int mode, hipStream_t st);
+int mul_act(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int cols, int mode,
+            hipStream_t st);
 int select_step(const void* table, void* cur, int64_t per_step_elems, int* step_ptr, hipStream_t st);
 int advance_step(int* step_ptr, hipStream_t st);
 

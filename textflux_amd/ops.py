@@ -465,3 +465,75 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
     g.epilogue = EPI_BIAS
     L.check(L.lib().tfx_gemm_bf16_f32(C.byref(g), _stream()), "gemm_f32")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# text-encoder kernels (textenc.hip)
+def attention64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, rel_bias: Optional[torch.Tensor] = None,
+                causal: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q, k, v: [B, N, H*64] bf16 (row / batch strided views allowed), N <= 512 -> [B, N, H*64].  rel_bias: fp32 [H, 2N-1]
+    indexed by key - query + N - 1 (T5); causal: keys after the query masked (CLIP)."""
+    _chk_dev(q, k, v, rel_bias, out)
+    B, N, HD = q.shape
+    H = HD // 64
+    assert HD % 64 == 0 and q.dtype == BF16
+    if rel_bias is not None:
+        assert rel_bias.dtype == torch.float32 and rel_bias.is_contiguous() and rel_bias.shape == (H, 2 * N - 1)
+    if out is None:
+        out = torch.empty(B, N, HD, dtype=BF16, device=q.device)
+    a = L.AttnArgs()
+    a.q, a.k, a.v, a.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+    a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.B, a.H, a.N, a.scale = B, H, N, scale
+    L.check(L.lib().tfx_attention64(C.byref(a), _p(rel_bias), 1 if causal else 0, _stream()), "attention64")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """T5LayerNorm over the last dim of x [rows, D] (fp32 or bf16) -> bf16."""
+    _chk_dev(x, w, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and w.dtype == BF16 and x.dtype in (torch.float32, BF16)
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    L.check(L.lib().tfx_rmsnorm(x.data_ptr(), 0 if x.dtype == torch.float32 else 1, x.stride(0), w.data_ptr(), out.data_ptr(),
+                                out.stride(0), x.shape[0], x.shape[1], eps, _stream()), "rmsnorm")
+    return out
+
+
+def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    _chk_dev(table, ids)
+    assert table.dtype == BF16 and table.is_contiguous() and ids.dtype == torch.int64
+    ids = ids.contiguous().view(-1)
+    out = torch.empty(ids.numel(), table.shape[1], dtype=BF16, device=table.device)
+    L.check(L.lib().tfx_gather_rows(table.data_ptr(), ids.data_ptr(), out.data_ptr(), ids.numel(), table.shape[1],
+                                    table.shape[0], _stream()), "gather_rows")
+    return out
+
+
+def add_into_f32_(x32: torch.Tensor, y: torch.Tensor, assign: bool = False) -> torch.Tensor:
+    _chk_dev(x32, y)
+    assert x32.dtype == torch.float32 and x32.is_contiguous() and y.is_contiguous() and y.numel() == x32.numel()
+    mode = 2 if assign else (0 if y.dtype == BF16 else 1)
+    assert y.dtype in (BF16, torch.float32) and not (assign and y.dtype != BF16)
+    L.check(L.lib().tfx_add_into_f32(x32.data_ptr(), y.data_ptr(), x32.numel(), mode, _stream()), "add_into_f32")
+    return x32
+
+
+def mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a * b for bf16 [rows, cols] row-strided views."""
+    _chk_dev(a, b)
+    assert a.dim() == 2 and a.shape == b.shape and a.stride(1) == 1 and b.stride(1) == 1 and a.dtype == BF16
+    out = torch.empty(a.shape, dtype=BF16, device=a.device)
+    L.check(L.lib().tfx_mul_act(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), a.shape[0],
+                                a.shape[1], 0, _stream()), "mul")
+    return out
+
+
+def quick_gelu(a: torch.Tensor) -> torch.Tensor:
+    _chk_dev(a)
+    assert a.dim() == 2 and a.stride(1) == 1 and a.dtype == BF16
+    out = torch.empty(a.shape, dtype=BF16, device=a.device)
+    L.check(L.lib().tfx_mul_act(a.data_ptr(), a.stride(0), None, 0, out.data_ptr(), out.stride(0), a.shape[0], a.shape[1], 1,
+                                _stream()), "quick_gelu")
+    return out

@@ -134,12 +134,11 @@ class FluxFillPipeline:
         if transformer is None:
             transformer = FluxTransformer2DModel.from_pretrained(path, subfolder="transformer", torch_dtype=torch_dtype,
                                                                  device=device)
-        for name, cls_name in (("text_encoder", "CLIPTextModel"), ("text_encoder_2", "T5EncoderModel")):
-            if name not in comp:
-                import transformers
+        from . import text_encoders
+        for name, enc_cls in (("text_encoder", text_encoders.CLIPTextModel), ("text_encoder_2", text_encoders.T5EncoderModel)):
+            if name not in comp:     # the HIP text encoders read the transformers checkpoint layout (config.json + safetensors)
                 sub = os.path.join(path, name)
-                comp[name] = (getattr(transformers, cls_name).from_pretrained(sub, torch_dtype=torch_dtype).to(device)
-                              if os.path.isdir(sub) else None)
+                comp[name] = enc_cls.from_pretrained(sub, torch_dtype=torch_dtype, device=device) if os.path.isdir(sub) else None
         for name, cls_name in (("tokenizer", "CLIPTokenizer"), ("tokenizer_2", "T5TokenizerFast")):
             if name not in comp:
                 import transformers
@@ -220,7 +219,8 @@ class FluxFillPipeline:
         sd, alphas = self.lora_state_dict(path_or_dict, return_alphas=True, **kwargs)
         self.load_lora_into_transformer(sd, alphas, self.transformer)
 
-    # ------------------------------------------------------------------ prompt encoding (third-party `transformers`)
+    # ------------------------------------------------------------------ prompt encoding (HIP text encoders, text_encoders.py;
+    # any object with the transformers call signature works -- tokenizers are `transformers` objects)
     def enable_prompt_cache(self, max_entries: int = 256):
         """Keep the encoder outputs of the last `max_entries` distinct prompt strings (0 disables).  TextFlux drives the
         pipeline with ONE fixed CLIP prompt (the template) and T5 prompts that differ only in the quoted words
