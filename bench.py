@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--cpu-baseline-c1", action="store_true", help="only run BASELINE config 1 on the host cores (minutes, ~50 GB RAM) and print it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of per-step hipGraph replay")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help=argparse.SUPPRESS)  # tuning knobs (tfx_set_option)
+    ap.add_argument("--no-text-encoders", action="store_true", help="inject fixed prompt embeddings instead of running T5-XXL / CLIP-L per call")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: e4m3 block linears on the fp8 MFMA (NOT the bf16 headline)")
     a = ap.parse_args()
     if a.cpu_baseline_c1:
@@ -189,8 +190,39 @@ def main():
         sch = StochasticRFOvershotDiscreteScheduler(**sched_cfg)
         sch.set_c(2.0)
         sch.set_overshot_func(lambda t, dt: t + dt)
-    pipe = FluxFillPipeline(scheduler=sch, vae=vae, text_encoder=None, tokenizer=None, text_encoder_2=None,
-                            tokenizer_2=None, transformer=tr)
+    # text encoders at their real geometry (T5-XXL: 24 x d_model 4096 / 64 heads / d_ff 10240, 4.7 B parameters; CLIP-L: 12 x 768),
+    # random-init; the tokenizers' vocabulary files are not available offline, so token ids come from a stand-in tokenizer
+    # (host string processing is not what is measured).  Rank 0 encodes, the embeddings are broadcast (multi-GPU).
+    te = te2 = tok = tok2 = None
+    use_te = not a.no_text_encoders
+    if use_te:
+        from types import SimpleNamespace
+
+        class _Tok:
+            def __init__(self, n, vocab):
+                self.model_max_length, self.vocab = n, vocab
+
+            def __call__(self, prompts, padding=None, max_length=None, truncation=None, return_tensors=None, **kw):
+                rows = []
+                for p in prompts:
+                    gtok = torch.Generator().manual_seed(sum(p.encode()) % 100003)
+                    n = min(max_length - 1, 20 + len(p) // 4)
+                    r = torch.randint(3, self.vocab - 1, (max_length,), generator=gtok)
+                    r[n] = self.vocab - 1           # EOS (largest id: CLIP's legacy pooling position)
+                    r[n + 1:] = 0                   # padding
+                    rows.append(r)
+                return SimpleNamespace(input_ids=torch.stack(rows))
+
+        tok, tok2 = _Tok(77, 49408), _Tok(512, 32128)
+        if rank == 0:
+            from textflux_amd.text_encoders import CLIPTextModel, T5EncoderModel
+            te = CLIPTextModel(dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                    num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu",
+                                    eos_token_id=2)).init_random_(seed=11, device=dev)
+            te2 = T5EncoderModel(dict(vocab_size=32128, d_model=4096, d_kv=64, d_ff=10240, num_layers=24, num_heads=64,
+                                      feed_forward_proj="gated-gelu")).init_random_(seed=12, device=dev)
+    pipe = FluxFillPipeline(scheduler=sch, vae=vae, text_encoder=te, tokenizer=tok, text_encoder_2=te2,
+                            tokenizer_2=tok2, transformer=tr)
     pipe.set_progress_bar_config(disable=True)
     pipe.enable_hip_graph(not a.no_graph)
     if a.fp8:
@@ -210,8 +242,19 @@ def main():
     mask[:, :, H // 4: 3 * H // 4, W // 8: 7 * W // 8] = 1.0
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
 
+    from textflux_amd import glyph
+    prompts2 = [glyph.generate_prompt([f"WORD{rank}{i}"]) for i in range(B)]     # one T5 prompt per image, one fixed CLIP prompt
+
     def one_call():
-        return pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, image=image, mask_image=mask, height=H, width=W,
+        pe_c, pooled_c = pe, pooled
+        if use_te:     # inside the timed region: B T5-XXL prompts + the CLIP template, encoded on rank 0, broadcast over RCCL
+            if rank == 0:
+                with torch.no_grad():
+                    pe_c, pooled_c, _ = pipe.encode_prompt(prompt=[glyph.PROMPT_TEMPLATE2] * B, prompt_2=prompts2, device=dev,
+                                                           max_sequence_length=T_TXT)
+            pe_c, pooled_c = tdist.broadcast_conditioning(pe_c if rank == 0 else None, pooled_c if rank == 0 else None,
+                                                          (B, T_TXT, 4096), (B, 768), torch.bfloat16, dev)
+        return pipe(prompt_embeds=pe_c, pooled_prompt_embeds=pooled_c, image=image, mask_image=mask, height=H, width=W,
                     num_inference_steps=n, guidance_scale=30.0, generator=gen, output_type="pt").images
 
     for _ in range(a.warmup):
@@ -259,10 +302,13 @@ def main():
                       f"images/sec (whole node), {H}x{W} {n}-step FLUX-Fill",
             "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp8 (e4m3 operands, fp32 accumulate) block linears; bf16 elsewhere" if a.fp8 else "bf16", "data": "synthetic (random-init FLUX.1-Fill-architecture weights, random image, box mask, "
-                                     "injected random prompt embeddings; text encoders bypassed)",
+            "dtype": "fp8 (e4m3 operands, fp32 accumulate) block linears; bf16 elsewhere" if a.fp8 else "bf16", "data": ("synthetic (random-init FLUX.1-Fill / T5-XXL / CLIP-L architecture weights, random image, box mask; per call: "
+                                      "8 T5 prompts + the CLIP template encoded by the HIP text encoders from stand-in token ids)") if use_te else
+                                     ("synthetic (random-init FLUX.1-Fill-architecture weights, random image, box mask, "
+                                      "injected random prompt embeddings; text encoders bypassed)"),
             "config": {"workload": f"{'P1024' if (H, W) == (1024, 1024) else f'{H}x{W}'}: FluxFillPipeline.__call__ {H}x{W}, {n} {a.sampler} steps, guidance 30, "
-                                   f"batch {B}/GPU (S={S} image + 512 text tokens), VAE encode+decode included"
+                                   f"batch {B}/GPU (S={S} image + 512 text tokens), "
+                                   + ("T5-XXL + CLIP-L prompt encoding, " if use_te else "") + "VAE encode+decode included"
                                    + ("" if full else f" [REDUCED MODEL {a.layers} - not a valid headline]")
                                    + (" [fp8 linears: BASELINE config 5 precision, not the bf16 headline]" if a.fp8 else ""),
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, conditioning broadcast over RCCL)"},

@@ -108,6 +108,31 @@ class T5EncoderModel(_Encoder):
         self._bias_tables = {}
         return self
 
+    def init_random_(self, seed: int = 0, device="cuda", std: float = 0.02):
+        """Random weights of the configured shapes, generated on the device (synthetic benchmarking; no checkpoints offline)."""
+        c = self.config
+        dev = torch.device(device)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        inner = c.num_heads * 64
+
+        def rnd(*shape, scale=std):
+            t = torch.empty(*shape, dtype=BF16, device=dev)
+            flat = t.view(-1)
+            for s0 in range(0, flat.numel(), 1 << 26):
+                e = min(flat.numel(), s0 + (1 << 26))
+                flat[s0:e].copy_((torch.randn(e - s0, generator=g, device=dev) * scale).to(BF16))
+            return t
+
+        ones = lambda n: (1.0 + 0.1 * torch.randn(n, generator=g, device=dev)).to(BF16)
+        w = {"embed": rnd(c.vocab_size, c.d_model, scale=1.0), "final_ln": ones(c.d_model),
+             "rel_bias": rnd(c.relative_attention_num_buckets, c.num_heads, scale=0.5)}
+        for i in range(c.num_layers):
+            w[f"{i}.ln0"], w[f"{i}.ln1"] = ones(c.d_model), ones(c.d_model)
+            w[f"{i}.qkv"], w[f"{i}.o"] = rnd(3 * inner, c.d_model), rnd(c.d_model, inner)
+            w[f"{i}.wi"], w[f"{i}.wo"] = rnd(2 * c.d_ff, c.d_model), rnd(c.d_model, c.d_ff)
+        self.w, self.device, self._bias_tables = w, dev, {}
+        return self
+
     def _rel_bias(self, T: int) -> torch.Tensor:
         """fp32 [H, 2T - 1]: bias(h, key - query) (T5Attention.compute_bias depends on the distance only).  Host integer
         bucketing of the 2T - 1 distances, one table lookup."""
@@ -191,6 +216,24 @@ class CLIPTextModel(_Encoder):
             for n, k in (("o", "self_attn.out_proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
                 w[f"{i}.{n}.w"], w[f"{i}.{n}.b"] = g(l + k + ".weight"), g(l + k + ".bias")
         ln("final", "final_layer_norm")
+        self.w, self.device = w, dev
+        return self
+
+    def init_random_(self, seed: int = 0, device="cuda", std: float = 0.02):
+        c = self.config
+        dev = torch.device(device)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        rnd = lambda *shape, scale=std: (torch.randn(*shape, generator=g, device=dev) * scale).to(BF16)
+        D, I = c.hidden_size, c.intermediate_size
+        w = {"tok": rnd(c.vocab_size, D, scale=1.0), "pos": rnd(c.max_position_embeddings, D, scale=0.1)}
+        names = [f"{i}.{n}" for i in range(c.num_hidden_layers) for n in ("ln1", "ln2")] + ["final"]
+        for n in names:
+            w[n + ".scale"], w[n + ".shift"] = rnd(1, D, scale=0.05), rnd(1, D, scale=0.05)
+        for i in range(c.num_hidden_layers):
+            w[f"{i}.qkv.w"], w[f"{i}.qkv.b"] = rnd(3 * D, D), rnd(3 * D)
+            w[f"{i}.o.w"], w[f"{i}.o.b"] = rnd(D, D), rnd(D)
+            w[f"{i}.fc1.w"], w[f"{i}.fc1.b"] = rnd(I, D), rnd(I)
+            w[f"{i}.fc2.w"], w[f"{i}.fc2.b"] = rnd(D, I), rnd(D)
         self.w, self.device = w, dev
         return self
 
