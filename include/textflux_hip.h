@@ -248,10 +248,11 @@ int tfx_vae_sample_pack(const void* moments, const void* eps, int32_t eps_dtype,
  * (P:1752-1765, 2126-2127): the decoder input. */
 int tfx_unpack_latents(const void* latents, int64_t ld, void* out, int32_t B, int32_t h, int32_t w, int32_t L, float shift,
                        float scale, tfx_stream stream);
-/* x [B, HW, Cs] NHWC bf16 (first C channels) -> mode 0 NCHW bf16 | 1 NHWC f32 | 2 NHWC u8 = round(255 v) | 3 NCHW f32;
- * denorm != 0: v = clamp(x / 2 + 0.5, 0, 1) in bf16 steps (IP:227-239, 196-209, 133-154). */
-int tfx_postprocess(const void* x, void* out, int32_t B, int64_t HW, int32_t Cs, int32_t C, int32_t mode, int32_t denorm,
-                    tfx_stream stream);
+/* x [B, H, W, Cs] NHWC bf16 (first C channels), window rows [y0, y0 + Hc) x columns [x0, x0 + Wc) -> mode 0 NCHW bf16 |
+ * 1 NHWC f32 | 2 NHWC u8 = round(255 v) | 3 NCHW f32; denorm != 0: v = clamp(x / 2 + 0.5, 0, 1) in bf16 steps (IP:227-239,
+ * 196-209, 133-154).  The window is the callers' result crop (run_inference.py:460-465), applied on the device. */
+int tfx_postprocess(const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t Cs, int32_t C, int32_t mode, int32_t denorm,
+                    int32_t y0, int32_t x0, int32_t Hc, int32_t Wc, tfx_stream stream);
 /* helpers of the VAE mid-block attention (one head of dim C over h*w tokens, AttnProcessor2_0,
  * D/models/attention_processor.py:2799-2881): out[b][c, n] = in[b][n, c]; p[r, :N] = bf16(softmax(scale * s[r, :N])) with
  * s fp32 (row stride lds) from tfx_gemm_bf16_f32 and p bf16 (row stride ldp), fp32 statistics -- what a flash kernel

@@ -132,6 +132,11 @@ def test_postprocess_modes(ops, denorm):
         u8 = ops.postprocess(x.cuda(), 3, "u8", denorm)
         ref = (den.permute(0, 2, 3, 1).float().numpy() * 255).round().astype("uint8")
         assert np.array_equal(u8.cpu().numpy(), ref)
+        box = (5, 3, 21, 14)                                           # PIL box (left, top, right, bottom)
+        u8c = ops.postprocess(x.cuda(), 3, "u8", denorm, crop=box)
+        assert np.array_equal(u8c.cpu().numpy(), ref[:, 3:14, 5:21])
+        ptc = ops.postprocess(x.cuda(), 3, "pt", denorm, crop=box)
+        assert torch.equal(ptc.cpu(), den[:, :, 3:14, 5:21])
 
 
 def test_transpose_and_row_softmax(ops):

@@ -127,7 +127,8 @@ SIGNATURES = {
                                     c_float, c_int64, c_int32, c_void_p]),
     "tfx_unpack_latents": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float,
                                    c_void_p]),
-    "tfx_postprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "tfx_postprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                c_int32, c_int32, c_void_p]),
     "tfx_transpose": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "tfx_row_softmax": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "tfx_attention64": (c_int, [C.POINTER(AttnArgs), c_void_p, c_int32, c_void_p]),

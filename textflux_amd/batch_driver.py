@@ -137,12 +137,15 @@ def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], bat
         n = len(mine.items)
         try:
             gens = [torch.Generator(device=device).manual_seed(int(seed)) for _ in range(n)]   # run_inference.py:76, per image
+            boxes = [glyph.crop_box(w.size, w.meta) for w in mine.items]
+            same_box = all(bx == boxes[0] for bx in boxes)      # one crop window for the whole batch: applied on the device
+            kw = dict(output_crop=boxes[0]) if same_box and getattr(pipe, "supports_output_crop", False) else {}
             images = pipe(height=mine.size[1], width=mine.size[0], image=[w.image for w in mine.items],
                           mask_image=[w.mask for w in mine.items], num_inference_steps=num_inference_steps, generator=gens,
                           max_sequence_length=max_sequence_length, guidance_scale=guidance_scale,
-                          prompt_embeds=pe_mine[:n], pooled_prompt_embeds=pooled1.expand(n, -1).contiguous()).images
-            for w, img in zip(mine.items, images):
-                cropped = img.crop(glyph.crop_box(img.size, w.meta))
+                          prompt_embeds=pe_mine[:n], pooled_prompt_embeds=pooled1.expand(n, -1).contiguous(), **kw).images
+            for w, img, bx in zip(mine.items, images, boxes):
+                cropped = img if kw else img.crop(bx)
                 if save is not None:
                     save(w.index, cropped)
                 elif out_dir is not None:

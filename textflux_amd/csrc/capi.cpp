@@ -359,10 +359,10 @@ int tfx_unpack_latents(const void* latents, int64_t ld, void* out, int32_t B, in
   if (!latents || !out) return fail("tfx_unpack_latents: null pointer");
   return unpack_latents(latents, ld, out, B, h, w, L, shift, scale, S(stream));
 }
-int tfx_postprocess(const void* x, void* out, int32_t B, int64_t HW, int32_t Cs, int32_t C, int32_t mode, int32_t denorm,
-                    tfx_stream stream) {
+int tfx_postprocess(const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t Cs, int32_t C, int32_t mode, int32_t denorm,
+                    int32_t y0, int32_t x0, int32_t Hc, int32_t Wc, tfx_stream stream) {
   if (!x || !out) return fail("tfx_postprocess: null pointer");
-  return postprocess(x, out, B, HW, Cs, C, mode, denorm, S(stream));
+  return postprocess(x, out, B, H, W, Cs, C, mode, denorm, y0, x0, Hc, Wc, S(stream));
 }
 int tfx_transpose(const void* in, int64_t ldi, int64_t in_bstride, void* out, int64_t ldo, int64_t out_bstride, int32_t N,
                   int32_t C, int32_t batch, tfx_stream stream) {

@@ -156,21 +156,26 @@ __global__ __launch_bounds__(256) void unpack_latents_kernel(const bf16_t* __res
   *reinterpret_cast<u32x4*>(out + i * 8) = pack8(v);
 }
 
-// x NHWC [B, H, W, Cs] bf16 (first C channels used) -> mode 0: NCHW bf16, 1: NHWC fp32, 2: NHWC uint8 (round(255 v)),
-// 3: NCHW fp32.  denorm: v = clamp(bf16(bf16(x * 0.5) + 0.5), 0, 1)  (VaeImageProcessor.denormalize, IP:227-239).
-__global__ __launch_bounds__(256) void postprocess_kernel(const bf16_t* __restrict__ x, void* __restrict__ out, int B, int64_t HW,
-                                                          int Cs, int C, int mode, int denorm) {
+// x NHWC [B, H, W, Cs] bf16 (first C channels used), cropped to the window (y0, x0, Hc, Wc) -> mode 0: NCHW bf16,
+// 1: NHWC fp32, 2: NHWC uint8 (round(255 v)), 3: NCHW fp32.  denorm: v = clamp(bf16(bf16(x * 0.5) + 0.5), 0, 1)
+// (VaeImageProcessor.denormalize, IP:227-239).  The window is the callers' result crop (run_inference.py:460-465: only the
+// scene part of the concatenated image is kept), applied before the image leaves the device.
+__global__ __launch_bounds__(256) void postprocess_kernel(const bf16_t* __restrict__ x, void* __restrict__ out, int B, int H, int W,
+                                                          int Cs, int C, int mode, int denorm, int y0, int x0, int Hc, int Wc) {
+  const int64_t HWc = (int64_t)Hc * Wc;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= B * HW) return;
-  const int b = (int)(i / HW);
-  const int64_t pix = i - b * HW;
+  if (i >= B * HWc) return;
+  const int b = (int)(i / HWc);
+  const int64_t pix = i - b * HWc;
+  const int yy = (int)(pix / Wc), xx = (int)(pix - (int64_t)yy * Wc);
+  const bf16_t* src = x + (((int64_t)b * H + y0 + yy) * W + x0 + xx) * Cs;
   for (int c = 0; c < C; ++c) {
-    float v = bf2f(x[i * Cs + c]);
+    float v = bf2f(src[c]);
     if (denorm) v = fminf(fmaxf(round_bf(round_bf(v * 0.5f) + 0.5f), 0.f), 1.f);
-    if (mode == 0) ((bf16_t*)out)[((int64_t)b * C + c) * HW + pix] = f2bf(v);
+    if (mode == 0) ((bf16_t*)out)[((int64_t)b * C + c) * HWc + pix] = f2bf(v);
     else if (mode == 1) ((float*)out)[i * C + c] = v;
     else if (mode == 2) ((uint8_t*)out)[i * C + c] = (uint8_t)rintf(__fmul_rn(v, 255.0f));
-    else ((float*)out)[((int64_t)b * C + c) * HW + pix] = v;
+    else ((float*)out)[((int64_t)b * C + c) * HWc + pix] = v;
   }
 }
 
@@ -323,11 +328,13 @@ int unpack_latents(const void* lat, int64_t ld, void* out, int B, int h, int w, 
   return check_launch("unpack_latents");
 }
 
-int postprocess(const void* x, void* out, int B, int64_t HW, int Cs, int C, int mode, int denorm, hipStream_t st) {
+int postprocess(const void* x, void* out, int B, int H, int W, int Cs, int C, int mode, int denorm, int y0, int x0, int Hc, int Wc,
+                hipStream_t st) {
   if (mode < 0 || mode > 3 || C > Cs) return fail("postprocess: mode 0..3, C <= Cs");
-  const int64_t n = (int64_t)B * HW;
+  if (y0 < 0 || x0 < 0 || Hc <= 0 || Wc <= 0 || y0 + Hc > H || x0 + Wc > W) return fail("postprocess: crop window outside the image");
+  const int64_t n = (int64_t)B * Hc * Wc;
   if (n <= 0) return 0;
-  postprocess_kernel<<<blocks_for(n), 256, 0, st>>>((const bf16_t*)x, out, B, HW, Cs, C, mode, denorm);
+  postprocess_kernel<<<blocks_for(n), 256, 0, st>>>((const bf16_t*)x, out, B, H, W, Cs, C, mode, denorm, y0, x0, Hc, Wc);
   return check_launch("postprocess");
 }
 

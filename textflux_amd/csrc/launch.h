@@ -106,7 +106,8 @@ int pack_mask(const void* mask, int mask_dtype, void* out, int B, int H, int W, 
 int sample_pack(const void* moments, const void* eps, int eps_dtype, void* out, int B, int h, int w, int L, float shift,
                 float scale, int64_t ld, int col0, hipStream_t st);
 int unpack_latents(const void* lat, int64_t ld, void* out, int B, int h, int w, int L, float shift, float scale, hipStream_t st);
-int postprocess(const void* x, void* out, int B, int64_t HW, int Cs, int C, int mode, int denorm, hipStream_t st);
+int postprocess(const void* x, void* out, int B, int H, int W, int Cs, int C, int mode, int denorm, int y0, int x0, int Hc, int Wc,
+                hipStream_t st);
 int transpose_bf16(const void* in, int64_t ldi, int64_t ibs, void* out, int64_t ldo, int64_t obs, int N, int C, int batch,
                    hipStream_t st);
 int row_softmax(const float* s, int64_t lds, void* p, int64_t ldp, int rows, int N, float scale, hipStream_t st);

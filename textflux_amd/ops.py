@@ -406,19 +406,21 @@ def unpack_latents(lat: torch.Tensor, h: int, w: int, shift: float, scale: float
     return out
 
 
-def postprocess(x: torch.Tensor, C: int, mode: str, denorm: bool = True) -> torch.Tensor:
+def postprocess(x: torch.Tensor, C: int, mode: str, denorm: bool = True, crop=None) -> torch.Tensor:
     """x [B, H, W, Cs] NHWC bf16 -> "pt": [B, C, H, W] bf16 | "np": [B, H, W, C] f32 | "u8": [B, H, W, C] uint8 |
-    "pt32": [B, C, H, W] f32."""
+    "pt32": [B, C, H, W] f32; crop = (left, top, right, bottom) in pixels keeps only that window (PIL box convention)."""
     _chk_dev(x)
     assert x.is_contiguous() and x.dtype == BF16
     B, H, W, Cs = x.shape
+    x0, y0, x1, y1 = crop if crop is not None else (0, 0, W, H)
+    Hc, Wc = y1 - y0, x1 - x0
     code = {"pt": 0, "np": 1, "u8": 2, "pt32": 3}[mode]
     if code in (0, 3):
-        out = torch.empty(B, C, H, W, dtype=BF16 if code == 0 else torch.float32, device=x.device)
+        out = torch.empty(B, C, Hc, Wc, dtype=BF16 if code == 0 else torch.float32, device=x.device)
     else:
-        out = torch.empty(B, H, W, C, dtype=torch.float32 if code == 1 else torch.uint8, device=x.device)
-    L.check(L.lib().tfx_postprocess(x.data_ptr(), out.data_ptr(), B, H * W, Cs, C, code, 1 if denorm else 0, _stream()),
-            "postprocess")
+        out = torch.empty(B, Hc, Wc, C, dtype=torch.float32 if code == 1 else torch.uint8, device=x.device)
+    L.check(L.lib().tfx_postprocess(x.data_ptr(), out.data_ptr(), B, H, W, Cs, C, code, 1 if denorm else 0, y0, x0, Hc, Wc,
+                                    _stream()), "postprocess")
     return out
 
 

@@ -94,6 +94,7 @@ class _NullBar:
 
 class FluxFillPipeline:
     _callback_tensor_inputs = ["latents", "prompt_embeds"]
+    supports_output_crop = True
     model_index_name = "model_index.json"
 
     def __init__(self, scheduler, vae, text_encoder, tokenizer, text_encoder_2, tokenizer_2,
@@ -578,7 +579,7 @@ class FluxFillPipeline:
             progress_bar.update()
         return latents
 
-    def _decode_to_output(self, latents, height, width, output_type):
+    def _decode_to_output(self, latents, height, width, output_type, crop=None):
         """P:2126-2129 + VaeImageProcessor.postprocess: un-patchify, z / scale + shift, VAE decode, denormalise, and the
         output layout, all on NHWC device tensors; only the finished uint8 / float32 image crosses to the host."""
         if output_type not in ("pt", "np", "pil"):
@@ -590,11 +591,11 @@ class FluxFillPipeline:
         img = self.vae.decode_nhwc(z)
         denorm = self.image_processor.do_normalize
         if output_type == "pt":
-            return ops.postprocess(img, c.out_channels, "pt", denorm)
+            return ops.postprocess(img, c.out_channels, "pt", denorm, crop)
         if output_type == "np":
-            return ops.postprocess(img, c.out_channels, "np", denorm).cpu().numpy()
+            return ops.postprocess(img, c.out_channels, "np", denorm, crop).cpu().numpy()
         import PIL.Image
-        u8 = ops.postprocess(img, c.out_channels, "u8", denorm).cpu().numpy()
+        u8 = ops.postprocess(img, c.out_channels, "u8", denorm, crop).cpu().numpy()
         if u8.shape[-1] == 1:
             return [PIL.Image.fromarray(a.squeeze(), mode="L") for a in u8]
         return [PIL.Image.fromarray(a) for a in u8]
@@ -610,9 +611,11 @@ class FluxFillPipeline:
                  joint_attention_kwargs: Optional[Dict[str, Any]] = None,
                  callback_on_step_end: Optional[Callable] = None,
                  callback_on_step_end_tensor_inputs: List[str] = ["latents"], max_sequence_length: int = 512,
-                 amo_noise: Optional[List[torch.Tensor]] = None):
-        """Same arguments / defaults / return as the reference `__call__` (P:1850-1873, 2122-2137).  `amo_noise` is the
-        one addition: a list of pre-drawn eps tensors for the AMO sampler (replay across devices)."""
+                 amo_noise: Optional[List[torch.Tensor]] = None, output_crop=None):
+        """Same arguments / defaults / return as the reference `__call__` (P:1850-1873, 2122-2137).  Two additions:
+        `amo_noise`, a list of pre-drawn eps tensors for the AMO sampler (replay across devices), and
+        `output_crop` = (left, top, right, bottom), the callers' result crop (run_inference.py:460-465) applied on the
+        device so that only the kept pixels are converted and copied to the host."""
         height = height or self.default_sample_size * self.vae_scale_factor
         width = width or self.default_sample_size * self.vae_scale_factor
         self.check_inputs(prompt, prompt_2, height, width, prompt_embeds=prompt_embeds,
@@ -671,7 +674,7 @@ class FluxFillPipeline:
         if output_type == "latent":
             image = latents
         else:
-            image = self._decode_to_output(latents, height, width, output_type)
+            image = self._decode_to_output(latents, height, width, output_type, output_crop)
         self.maybe_free_model_hooks()
         if not return_dict:
             return (image,)
