@@ -172,6 +172,11 @@ typedef struct tfx_dit_desc {
    * caller-owned workspace of the quantised activations.  Embedders, modulation and proj_out stay bf16. */
   void* q8; float* q8_scale;
   void* gemm_workspace; int64_t gemm_workspace_bytes;   /* optional, passed to every block Linear (tfx_gemm_args.workspace) */
+  /* optional: the rotary table as (cos, sin) pairs, fp32 [N, 64, 2] (cos_tab / sin_tab hold every value twice: pair i =
+   * columns 2i, 2i + 1).  When set, the q | k | v (| mlp) projections with at least as many 256 x 256 tiles as the device
+   * has CUs apply the per-head RMSNorm + RoPE in their GEMM epilogue (bf16 mode); the others -- and every projection when
+   * this is NULL -- are followed by tfx_rmsnorm_rope as a separate pass.  Same rounding points either way. */
+  const float* rope_cs;
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
 

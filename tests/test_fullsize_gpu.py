@@ -114,3 +114,55 @@ def test_full_model_batch_consistency_and_determinism():
     finally:
         ops.set_option("gemm_splitk", 1)
     assert torch.equal(n2[0], n2[1]) and torch.equal(n2[0], n1[0])
+
+
+def test_fused_qk_norm_rope_epilogue_matches_separate_pass():
+    """q/k RMSNorm + RoPE inside the projection GEMM's epilogue (tfx_dit_desc.rope_cs; taken when the GEMM has >= one tile
+    per CU) against the same GEMM followed by tfx_rmsnorm_rope: same rounding points, different fp32 summation order of the
+    128-column sum of squares -> the normalised, rotated k columns agree to one bf16 ulp on all but a sliver of elements,
+    and the model outputs to bf16 noise.  Double block (separate text / image projections, position offset T) and single
+    block (joint projection with the GELU columns) at the production shapes."""
+    from textflux_amd.transformer import FluxTransformer2DModel
+    m = FluxTransformer2DModel(in_channels=384, out_channels=64, num_layers=1, num_single_layers=1,
+                               guidance_embeds=True).init_random_(seed=9, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(4)
+    B, S, T = 2, 4096, 512
+    hs = torch.randn(B, S, 384, generator=g, device="cuda").to(BF)
+    pe = (torch.randn(B, T, 4096, generator=g, device="cuda") * 0.1).to(BF)
+    pooled = torch.randn(B, 768, generator=g, device="cuda").to(BF)
+    ids = torch.zeros(S, 3)
+    ids[:, 1] = torch.arange(S) // 64
+    ids[:, 2] = torch.arange(S) % 64
+    kw = dict(hidden_states=hs, encoder_hidden_states=pe, pooled_projections=pooled, timestep=torch.full((B,), 0.7, device="cuda").to(BF),
+              guidance=torch.full((B,), 30.0, device="cuda"), img_ids=ids, txt_ids=torch.zeros(T, 3), return_dict=False)
+    # per block, from the SAME input stream: the k columns after the projection (+ norm + RoPE), before anything downstream
+    temb = torch.randn(B, D, generator=g, device="cuda").to(BF)
+    hid0 = torch.randn(B, S + T, D, generator=g, device="cuda").to(BF)
+    outs, ks = {}, {}
+    for fused in (False, True):
+        m.fuse_qk_norm_rope = fused
+        m._session = None
+        outs[fused] = m(**kw)[0].clone()
+        ses = m.session(B, S, T)
+        assert (ses.desc.rope_cs is not None) == fused
+        mod = m.modulation(temb)
+        for blk in (0, 1):                              # double block, then single block, each on the same hid0
+            ses.hid.copy_(hid0)
+            ses.run(mod, first_block=blk, last_block=blk + 1, flags=3)
+            ks[(fused, blk)] = ses.y[:, :, :D].clone()  # k columns: normalised + rotated, not overwritten by attention
+    assert torch.isfinite(outs[True].float()).all()
+    for blk in (0, 1):
+        a, b = ks[(False, blk)].float(), ks[(True, blk)].float()
+        diff = (a - b).abs()
+        # a rotated element can be much smaller than the pair it was rotated from (y0 c - y1 s cancels), so the yardstick is
+        # one bf16 step of the PAIR's magnitude, which the rotation preserves: a one-ulp difference of either normalised
+        # component moves the outputs by at most that
+        pair = (a.view(*a.shape[:-1], -1, 2) ** 2).sum(-1).sqrt().repeat_interleave(2, dim=-1)
+        assert (diff <= 2 ** -6 * pair + 1e-6).all(), (blk, (diff / (2 ** -6 * pair + 1e-6)).max().item())   # y step + output rounding
+        frac = (diff > 0).float().mean().item()
+        print(f"block {blk}: fused vs separate q/k norm+RoPE: {frac:.2e} of the k elements differ, all within one bf16 step of their pair")
+        assert frac < 2e-2
+    rel = ((outs[True].float() - outs[False].float()).abs().mean() / outs[False].float().abs().mean()).item()
+    print(f"model output rel MAE fused vs separate: {rel:.2e}")
+    assert rel < 5e-3
+    m.fuse_qk_norm_rope = True

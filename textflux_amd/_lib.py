@@ -70,6 +70,7 @@ class DitDesc(C.Structure):
         ("first_block", c_int32), ("last_block", c_int32), ("flags", c_int32),
         ("q8", c_void_p), ("q8_scale", c_void_p),
         ("gemm_workspace", c_void_p), ("gemm_workspace_bytes", c_int64),
+        ("rope_cs", c_void_p),
     ]
 
 

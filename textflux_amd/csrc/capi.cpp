@@ -33,6 +33,18 @@ struct Gemm {
     return *this;
   }
   Gemm& scratch(void* ws, int64_t bytes) { a.workspace = ws; a.workspace_bytes = bytes; return *this; }
+  // fused per-head RMSNorm + RoPE on the k / q column ranges [0, D) / [2D, 3D) of a [k | v | q | ...] projection
+  Gemm& qknorm(const void* wq, const void* wk, const float* cs, int pos0, int D, float eps) {
+    a.qkn_wq = wq; a.qkn_wk = wk; a.qkn_rope_cs = cs; a.qkn_pos0 = pos0;
+    a.qkn_k0 = 0; a.qkn_k1 = D; a.qkn_q0 = 2 * D; a.qkn_q1 = 3 * D; a.qkn_eps = eps;
+    if (a.epilogue == EPI_BIAS) { a.epilogue = EPI_BIAS_GELU; a.gelu_from_col = 1 << 30; }   // bias only: GELU never starts
+    return *this;
+  }
+  bool qknorm_ok(const void* wq, const void* wk, const float* cs, int pos0, int D, float eps) const {
+    Gemm t = *this;
+    t.qknorm(wq, wk, cs, pos0, D, eps);
+    return gemm_qkn_ok(t.a);
+  }
   int run(hipStream_t st) const { return gemm_bf16(a, st); }
   bool fp8_ready() const { return lin->w8 && lin->w8_scale && a.K % 256 == 0; }
   // fp8 linear whose activation rows were already quantised by the producer (ln_modulate_fp8)
@@ -91,9 +103,14 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
     if (T > 0) TRY(copy_rows(d.ctx0, D, (int64_t)T * D, hid, D, hid_bs, T, D, B, st));
   }
 
-  auto attention = [&](int Ttxt, const void* nq, const void* nk, const void* naq, const void* nak) -> int {
-    // y = [k | v | q | ...]; RMSNorm+RoPE in place on q,k; attention output overwrites q
-    TRY(rmsnorm_rope(y, D7, y_bs, 2 * D, 0, H, N, Ttxt, B, nq, nk, naq, nak, d.cos_tab, d.sin_tab, eps, st));
+  // y = [k | v | q | ...]; RMSNorm + RoPE of q, k on the row range [row0, row0 + rows) as a separate pass (projections that
+  // did not carry it in their epilogue); attention output overwrites q
+  auto norm_rope_rows = [&](int row0, int rows, const void* nq, const void* nk) -> int {
+    if (rows <= 0) return 0;
+    return rmsnorm_rope(y + (int64_t)row0 * D7, D7, y_bs, 2 * D, 0, H, rows, 0, B, nq, nk, nq, nk, d.cos_tab + (int64_t)row0 * 128,
+                        d.sin_tab + (int64_t)row0 * 128, eps, st);
+  };
+  auto attention = [&]() -> int {
     AttnArgs a;
     a.q = y + 2 * D; a.k = y; a.v = y + D; a.o = y + 2 * D;
     a.ldq = a.ldk = a.ldv = a.ldo = D7;
@@ -105,6 +122,12 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
   // LayerNorm + modulation of rows [row0, row0 + rows) of every batch's joint stream, feeding ONE Linear.  bf16 mode:
   // xn (bf16) then the GEMM.  fp8 mode: the norm writes the e4m3 rows + scales straight into the q8 workspace
   // (layout [B][N][D] bytes / [B][N]) and the GEMM consumes them -- no bf16 round trip, no separate quantisation pass.
+  // projection of rows [row0, row0 + rows) into y with q/k norm + RoPE: fused into the GEMM epilogue when the shape allows
+  // (bf16 mode, persistent kernel, enough tiles to fill the chip unsplit), else the GEMM followed by the separate pass
+  const bool may_fuse = d.rope_cs && !q8;
+  auto fused_here = [&](const Gemm& gm, int row0, const void* nq, const void* nk) -> bool {
+    return may_fuse && gm.qknorm_ok(nq, nk, d.rope_cs, row0, D, eps);
+  };
   auto norm_gemm = [&](const uint16_t* src, int row0, int rows, const uint16_t* shift, const uint16_t* scale, Gemm gm) -> int {
     gm.scratch(d.gemm_workspace, d.gemm_workspace_bytes);
     if (q8 && gm.fp8_ready()) {
@@ -123,9 +146,21 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
       const tfx_double_block& w = d.dbl[blk];
       const uint16_t* mi = mod + (int64_t)blk * 12 * D;  // img: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp
       const uint16_t* mt = mi + 6 * D;                   // txt: same six
-      TRY(norm_gemm(hid_img, T, Sn, mi, mi + D, Gemm(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B)));
-      if (T > 0) TRY(norm_gemm(hid, 0, T, mt, mt + D, Gemm(xn, D, hid_bs, w.qkv_txt, D, y, D7, y_bs, T, 3 * D, D, B)));
-      TRY(attention(T, w.norm_q, w.norm_k, w.norm_added_q, w.norm_added_k));
+      {
+        Gemm gi(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B);
+        const bool fi = fused_here(gi, T, w.norm_q, w.norm_k);
+        if (fi) gi.qknorm(w.norm_q, w.norm_k, d.rope_cs, T, D, eps);
+        TRY(norm_gemm(hid_img, T, Sn, mi, mi + D, gi));
+        if (!fi) TRY(norm_rope_rows(T, Sn, w.norm_q, w.norm_k));
+        if (T > 0) {
+          Gemm gt(xn, D, hid_bs, w.qkv_txt, D, y, D7, y_bs, T, 3 * D, D, B);
+          const bool ft = fused_here(gt, 0, w.norm_added_q, w.norm_added_k);
+          if (ft) gt.qknorm(w.norm_added_q, w.norm_added_k, d.rope_cs, 0, D, eps);
+          TRY(norm_gemm(hid, 0, T, mt, mt + D, gt));
+          if (!ft) TRY(norm_rope_rows(0, T, w.norm_added_q, w.norm_added_k));
+        }
+      }
+      TRY(attention());
       // hidden += gate_msa * to_out(attn)   (:817-818, 830-831)
       TRY(Gemm(y_img + 2 * D, D7, y_bs, w.out_img, D, hid_img, D, hid_bs, Sn, D, D, B)
               .gate_res(mi + 2 * D, mbs, hid_img, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
@@ -147,8 +182,14 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
       const int j = blk - d.n_double;
       const tfx_single_block& w = d.sgl[j];
       const uint16_t* ms = mod + (int64_t)d.n_double * 12 * D + (int64_t)j * 3 * D;  // shift scale gate
-      TRY(norm_gemm(hid, 0, N, ms, ms + D, Gemm(xn, D, hid_bs, w.qkv_mlp, D, y, D7, y_bs, N, 7 * D, D, B).gelu(3 * D)));
-      TRY(attention(0, w.norm_q, w.norm_k, w.norm_q, w.norm_k));
+      {
+        Gemm gs = Gemm(xn, D, hid_bs, w.qkv_mlp, D, y, D7, y_bs, N, 7 * D, D, B).gelu(3 * D);
+        const bool fs = fused_here(gs, 0, w.norm_q, w.norm_k);
+        if (fs) gs.qknorm(w.norm_q, w.norm_k, d.rope_cs, 0, D, eps);
+        TRY(norm_gemm(hid, 0, N, ms, ms + D, gs));
+        if (!fs) TRY(norm_rope_rows(0, N, w.norm_q, w.norm_k));
+      }
+      TRY(attention());
       TRY(Gemm(y + 2 * D, D7, y_bs, w.proj_out, 5 * D, hid, D, hid_bs, N, D, 5 * D, B)
               .gate_res(ms + 2 * D, mbs, hid, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
     }

@@ -26,6 +26,8 @@
 // first readers: X0_lo/W_lo 8t+15, X1_lo 8t+16, W_hi 8t+17, X0_hi 8t+19, X1_hi 8t+20 -> >= 11 slots in flight; a request
 // is waited for by its issuer (vmcnt(8): the 4 newest sections may still be in flight), then one barrier -> readable.
 // See DESIGN.md "GEMM".
+#include <type_traits>
+
 #include "common.h"
 #include "launch.h"
 
@@ -46,6 +48,8 @@ struct GemmParams {
   const float* a_scale; int64_t as_bs; const float* w_scale;   // fp8 kernel only
   float* ws; int sk;                                             // split-K: fp32 partials [sk][batch][M][N], slices
   int64_t ws_ld, ws_bs;                                           // row / (slice, batch) strides of ws in floats (fp32-output mode: ldc / c_bstride)
+  // fused per-head RMSNorm + RoPE of the q / k column ranges (QKN kernel instantiation; see GemmArgs)
+  const bf16_t* nq_w; const bf16_t* nk_w; const float* rope_cs; int rope_pos0, nq0, nq1, nk0, nk1; float n_eps;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -501,7 +505,12 @@ constexpr int PP_LDS_TOTAL = PP_STG + 8 * PP_STG_WAVE;  // 163840 = all of the C
 // SPLIT: the work unit is (tile, K slice): p.sk slices of nt / p.sk K-tiles each, units ordered slice-major; the epilogue
 // stores the raw fp32 accumulators to p.ws [slice][batch][M][N] and splitk_reduce_kernel<EPI> finishes (sum over the
 // slices in order, bias, activation, gate, residual).  Used when a GEMM has fewer tiles than the chip has CUs.
-template <int EPI, int PLACE = 2, bool FP8 = false, bool SPLIT = false>
+// QKN (the fused q | k | v (| mlp) projections of the DiT blocks): tiles inside the q / k column ranges -- a 256-column tile
+// is exactly two heads -- get the per-head RMSNorm (fp32 sum of squares over the 128 columns of the bf16-rounded Linear
+// output, * weight) and the interleaved-pair RoPE applied in the epilogue, rounding for rounding as rmsnorm_rope_kernel
+// (elementwise.hip) does it after the fact (reference: D/models/attention_processor.py:2001-2037).  A head's 128 columns
+// belong to two waves (column stripes wc, wc ^ 1): their partial sums meet in LDS between two extra barriers per such tile.
+template <int EPI, int PLACE = 2, bool FP8 = false, bool SPLIT = false, bool QKN = false>
 __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -804,63 +813,140 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #pragma unroll
       for (int d = 0; d < RES_DEPTH; ++d) load_res(d, rr[d]);
     }
+    const bool in_q = QKN && n0 >= p.nq0 && n0 < p.nq1;
+    const bool norm_tile = QKN && (in_q || (n0 >= p.nk0 && n0 < p.nk1));      // block-uniform
     // every request of this tile's K loop (incl. the next tile's first K-tiles) is older than the stores below;
     // loads and stores retire out of order with respect to each other, so the counted waits of the next K loop are
     // only meaningful once these have landed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float rinv[4] = {0.f, 0.f, 0.f, 0.f};
+    u32x4 nw8 = u32x4{0u, 0u, 0u, 0u};     // norm weights of the 8 columns this lane stores (norm tiles)
+    if (norm_tile) {
+      nw8 = *reinterpret_cast<const u32x4*>((in_q ? p.nq_w : p.nk_w) + (wc & 1) * 64 + cchunk * 8);
+      // Linear output in bf16 (what the reference's RMSNorm sees), in place; sum of squares of this lane's 32 columns
+      float ss[4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+      for (int mi = 0; mi < 4; ++mi) {
+        ss[mi] = 0.f;
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
+        for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const u32x2 br = bsr[nj][qd];
-          const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
-                               __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
-          float v[4];
+          for (int qd = 0; qd < 4; ++qd) {
+            const u32x2 br = bsr[nj][qd];
+            const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
+                                 __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][qd * 4 + e] + bs[e];
-          if (do_gelu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+            for (int e = 0; e < 4; ++e) {
+              const float x = round_bf(acc[mi][nj][qd * 4 + e] + bs[e]);
+              acc[mi][nj][qd * 4 + e] = x;
+              ss[mi] += x * x;
+            }
           }
-          if (EPI == EPI_BIAS_GATE_RES) {
-            const u32x2 gr = gtr[nj][qd];
-            const float gt[4] = {__uint_as_float(gr[0] << 16), __uint_as_float(gr[0] & 0xffff0000u),
-                                 __uint_as_float(gr[1] << 16), __uint_as_float(gr[1] & 0xffff0000u)};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gt[e] * round_bf(v[e]);
-          }
-          u32x2 o;
-          o[0] = pack_bf2(v[0], v[1]);
-          o[1] = pack_bf2(v[2], v[3]);
-          // row r32, 16-byte chunk c = nj*4 + qd stored at chunk c ^ (r32 & 7); the 8-byte half is flipped for rows
-          // 8..15 / 24..31 so the 16 lanes of a ds_write_b64 group touch 16 different bank pairs
-          const int c = nj * 4 + qd;
-          *reinterpret_cast<u32x2*>(stg + r32 * 128 + ((c ^ (r32 & 7)) << 4) + ((hi_e ^ ((r32 >> 3) & 1)) << 3)) = o;
-        }
-      // wave-private region + in-order LDS pipe: no barrier between the writes above and the reads below
-#pragma unroll
-      for (int itr = 0; itr < 4; ++itr) {
-        const int row = itr * 8 + crow;
-        const int m = m0 + g * 128 + mi * 32 + row;
-        u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((cchunk ^ (row & 7)) << 4));
-        if (itr & 1) { const uint32_t t0 = val[0], t1 = val[1]; val[0] = val[2]; val[1] = val[3]; val[2] = t0; val[3] = t1; }
-        if (HAS_RES) {
-          float fv[8], fr[8];
-          unpack8(val, fv);
-          unpack8(rr[mi % RES_DEPTH][itr], fr);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) fv[e] += fr[e];
-          val = pack8(fv);
-        }
-        if (m < p.M && nst < p.N) *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
+        ss[mi] += __shfl_xor(ss[mi], 32, 64);       // the other 32 columns of this wave's stripe
       }
-      if (HAS_RES && mi + RES_DEPTH < 4) {
-        load_res(mi + RES_DEPTH, rr[mi % RES_DEPTH]);   // in flight while the next block is converted and staged
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      if (hi_e == 0) *reinterpret_cast<f32x4*>(stg + r32 * 16) = f32x4{ss[0], ss[1], ss[2], ss[3]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TFX_BARRIER();                                 // both stripes of every head have published their sums
+      const f32x4 other = *reinterpret_cast<const f32x4*>(smem + PP_STG + (wave ^ 1) * PP_STG_WAVE + r32 * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TFX_BARRIER();                                 // ... and read the partner's, before the staging areas are reused below
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) rinv[mi] = rsqrtf((ss[mi] + other[mi]) * (1.0f / 128.0f) + p.n_eps);
     }
+    auto store_blocks = [&](auto NORM_T) __attribute__((always_inline)) {
+      constexpr bool NORM = decltype(NORM_T)::value;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        // (cos, sin) pairs of the four rows this lane stores from this row block, requested before the block is converted
+        // and staged (the latency hides behind that work)
+        f32x4 csr[4][2];
+        if (NORM) {
+#pragma unroll
+          for (int itr = 0; itr < 4; ++itr) {
+            const int mrow = min(m0 + g * 128 + mi * 32 + itr * 8 + crow, p.M - 1);
+            const float* cs = p.rope_cs + (int64_t)(p.rope_pos0 + mrow) * 128 + (wc & 1) * 64 + cchunk * 8;
+            csr[itr][0] = *reinterpret_cast<const f32x4*>(cs);
+            csr[itr][1] = *reinterpret_cast<const f32x4*>(cs + 4);
+          }
+        }
+  #pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+  #pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const u32x2 br = bsr[nj][qd];
+            const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
+                                 __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
+            float v[4];
+            if (NORM) {      // already bias-added and bf16-rounded by the pre-pass; normalised + rotated after the transpose
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][qd * 4 + e];
+            } else {
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][qd * 4 + e] + bs[e];
+            }
+            if (do_gelu) {
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+            }
+            if (EPI == EPI_BIAS_GATE_RES) {
+              const u32x2 gr = gtr[nj][qd];
+              const float gt[4] = {__uint_as_float(gr[0] << 16), __uint_as_float(gr[0] & 0xffff0000u),
+                                   __uint_as_float(gr[1] << 16), __uint_as_float(gr[1] & 0xffff0000u)};
+  #pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gt[e] * round_bf(v[e]);
+            }
+            u32x2 o;
+            o[0] = pack_bf2(v[0], v[1]);
+            o[1] = pack_bf2(v[2], v[3]);
+            // row r32, 16-byte chunk c = nj*4 + qd stored at chunk c ^ (r32 & 7); the 8-byte half is flipped for rows
+            // 8..15 / 24..31 so the 16 lanes of a ds_write_b64 group touch 16 different bank pairs
+            const int c = nj * 4 + qd;
+            *reinterpret_cast<u32x2*>(stg + r32 * 128 + ((c ^ (r32 & 7)) << 4) + ((hi_e ^ ((r32 >> 3) & 1)) << 3)) = o;
+          }
+        }
+        // wave-private region + in-order LDS pipe: no barrier between the writes above and the reads below
+        if (QKN) __builtin_amdgcn_sched_barrier(0);   // keeps the table loads of later row blocks from being hoisted over live accumulators
+  #pragma unroll
+        for (int itr = 0; itr < 4; ++itr) {
+          const int row = itr * 8 + crow;
+          const int m = m0 + g * 128 + mi * 32 + row;
+          u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((cchunk ^ (row & 7)) << 4));
+          if (itr & 1) { const uint32_t t0 = val[0], t1 = val[1]; val[0] = val[2]; val[1] = val[3]; val[2] = t0; val[3] = t1; }
+          if (NORM) {
+            // this lane now holds 8 consecutive columns (4 rotation pairs) of row `row`: its 1/rms sits in the lane whose r32 is
+            // that row, its (cos, sin) pairs are 32 contiguous bytes of the table (the 8 lanes of a row read 256 contiguous bytes)
+            const float rr_row = __shfl(rinv[mi], row, 64);
+            const f32x4 c0 = csr[itr][0], c1 = csr[itr][1];
+            float x[8], wv[8], y[8], o8[8];
+            unpack8(val, x);
+            unpack8(nw8, wv);
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = round_bf(round_bf(x[e] * rr_row) * wv[e]);
+            o8[0] = y[0] * c0[0] + (-y[1]) * c0[1];  o8[1] = y[1] * c0[0] + y[0] * c0[1];
+            o8[2] = y[2] * c0[2] + (-y[3]) * c0[3];  o8[3] = y[3] * c0[2] + y[2] * c0[3];
+            o8[4] = y[4] * c1[0] + (-y[5]) * c1[1];  o8[5] = y[5] * c1[0] + y[4] * c1[1];
+            o8[6] = y[6] * c1[2] + (-y[7]) * c1[3];  o8[7] = y[7] * c1[2] + y[6] * c1[3];
+            val = pack8(o8);
+          }
+          if (HAS_RES) {
+            float fv[8], fr[8];
+            unpack8(val, fv);
+            unpack8(rr[mi % RES_DEPTH][itr], fr);
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+            val = pack8(fv);
+          }
+          if (m < p.M && nst < p.N) *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
+        }
+        if (HAS_RES && mi + RES_DEPTH < 4) {
+          load_res(mi + RES_DEPTH, rr[mi % RES_DEPTH]);   // in flight while the next block is converted and staged
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (QKN) __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (QKN && norm_tile) store_blocks(std::true_type{});
+    else store_blocks(std::false_type{});
     if (!has_next) break;
     cur = nxt;
     it = nit;
@@ -962,6 +1048,8 @@ static GemmParams make_params(const GemmArgs& a) {
   p.csh = a.conv_cin == 8 ? 3 : a.conv_cin == 16 ? 4 : a.conv_cin == 32 ? 5 : 0;
   p.a_scale = a.a_scale; p.as_bs = a.a_scale_bstride; p.w_scale = a.w_scale;
   p.ws = nullptr; p.sk = 1; p.ws_ld = a.N; p.ws_bs = (int64_t)a.M * a.N;
+  p.nq_w = (const bf16_t*)a.qkn_wq; p.nk_w = (const bf16_t*)a.qkn_wk; p.rope_cs = a.qkn_rope_cs; p.rope_pos0 = a.qkn_pos0;
+  p.nq0 = a.qkn_q0; p.nq1 = a.qkn_q1; p.nk0 = a.qkn_k0; p.nk1 = a.qkn_k1; p.n_eps = a.qkn_eps;
   return p;
 }
 
@@ -1047,7 +1135,20 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
       for (int c = 4; c >= 2; --c)
         if (T * c <= grid && nt % (2 * c) == 0 && nt / c >= 8 && (int64_t)c * p.batch * p.M * p.N * 4 <= ws_bytes) { sk = c; break; }
     }
-    if (sk > 1) {
+    if (p.rope_cs) {   // fused q / k RMSNorm + RoPE epilogue: EPI_BIAS_GELU instantiation only (plain bias = gelu_from >= N)
+      if (EPI != EPI_BIAS_GELU) return fail("gemm: the q/k norm + RoPE epilogue rides on the bias(+GELU) epilogue");
+      static bool attrq = false;
+      const void* fn = (const void*)gemm8pp_kernel<EPI_BIAS_GELU, 2, false, false, true>;
+      if (!attrq) {
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, fn);
+        (void)hipGetLastError();
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess)
+          return fail("gemm: cannot raise dynamic LDS limit for the q/k-norm kernel");
+        attrq = true;
+      }
+      gemm8pp_kernel<EPI_BIAS_GELU, 2, false, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+    } else if (sk > 1) {
       static bool attr = false;
       if (!attr) {
         const void* fn = (const void*)gemm8pp_kernel<EPI_BIAS, 2, false, true>;
@@ -1116,7 +1217,24 @@ int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
   return fail("gemm: unknown epilogue %d", a.epilogue);
 }
 
-int gemm_bf16(const GemmArgs& a, hipStream_t st) { return gemm_bf16_variant(a, fast_ok(a) ? 1 : 0, st); }
+int gemm_bf16(const GemmArgs& a, hipStream_t st) {
+  if (a.qkn_rope_cs && !gemm_qkn_ok(a)) return fail("gemm: shape not eligible for the fused q/k norm + RoPE epilogue");
+  return gemm_bf16_variant(a, fast_ok(a) ? 1 : 0, st);
+}
+
+// The fused q/k norm + RoPE epilogue needs the persistent kernel, whole heads per tile pair (column ranges on 256-column
+// tile boundaries), the bias(+GELU) epilogue, and enough tiles that the auto path would not split K (the split-K reduce
+// pass has no such epilogue; few-tile GEMMs -- the text stream at small batch -- keep the separate rmsnorm_rope kernel).
+bool gemm_qkn_ok(const GemmArgs& a) {
+  if (!fast_ok(a) || a.conv_cin > 0 || (a.epilogue != EPI_BIAS_GELU && a.epilogue != EPI_BIAS)) return false;
+  const GemmParams p = make_params(a);
+  if (!persist_ok(p)) return false;
+  if ((a.qkn_q0 | a.qkn_q1 | a.qkn_k0 | a.qkn_k1) % 256) return false;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  return (int64_t)p.batch * p.tm * p.tn >= (cus & ~7);
+}
 
 // ---- fp32 output (raw accumulators, no epilogue): C [batch][M, N] floats with row stride ldc.  The score GEMM of the
 // VAE mid-block attention: q k^T must reach the softmax unrounded.  The persistent kernel in its (tile, slice) form with

@@ -49,6 +49,11 @@ struct GemmArgs {
   // fp8 (e4m3) operands, gemm_fp8 only: A and W hold one byte per element, C = (A.W^T) * a_scale[b][m] * w_scale[n] + bias
   const float* a_scale = nullptr; int64_t a_scale_bstride = 0;   // per activation row
   const float* w_scale = nullptr;                                 // per output channel
+  // fused epilogue of the DiT's q | k | v (| mlp) projections (gemm_qkn_ok() shapes only): per-head (128 columns) RMSNorm
+  // with weights qkn_wq / qkn_wk on the column ranges [qkn_q0, qkn_q1) / [qkn_k0, qkn_k1), then interleaved-pair RoPE with
+  // (cos, sin) pairs qkn_rope_cs [tokens][64][2] fp32 at token qkn_pos0 + row; == rmsnorm_rope() applied afterwards
+  const void* qkn_wq = nullptr; const void* qkn_wk = nullptr; const float* qkn_rope_cs = nullptr;
+  int qkn_pos0 = 0, qkn_q0 = 0, qkn_q1 = 0, qkn_k0 = 0, qkn_k1 = 0; float qkn_eps = 1e-6f;
   // optional scratch for split-K (fp32 partials); without it few-tile GEMMs run unsplit
   void* workspace = nullptr; int64_t workspace_bytes = 0;
 };
@@ -56,6 +61,7 @@ void set_gemm_group_m(int gm);
 void set_gemm_place(int v);
 void set_gemm_splitk(int v);
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
+bool gemm_qkn_ok(const GemmArgs& a);                          // can this GEMM carry the fused q/k norm + RoPE epilogue?
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
 int gemm_bf16_f32out(const GemmArgs& a, hipStream_t st);     // C = fp32 raw accumulators [batch][M, N] (ldc, c_bstride in floats)
 int gemm_fp8(const GemmArgs& a, hipStream_t st);             // persistent MFMA kernel on e4m3 operands (K % 256 == 0)

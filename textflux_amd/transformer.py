@@ -74,6 +74,7 @@ class FluxTransformer2DModel:
         self.w: Dict[str, torch.Tensor] = {}     # fused weights (see module docstring)
         self.w8: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}   # enable_fp8(): name -> (e4m3 bytes [out,in], scale f32 [out])
         self._session: Optional["DitSession"] = None
+        self.fuse_qk_norm_rope = True   # q/k RMSNorm + RoPE in the projection GEMM's epilogue where eligible (tfx_dit_desc.rope_cs)
         D = self.inner_dim
         self.mod_len = 12 * D * num_layers + 3 * D * num_single_layers + 2 * D
 
@@ -366,6 +367,7 @@ class DitSession:
         # into the kernel arguments, so a new ids layout for the same (B, S, T) must not move them
         self.cos = torch.empty(N, c.attention_head_dim, dtype=torch.float32, device=dev)
         self.sin = torch.empty(N, c.attention_head_dim, dtype=torch.float32, device=dev)
+        self.rope_cs = torch.empty(N, c.attention_head_dim // 2, 2, dtype=torch.float32, device=dev)   # (cos_i, sin_i) pairs
         self._ids_key = None
         w = model.w
 
@@ -398,6 +400,7 @@ class DitSession:
         d.hid, d.xn, d.y, d.out = self.hid.data_ptr(), self.xn.data_ptr(), self.y.data_ptr(), self.out.data_ptr()
         d.first_block, d.last_block, d.flags = 0, -1, 0
         d.cos_tab, d.sin_tab = self.cos.data_ptr(), self.sin.data_ptr()
+        d.rope_cs = self.rope_cs.data_ptr() if model.fuse_qk_norm_rope else None
         if self.fp8:
             d.q8, d.q8_scale = self.q8.data_ptr(), self.q8_scale.data_ptr()
         # scratch for the split-K path of few-tile GEMMs (text stream, small batch x resolution): fp32 partials of at most
@@ -443,6 +446,7 @@ class DitSession:
             cos, sin = rope_tables(ids, m.config.axes_dims_rope)
             self.cos.copy_(cos)
             self.sin.copy_(sin)
+            self.rope_cs.copy_(torch.stack((cos[:, 0::2], sin[:, 0::2]), dim=-1))
             self._ids_key = key
 
     def graph_buffers(self, n_steps: int, n_coef: int, lat_shape):
