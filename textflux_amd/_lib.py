@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtextflux_hip.so")
+# TFX_LIB (tools/ only): path of the -DTFX_BENCH build with every A/B kernel variant (`make -C textflux_amd/csrc bench`)
+LIB_PATH = os.environ.get("TFX_LIB") or os.path.join(_HERE, "libtextflux_hip.so")
 HASH_PATH = LIB_PATH + ".srchash"
 CSRC = os.path.join(_HERE, "csrc")
 
@@ -164,6 +165,8 @@ def _src_hash() -> str:
 def is_stale() -> bool:
     """True when libtextflux_hip.so is missing or was not built from the sources now in csrc/ (content hash kept in a
     side file next to the library; mtimes do not survive the copy to the GPU box)."""
+    if os.environ.get("TFX_LIB"):
+        return not os.path.exists(LIB_PATH)          # an explicitly chosen build is the caller's business
     if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
     with open(HASH_PATH) as f:

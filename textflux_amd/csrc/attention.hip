@@ -498,6 +498,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_mx_kernel(const bf16_t* Q, co
 }
 
 
+#ifdef TFX_BENCH
 // -------------------------------------------------------------------------------------------------------------
 // Ping-pong variant.  Same math and data layouts as attn_kernel<8>, different schedule: the tile loop is split into
 // a VALU phase   PA(u) = request the 16 V(u) fragments into registers; online softmax of tile u (scores already in
@@ -767,6 +768,8 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
   }
 }
 
+#endif  // TFX_BENCH
+
 static int g_attn_waves = 10;  // 10 (default) matrix-pipe softmax; 8 exact-online-max lock-step kernel; 4 / 12 = 4-wave workgroups of 8 / 10; 9 = 128 keys per barrier; 16 = ping-pong
 static unsigned long long* g_attn_dbg = nullptr;  // bench-only phase timing buffer
 void set_attention_debug(void* p) {
@@ -777,6 +780,10 @@ static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
 void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20) ? nw : 16; }
 
+// The product library carries the default kernel (10: matrix-pipe softmax), the textbook exact-online-maximum kernel (8: the
+// second implementation the tests compare it with) and the half-tile pipelined kernel (20, attention_hp.hip).  The other
+// schedules tried on the way (4 / 12: two 4-wave workgroups per CU, 9: 128 keys per barrier, 16: ping-pong) and the timing
+// ablations are compiled only with -DTFX_BENCH (`make bench` -> libtextflux_hip_bench.so, used by tools/).
 int joint_attention(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.H <= 0 || a.N <= 0) return 0;
   if ((a.ldq | a.ldk | a.ldv | a.q_bstride | a.k_bstride | a.v_bstride) % 8 || (a.ldo | a.o_bstride) % 4)
@@ -790,32 +797,46 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     if (prof) prof_end(1, st);
     return rc ? rc : check_launch("joint_attention");
   }
+#ifndef TFX_BENCH
+  if (g_attn_waves != 8 && g_attn_waves != 10)
+    return fail("attention: kernel variant %d is a bench-only schedule (build with -DTFX_BENCH)", g_attn_waves);
+  if (g_attn_abl) return fail("attention: ablations are bench-only (build with -DTFX_BENCH)");
+#endif
   const int NW = (g_attn_waves == 16 || g_attn_waves == 9 || g_attn_waves == 10) ? 8 : g_attn_waves == 12 ? 4 : g_attn_waves;
-  const bool pp = g_attn_waves == 16;
   const int qblk = NW * 32;
   static bool attr_set = false;
   if (!attr_set) {
+    const void* fns[] = {(const void*)attn_kernel<8>, (const void*)attn_mx_kernel<8>,
+#ifdef TFX_BENCH
+                         (const void*)attn_kernel<4>, (const void*)attn_mx_kernel<4>,
+#endif
+    };
+    for (const void* fn : fns) {
+      hipFuncAttributes fa;
+      (void)hipFuncGetAttributes(&fa, fn);
+      (void)hipGetLastError();
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
+        return fail("attention: cannot raise dynamic LDS limit");
+    }
+#ifdef TFX_BENCH
     hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<8>);
-    (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<4>);
     (void)hipFuncGetAttributes(&fa, (const void*)attn_kernel<8, 0, 2>);
     (void)hipFuncGetAttributes(&fa, (const void*)attn_pp_kernel<false>);
-    (void)hipFuncGetAttributes(&fa, (const void*)attn_mx_kernel<8>);
-    (void)hipFuncGetAttributes(&fa, (const void*)attn_mx_kernel<4>);
     (void)hipGetLastError();
-    hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_kernel<8, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS2);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_PP);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_mx_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_mx_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-    if (e != hipSuccess) return fail("attention: cannot raise dynamic LDS limit: %s", hipGetErrorString(e));
+    if (hipFuncSetAttribute((const void*)attn_kernel<8, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS2) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_PP) != hipSuccess)
+      return fail("attention: cannot raise dynamic LDS limit (bench variants)");
+#endif
     attr_set = true;
   }
   const int nqb = (a.N + qblk - 1) / qblk;
   const unsigned grid = (unsigned)(a.B * a.H * nqb);
   const bool prof = prof_on(st);
   if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
+  const float sl2 = a.scale * 1.4426950408889634f;
+#define ATT_ARGS (const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, \
+                 a.k_bstride, a.v_bstride, a.o_bstride, a.H, a.N, nqb, sl2
+#ifdef TFX_BENCH
   if (g_attn_abl) {
     (void)hipFuncSetAttribute((const void*)attn_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     (void)hipFuncSetAttribute((const void*)attn_kernel<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
@@ -823,39 +844,34 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)attn_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     (void)hipFuncSetAttribute((const void*)attn_kernel<8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
     (void)hipFuncSetAttribute((const void*)attn_kernel<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS);
-#define ATT_ABL(A) attn_kernel<8, A><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f)
-    switch (g_attn_abl) { case 1: ATT_ABL(1); break; case 2: ATT_ABL(2); break; case 4: ATT_ABL(4); break; case 8: ATT_ABL(8); break; case 16: ATT_ABL(16); break; default: ATT_ABL(15); }
-#undef ATT_ABL
-  } else if (pp)
+    switch (g_attn_abl) {
+      case 1: attn_kernel<8, 1><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS); break;
+      case 2: attn_kernel<8, 2><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS); break;
+      case 4: attn_kernel<8, 4><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS); break;
+      case 8: attn_kernel<8, 8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS); break;
+      case 16: attn_kernel<8, 16><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS); break;
+      default: attn_kernel<8, 15><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS); break;
+    }
+  } else if (g_attn_waves == 16) {
     if (g_attn_dbg) {
       (void)hipFuncSetAttribute((const void*)attn_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_PP);
-      attn_pp_kernel<true><<<grid, 512, ATT_LDS_PP, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
-                                                       a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
-                                                       a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f, g_attn_dbg);
-    } else
-      attn_pp_kernel<false><<<grid, 512, ATT_LDS_PP, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
-                                                        a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
-                                                        a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f, nullptr);
-  else if (g_attn_waves == 10)  // matrix-pipe softmax, one 8-wave workgroup per CU
-    attn_mx_kernel<8><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
-                                                  a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
-                                                  a.N, nqb, a.scale * 1.4426950408889634f);
-  else if (g_attn_waves == 12)  // matrix-pipe softmax, two independent 4-wave workgroups per CU
-    attn_mx_kernel<4><<<grid, 256, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
-                                                  a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
-                                                  a.N, nqb, a.scale * 1.4426950408889634f);
-  else if (g_attn_waves == 9)   // 8 waves, two 64-key sub-tiles per barrier
-    attn_kernel<8, 0, 2><<<grid, 512, ATT_LDS2, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
-                                                      a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
-                                                      a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f);
-  else if (NW == 8)
-    attn_kernel<8><<<grid, 512, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
-                                               a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
-                                               a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f);
-  else
-    attn_kernel<4><<<grid, 256, ATT_LDS, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o,
-                                               a.ldq, a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride,
-                                               a.o_bstride, a.H, a.N, nqb, a.scale * 1.4426950408889634f);
+      attn_pp_kernel<true><<<grid, 512, ATT_LDS_PP, st>>>(ATT_ARGS, g_attn_dbg);
+    } else {
+      attn_pp_kernel<false><<<grid, 512, ATT_LDS_PP, st>>>(ATT_ARGS, nullptr);
+    }
+  } else if (g_attn_waves == 12) {   // matrix-pipe softmax, two independent 4-wave workgroups per CU
+    attn_mx_kernel<4><<<grid, 256, ATT_LDS, st>>>(ATT_ARGS);
+  } else if (g_attn_waves == 9) {    // 8 waves, two 64-key sub-tiles per barrier
+    attn_kernel<8, 0, 2><<<grid, 512, ATT_LDS2, st>>>(ATT_ARGS);
+  } else if (g_attn_waves == 4) {
+    attn_kernel<4><<<grid, 256, ATT_LDS, st>>>(ATT_ARGS);
+  } else
+#endif
+  if (g_attn_waves == 10)            // matrix-pipe softmax, one 8-wave workgroup per CU (default)
+    attn_mx_kernel<8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS);
+  else                               // exact online maximum
+    attn_kernel<8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS);
+#undef ATT_ARGS
   if (prof) prof_end(1, st);
   return check_launch("joint_attention");
 }

@@ -148,7 +148,9 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* smem, uint32_t lds
 // bench_gemm_abl.py, gemm_abl2.py, energy_probe.py): bit 0 no operand requests in the main loop, bit 1 no LDS fragment
 // reads, bit 2 no barriers, bit 3 every tile reads panel 0 (L2-resident), bit 4 no MFMAs, bit 15 half the request bytes,
 // bit 16 every request reads the same 1 KiB (L1-resident).  ABL = 0 is the real kernel.
-template <int EPI, int ABL = 0, bool CONV = false>
+// CONV: 0 plain GEMM, 1 implicit 3x3 convolution with Cin % 64 == 0 (one tap per K-tile), 2 its narrow-input form
+// (Cin = 8 / 16 / 32: the tap is a per-lane quantity; a separate instantiation so that the wide form keeps its registers).
+template <int EPI, int ABL = 0, int CONV = 0>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     constexpr int kAux = GLDS_AUX;
     if (CONV && isx[q]) {
       const int vh = p.inH << p.cup, vw = p.inW << p.cup;
-      if (p.csh) {
+      if (CONV == 2) {
         // narrow inputs (Cin = 8 / 16 / 32: conv_in of the VAE ends): a 64-wide K-tile spans 64 / Cin taps, so the tap
         // is a per-lane quantity of the lane's 16-byte chunk; K is padded to a multiple of 64 and taps >= 9 read zeros
 #pragma unroll
@@ -1082,16 +1084,21 @@ static bool persist_ok(const GemmParams& p) {
          (int64_t)p.tn * 256 * p.ldw * 2 < (1ll << 32) - 65536;
 }
 
+#ifdef TFX_BENCH
 template <int ABL>
 static int launch_ablation(const GemmParams& p, hipStream_t st) {
   (void)hipFuncSetAttribute((const void*)gemm8p_kernel<EPI_BIAS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
   gemm8p_kernel<EPI_BIAS, ABL><<<(unsigned)(p.batch * p.tm * p.tn), 512, LDS_TOTAL, st>>>(p);
   return check_launch("gemm_ablation");
 }
+#endif  // TFX_BENCH
 
 template <int EPI>
 static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws_bytes, hipStream_t st) {
   if (variant >= 10) {  // tools/bench_kernels.py only: timing ablations with WRONG results by construction
+#ifndef TFX_BENCH
+    return fail("gemm: ablation variants are bench-only (build with -DTFX_BENCH)");
+#else
     switch (variant - 10) {
       case 1: return launch_ablation<1>(p, st);
       case 2: return launch_ablation<2>(p, st);
@@ -1107,6 +1114,7 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
       case 98304: return launch_ablation<98304>(p, st);
     }
     return fail("gemm: unknown ablation");
+#endif
   }
   if ((variant == 1 || variant == 3) && persist_ok(p)) {
     static int grid = 0;
@@ -1174,10 +1182,11 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
   }
   if (variant == 3) return fail("gemm: shape not eligible for the persistent kernel");
   if (variant == 1 || variant == 2) {
-    const bool conv = p.cin > 0;
-    static bool attr_set[2] = {false, false};
+    const int conv = p.cin > 0 ? (p.csh ? 2 : 1) : 0;
+    static bool attr_set[3] = {false, false, false};
     if (!attr_set[conv]) {
-      const void* fn = conv ? (const void*)gemm8p_kernel<EPI, 0, true> : (const void*)gemm8p_kernel<EPI, 0, false>;
+      const void* fn = conv == 2 ? (const void*)gemm8p_kernel<EPI, 0, 2> : conv == 1 ? (const void*)gemm8p_kernel<EPI, 0, 1>
+                                                                                  : (const void*)gemm8p_kernel<EPI, 0, 0>;
       hipFuncAttributes fa;  // forces the (lazily loaded) code object in before the attribute is set
       (void)hipFuncGetAttributes(&fa, fn);
       (void)hipGetLastError();
@@ -1189,10 +1198,12 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
     const unsigned grid = (unsigned)(p.batch * p.tm * p.tn);
     const bool prof = prof_on(st) && !conv;
     if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
-    if (conv)
-      gemm8p_kernel<EPI, 0, true><<<grid, 512, LDS_TOTAL, st>>>(p);
+    if (conv == 2)
+      gemm8p_kernel<EPI, 0, 2><<<grid, 512, LDS_TOTAL, st>>>(p);
+    else if (conv == 1)
+      gemm8p_kernel<EPI, 0, 1><<<grid, 512, LDS_TOTAL, st>>>(p);
     else
-      gemm8p_kernel<EPI, 0, false><<<grid, 512, LDS_TOTAL, st>>>(p);
+      gemm8p_kernel<EPI, 0, 0><<<grid, 512, LDS_TOTAL, st>>>(p);
     if (prof) prof_end(0, st);
   } else {
     dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch);
