@@ -778,7 +778,7 @@ void set_attention_debug(void* p) {
 }
 static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
-void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20) ? nw : 16; }
+void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || nw == 30) ? nw : 16; }
 
 // The product library carries the default kernel (10: matrix-pipe softmax), the textbook exact-online-maximum kernel (8: the
 // second implementation the tests compare it with) and the half-tile pipelined kernel (20, attention_hp.hip).  The other
@@ -797,8 +797,15 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     if (prof) prof_end(1, st);
     return rc ? rc : check_launch("joint_attention");
   }
+  if (g_attn_waves == 30) {
+    const bool prof = prof_on(st);
+    if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
+    const int rc = joint_attention_w4(a, st);
+    if (prof) prof_end(1, st);
+    return rc ? rc : check_launch("joint_attention");
+  }
 #ifndef TFX_BENCH
-  if (g_attn_waves != 8 && g_attn_waves != 10)
+  if (g_attn_waves != 8 && g_attn_waves != 10 && g_attn_waves != 30)
     return fail("attention: kernel variant %d is a bench-only schedule (build with -DTFX_BENCH)", g_attn_waves);
   if (g_attn_abl) return fail("attention: ablations are bench-only (build with -DTFX_BENCH)");
 #endif

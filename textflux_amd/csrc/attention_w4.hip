@@ -1,0 +1,467 @@
+// One-wave-per-SIMD joint attention (attention_waves = 30): same math and matrix-pipe softmax bookkeeping as
+// attn_mx_kernel (attention.hip), rebuilt around the SIMD's ISSUE budget.
+//
+// attn_mx_kernel gives every wave 32 query rows; per 64-key tile a wave issues 38 MFMAs (304 issue cycles), 32 v_exp_f32
+// (8 cycles each), ~60 other VALU instructions and 48 LDS fragment reads -- more issue cycles than the 1216 matrix-pipe
+// cycles the MFMAs occupy, so the pipe idles (53 % busy) whatever the schedule (tools/ubench/mfma_fill: one wave hides
+// <= ~24 issue cycles of other work behind each 32-cycle MFMA; two waves on a SIMD are served oldest-first, not
+// interleaved).  The K / V fragment reads and the staging traffic are per WAVE, not per row, so here
+//   * a workgroup is 4 waves (one per SIMD, the whole 512-register file each), a wave owns 64 query rows = two 32-row
+//     q-blocks: every K / V fragment read from LDS feeds two MFMAs, staging per row halves;
+//   * the tile loop is software-pipelined at the granularity of a UNIT = (32-key block, q-block): in step u the MFMA stream
+//     is S(u+1) = K Q^T - m_ref (1 + 8 MFMAs, a dependent chain) alternating with O^T += V^T P(u-1)^T, l += 1^T P(u-1)^T
+//     (2 x (4 + 1) MFMAs, independent accumulators), and the VALU stream in their shadow is the softmax of unit u
+//     (row maximum -> [rarely] move the lazy reference -> 16 v_exp_f32 + 8 v_cvt_pk_bf16_f32).  Consecutive units
+//     alternate between the two q-blocks, so the unit whose reference may move (u) never has MFMAs in flight on its own
+//     accumulators: moving the reference rescales O / l of q-block u & 1 only;
+//   * units run (kb0,q0) (kb0,q1) (kb1,q0) (kb1,q1): the K fragments of a key block serve two consecutive S chains and
+//     the V fragments two consecutive P.V groups; each fragment register is reloaded right after its last use, one whole
+//     step (~600 cycles) before its next, so no LDS latency is ever waited for and no fragment is double-buffered.
+// LDS: ring of 3 tiles (K rows padded to 272 B -> conflict-free b128 reads from ONE per-lane base register + immediates;
+// V rows 256 B with their 64-byte segments XOR-swizzled for the transpose reads), one barrier per 64-key tile.  Tile j + 2 is
+// written (global -> registers -> LDS) while tile j is consumed.
+#include <type_traits>
+
+#include "common.h"
+#include "launch.h"
+
+namespace tfx {
+
+namespace {
+constexpr int W4_KV = 64, W4_HD = 128;
+constexpr int W4_VT = W4_KV * 256;             // V tile bytes
+constexpr int W4_KROW = 272;                   // K row pitch
+constexpr int W4_KT = W4_KV * W4_KROW;         // K tile bytes
+constexpr int W4_NBUF = 3;
+constexpr int W4_KBASE = W4_NBUF * W4_VT;      // V tiles first, then K tiles
+constexpr float W4_THR = 4.0f;                 // lazy-reference threshold (log2 units), as attn_mx_kernel
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+template <int V>
+using IC = std::integral_constant<int, V>;
+}  // namespace
+
+constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
+
+#define W4_GAP() __builtin_amdgcn_sched_barrier(0)
+#ifdef W4_ASM_MFMA
+#define W4_PIN(...) asm volatile("" : __VA_ARGS__)
+#else
+#define W4_PIN(...)
+#endif
+#define W4_ACC "+a"
+// wait until every issued MFMA has written its result (there is no counter for the matrix pipe): 24 x 16 idle issue slots,
+// used twice per workgroup (before the first softmax, before the output)
+#define W4_DRAIN_MFMA()                                                                                                 \
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"      \
+               "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"      \
+               "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
+
+// The MFMAs are inline asm so that the register FILE of every operand is ours to choose: a wave owns all 512 registers, the
+// O / l accumulators (160) and the Q fragments (64) live in the AccVGPRs for the whole kernel, everything the VALU touches
+// (scores, weights) and the K / V fragments in the ArchVGPRs.  (hipcc's builtin takes one form for the whole function:
+// all-AGPR accumulators cost a v_accvgpr_read per score, all-VGPR ones overflow the 256 ArchVGPRs.)
+// Hazards the assembler does not see: an MFMA result needs >= 11 issued instructions before a VALU / memory read -- the
+// schedule below keeps every such read more than a dozen instructions away from the producing MFMA (S(u+1) completes at
+// the end of step u and is first read in step u+1; O of q-block QB is written in the steps of the OTHER q-block).
+#ifdef W4_ASM_MFMA
+// Operand files: srcA (K / V fragments, the constant ones) from the AccVGPRs, srcB (Q, P: what the VALU produces) from the
+// ArchVGPRs, C / D of the score chains in the ArchVGPRs, of the O / l accumulators in the AccVGPRs.
+__device__ __forceinline__ void w4_mfma_s0(f32x16& d, const bf16x8& k, const bf16x8& q) {        // S = k . q   (C = 0)
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(k), "v"(q));
+}
+__device__ __forceinline__ void w4_mfma_s(f32x16& d, const bf16x8& k, const bf16x8& q) {         // S += k . q
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(k), "v"(q));
+}
+__device__ __forceinline__ void w4_mfma_o(f32x16& d, const bf16x8& v, const u32x4& p) {          // O += v . p
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(v), "v"(p));
+}
+__device__ __forceinline__ void w4_mfma_l(f32x16& d, const bf16x8& ones, const u32x4& p) {       // l += 1 . p
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(ones), "v"(p));
+}
+#else
+__device__ __forceinline__ void w4_mfma_s0(f32x16& d, const bf16x8& k, const bf16x8& q) {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k, q, z, 0, 0, 0);
+}
+__device__ __forceinline__ void w4_mfma_s(f32x16& d, const bf16x8& k, const bf16x8& q) {
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k, q, d, 0, 0, 0);
+}
+__device__ __forceinline__ void w4_mfma_o(f32x16& d, const bf16x8& v, const u32x4& p) {
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v, __builtin_bit_cast(bf16x8, p), d, 0, 0, 0);
+}
+__device__ __forceinline__ void w4_mfma_l(f32x16& d, const bf16x8& ones, const u32x4& p) {
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8, p), d, 0, 0, 0);
+}
+#endif
+// single-instruction VALU helpers: hipcc would canonicalise MFMA outputs (v_max x, x) in front of fmaxf and sink the
+// exponentials / conversions to their first use in the NEXT step -- these stay where the schedule puts them
+__device__ __forceinline__ float w4_max7(float a, float b, float c, float d, float e, float f, float g) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7"
+      : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g));
+  return r;
+}
+__device__ __forceinline__ float w4_max4(float a, float b, float c, float d) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+  return r;
+}
+__device__ __forceinline__ float w4_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t w4_cvt_pk(float lo, float hi) {
+  uint32_t r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+__global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
+                                                         const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq, int64_t ldk,
+                                                         int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
+                                                         int64_t o_bs, int H, int N, int nqb, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int qblk = bid % nqb;
+  bid /= nqb;
+  const int h = bid % H;
+  const int b = bid / H;
+  const bf16_t* Qb = Q + b * q_bs + h * W4_HD;
+  const bf16_t* Kb = Kp + b * k_bs + h * W4_HD;
+  const bf16_t* Vb = Vp + b * v_bs + h * W4_HD;
+  bf16_t* Ob = O + b * o_bs + h * W4_HD;
+
+  // ---- Q fragments of the wave's two q-blocks, pre-scaled into the exp2 domain (one extra bf16 rounding of q)
+  int qrow[2];
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    qrow[qb] = qblk * 256 + wave * 64 + qb * 32 + l31;
+    const int rc = qrow[qb] < N ? qrow[qb] : N - 1;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)rc * ldq + s * 16 + hi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[qb][s][e] = (__bf16)((float)qf[qb][s][e] * scale_log2e);
+   // from here on the value lives in the AccVGPRs (one copy, not one per use)
+    }
+  }
+
+  const int nkv = (N + W4_KV - 1) / W4_KV;
+  // ---- staging: thread t moves the 16-byte chunks (row t / 16 + 16 i, chunk t % 16), i = 0..3, of a tile's K and V
+  u32x4 kreg[4], vreg[4];
+  const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)0xffffffffu, 0x00020000);
+  const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)0xffffffffu, 0x00020000);
+  const int ldk2 = (int)ldk * 2, ldv2 = (int)ldv * 2;
+  auto load_tile = [&](int j) __attribute__((always_inline)) {
+    int te = tid;
+    asm volatile("" : "+v"(te));     // offsets rebuilt per tile: as loop invariants they would pin registers
+    const int kr = te >> 4, ch = te & 15;
+    if (j == nkv - 1) {              // last (possibly ragged) tile: rows clamped to the last valid key
+      const int rem = N - 1 - j * W4_KV;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = min(kr + 16 * i, rem);
+        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, key * ldk2 + ch * 16, j * W4_KV * ldk2, 0));
+        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, key * ldv2 + ch * 16, j * W4_KV * ldv2, 0));
+      }
+    } else {
+      const int ko = kr * ldk2 + ch * 16, vo = kr * ldv2 + ch * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, ko, (j * W4_KV + 16 * i) * ldk2, 0));
+        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, (j * W4_KV + 16 * i) * ldv2, 0));
+      }
+    }
+  };
+  auto write_tile = [&](int buf) __attribute__((always_inline)) {
+    const int kr = tid >> 4, ch = tid & 15;
+    char* kd = smem + W4_KBASE + buf * W4_KT + kr * W4_KROW + ch * 16;
+    char* vd = smem + buf * W4_VT + kr * 256 + ((((ch >> 2) ^ (kr & 3)) << 6) | ((ch & 3) << 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(kd + i * 16 * W4_KROW) = kreg[i];
+      *reinterpret_cast<u32x4*>(vd + i * 16 * 256) = vreg[i];
+    }
+  };
+  // ---- fragment read addresses: one per-lane base for K, four (d blocks) for the V transpose reads, + immediates
+  const char* rK = smem + W4_KBASE + l31 * W4_KROW + hi * 16;
+  const int vi = lane & 15;
+  const char* rV[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    rV[db] = smem + (4 * hi + (vi >> 2)) * 256 + 32 * ((lane >> 4) & 1) + (vi & 3) * 8 + ((db ^ ((vi >> 2) & 3)) << 6);
+  // koff: byte offset of (buffer, key block) inside the K region; voff: of (buffer, first 16-key step) inside the V region
+  auto kread = [&](int koff, int s) __attribute__((always_inline)) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(rK + koff + s * 32);
+  };
+  auto vread = [&](int voff, int ks, int db) __attribute__((always_inline)) -> bf16x8 {
+    const char* va = rV[db] + voff + ks * 16 * 256;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 8 * 256));
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  f32x16 o[2][4], ol[2], sc[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ol[qb][r] = 0.f;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o[qb][db][r] = 0.f;
+    }
+  // materialise the zeros in the AccVGPRs HERE: hipcc would otherwise sink each accumulator's initialisation to just in
+  // front of its first (inline-asm) MFMA, with no wait states between the v_accvgpr_write and the MFMA's read of srcC
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+    W4_PIN(W4_ACC(ol[qb]), W4_ACC(o[qb][0]), W4_ACC(o[qb][1]), W4_ACC(o[qb][2]), W4_ACC(o[qb][3]));
+  bf16x8 kone, vone, qm[2], kf[8], vf[2][4];
+  u32x4 pf[2][2];                // bf16 weights of the pending / the current unit, per q-block and 16-key step
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    kone[e] = (__bf16)0.f;
+    vone[e] = (__bf16)1.0f;
+    qm[0][e] = qm[1][e] = (__bf16)0.f;
+  }
+  if (hi == 0) kone[0] = (__bf16)1.0f;
+  W4_PIN(W4_ACC(kone), W4_ACC(vone));   // constants of the bookkeeping MFMAs: AccVGPR residents, not re-materialised
+  float m_ref[2] = {0.f, 0.f};   // bf16-exact lazy reference maximum per q-block row (exp2 domain); -m_ref sits in qm[.][0]
+
+#ifdef W4_DEBUG_CLEAR_LDS
+  for (int i = tid * 16; i < ATT_LDS_W4; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
+  __syncthreads();
+#endif
+  // ---- prologue: tiles 0 and 1 in LDS, tile 2 requested; K fragments of (tile 0, key block 0); S(0)
+  load_tile(0);
+  write_tile(0);
+  if (nkv > 1) {
+    load_tile(1);
+    write_tile(1);
+  }
+  if (nkv > 2) load_tile(2);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) kf[s] = kread(0, s);
+  W4_GAP();
+  w4_mfma_s0(sc[0], kone, qm[0]);                 // reference 0: a zero product, starts the accumulate chain
+#pragma unroll
+  for (int s = 0; s < 8; ++s) w4_mfma_s(sc[0], kf[s], qf[0][s]);
+  // the only place a score is read right after its chain's last MFMA.  MFMAs are issued ahead of their execution (a
+  // dependent chain queues up), so the wait covers the whole chain: 9 x 32 cycles
+  W4_DRAIN_MFMA();
+  W4_GAP();
+
+  // One pipeline step = unit u of q-block QB (u & 1).
+  //   VALU : softmax of S(u) (sc[QB]) -> P(u) (pf[QB]);  rarely: move q-block QB's reference
+  //   MFMA : S(u+1) of the OTHER q-block (sc[OQ]) from the K fragments in kf;  pending P(u-1).V of the other q-block (pf[OQ], vf)
+  //   EVEN : (QB == 0) last user of kf / vf -> each register is reloaded right after its use: kf <- K rows at KN, vf <- V rows at VN
+  //   FIRST: the q-block's first unit pins the reference to the true row maximum
+  //   rag  : this unit's key block reaches past N (last tile only): keys >= N are masked; kb_abs = its first key
+  auto step = [&](auto QBc, auto PVc, auto FIRSTc, auto KNc, auto VNc, bool rag, int kb_abs) __attribute__((always_inline)) {
+    constexpr int QB = decltype(QBc)::value, OQ = 1 - QB;
+    constexpr bool EVEN = QB == 0, PV = decltype(PVc)::value != 0, FIRST = decltype(FIRSTc)::value != 0;
+    constexpr int KN = decltype(KNc)::value, VN = decltype(VNc)::value;
+    f32x16& cur = sc[QB];
+    f32x16& nxt = sc[OQ];
+    if (__builtin_expect(rag, 0)) {
+      int kbase = kb_abs + 4 * hi;
+      asm volatile("" : "+v"(kbase));     // keep the index arithmetic inside the (last-tile-only) branch
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kbase + (r & 3) + 8 * (r >> 2) >= N) cur[r] = -INFINITY;
+    }
+    // MFMA i of the S chain (0: the reference offset, 1..8: the head-dim steps) and of the pending P.V (ks = i / 5, block i % 5)
+    auto S = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value;
+      if constexpr (i == 0) {
+        w4_mfma_s0(nxt, kone, qm[OQ]);
+      } else {
+        w4_mfma_s(nxt, kf[i - 1], qf[OQ][i - 1]);
+        // reload a fragment register two MFMAs after its last reader was ISSUED: an issued MFMA may still be queued behind
+        // the one in the pipe when the next instructions issue, and reads its operands only when it starts
+        if constexpr (EVEN && i >= 2) kf[i - 2] = kread(KN, i - 2);
+      }
+    };
+    auto P = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value, ks = i / 5, db = i % 5;
+      if constexpr (PV) {
+        if constexpr (db == 4) {
+          w4_mfma_l(ol[OQ], vone, pf[OQ][ks]);
+        } else {
+          w4_mfma_o(o[OQ][db], vf[ks][db], pf[OQ][ks]);
+        }
+      }
+      if constexpr (EVEN && i >= 1 && (i - 1) % 5 < 4) vf[(i - 1) / 5][(i - 1) % 5] = vread(VN, (i - 1) / 5, (i - 1) % 5);
+      if constexpr (EVEN && i == 9) kf[7] = kread(KN, 7);
+    };
+    // scores 2i, 2i+1 -> exponentials (in place); the bf16 pack of pair i - 1 follows them (a transcendental result needs
+    // one instruction before a VALU reads it, and the asm pack is invisible to hipcc's hazard pass)
+    auto E = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value;
+      if constexpr (i < 8) {
+        cur[2 * i] = __builtin_amdgcn_exp2f(cur[2 * i]);
+        cur[2 * i + 1] = __builtin_amdgcn_exp2f(cur[2 * i + 1]);
+      }
+      if constexpr (i > 0) pf[QB][(i - 1) >> 2][(i - 1) & 3] = w4_cvt_pk(cur[2 * i - 2], cur[2 * i - 1]);
+    };
+    float mx;
+    S(IC<0>{});
+    P(IC<0>{});
+    mx = w4_max7(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6]);
+    W4_GAP();
+    S(IC<1>{});
+    P(IC<1>{});
+    mx = w4_max7(mx, cur[7], cur[8], cur[9], cur[10], cur[11], cur[12]);
+    W4_GAP();
+    S(IC<2>{});
+    P(IC<2>{});
+    mx = w4_max4(mx, cur[13], cur[14], cur[15]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = w4_max(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // both 32-key halves of the row
+    }
+    W4_GAP();
+    if (FIRST || !__all(mx <= W4_THR)) {
+      // move the reference: everything q-block QB accumulated against the old one is rescaled exactly once (no MFMA on
+      // o[QB] / ol[QB] is in this step's stream), the scores of this unit are shifted before they are exponentiated
+      const float m_new = round_bf(m_ref[QB] + (FIRST ? mx : fmaxf(mx, 0.f)));
+      const float d = m_new - m_ref[QB];
+      m_ref[QB] = m_new;
+      qm[QB][0] = (__bf16)(hi == 0 ? -m_new : 0.f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cur[r] -= d;
+      if constexpr (!FIRST) {
+        const float f = __builtin_amdgcn_exp2f(-d);
+        // one accumulator at a time through 16 ArchVGPRs; the empty asm statements pin each AccVGPR <-> VGPR round trip
+        // inside this (rare) branch
+        auto rescale = [&](f32x16& acc) __attribute__((always_inline)) {
+          W4_PIN(W4_ACC(acc));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] *= f;
+          W4_PIN(W4_ACC(acc));
+        };
+        rescale(ol[QB]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) rescale(o[QB][db]);
+      }
+    }
+    W4_GAP();
+    S(IC<3>{});
+    P(IC<3>{});
+    E(IC<0>{});
+    W4_GAP();
+    S(IC<4>{});
+    P(IC<4>{});
+    E(IC<1>{});
+    W4_GAP();
+    S(IC<5>{});
+    P(IC<5>{});
+    E(IC<2>{});
+    W4_GAP();
+    S(IC<6>{});
+    P(IC<6>{});
+    E(IC<3>{});
+    W4_GAP();
+    S(IC<7>{});
+    P(IC<7>{});
+    E(IC<4>{});
+    W4_GAP();
+    S(IC<8>{});
+    P(IC<8>{});
+    E(IC<5>{});
+    W4_GAP();
+    P(IC<9>{});
+    E(IC<6>{});
+    E(IC<7>{});
+    E(IC<8>{});
+    // the pending weights stay allocated to the end of the step: their registers must not be handed to this step's packs
+    // (an issued MFMA reads its operands when it starts, possibly after the next VALU instructions have executed)
+    asm volatile("" ::"v"(pf[OQ][0]), "v"(pf[OQ][1]));
+    W4_GAP();
+  };
+
+  // one 64-key tile j out of ring buffer B (compile-time: every fragment address is a per-lane base plus an immediate)
+  auto tile = [&](int j, auto Bc, auto FIRSTc) __attribute__((always_inline)) {
+    constexpr int B = decltype(Bc)::value, NB = (B + 1) % 3, WB = (B + 2) % 3;
+    constexpr int FIRST = decltype(FIRSTc)::value;
+    const bool rag = (j == nkv - 1) && (N & (W4_KV - 1));
+    // (kb0, q0): S(kb0, q1);  pending (tile j-1: kb1, q1);  reload kf <- K(j) kb1, vf <- V(j) kb0
+    step(IC<0>{}, IC<!FIRST>{}, IC<FIRST>{}, IC<B * W4_KT + 32 * W4_KROW>{}, IC<B * W4_VT>{}, rag, j * W4_KV);
+    if (j + 2 < nkv) write_tile(WB);         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
+    // (kb0, q1): S(kb1, q0);  pending (kb0, q0)
+    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, rag, j * W4_KV);
+    // (kb1, q0): S(kb1, q1);  pending (kb0, q1);  reload kf <- K(j+1) kb0, vf <- V(j) kb1
+    step(IC<0>{}, IC<1>{}, IC<0>{}, IC<NB * W4_KT>{}, IC<B * W4_VT + 2 * 16 * 256>{}, rag, j * W4_KV + 32);
+    if (j + 3 < nkv) load_tile(j + 3);
+    // (kb1, q1): S(tile j+1: kb0, q0);  pending (kb1, q0)
+    step(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, rag, j * W4_KV + 32);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  tile(0, IC<0>{}, IC<1>{});
+  for (int j = 1; j < nkv; j += 3) {
+    tile(j, IC<1>{}, IC<0>{});
+    if (j + 1 < nkv) tile(j + 1, IC<2>{}, IC<0>{});
+    if (j + 2 < nkv) tile(j + 2, IC<0>{}, IC<0>{});
+  }
+  // ---- drain: the pending P.V of the very last unit (last tile: kb1, q1), V fragments already in registers
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db) w4_mfma_o(o[1][db], vf[ks][db], pf[1][ks]);
+    w4_mfma_l(ol[1], vone, pf[1][ks]);
+  }
+  W4_DRAIN_MFMA();                               // the last MFMA results before the VALU reads them
+
+  // ---- finish: every row of the ones-block holds the full row sum
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float inv = 1.0f / ol[qb][0];
+    if (qrow[qb] < N) {
+      bf16_t* orow = Ob + (int64_t)qrow[qb] * ldo + 4 * hi;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          u32x2 w;
+          w[0] = pack_bf2(o[qb][db][qd * 4 + 0] * inv, o[qb][db][qd * 4 + 1] * inv);
+          w[1] = pack_bf2(o[qb][db][qd * 4 + 2] * inv, o[qb][db][qd * 4 + 3] * inv);
+          *reinterpret_cast<u32x2*>(orow + db * 32 + qd * 8) = w;
+        }
+    }
+  }
+}
+
+int joint_attention_w4(const AttnArgs& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, (const void*)attn_w4_kernel);
+    (void)hipGetLastError();
+    if (hipFuncSetAttribute((const void*)attn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_W4) != hipSuccess)
+      return fail("attention: cannot raise dynamic LDS limit to %d bytes", ATT_LDS_W4);
+    attr_set = true;
+  }
+  const int nqb = (a.N + 255) / 256;
+  const unsigned grid = (unsigned)(a.B * a.H * nqb);
+  attn_w4_kernel<<<grid, 256, ATT_LDS_W4, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
+                                                 a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
+                                                 a.N, nqb, a.scale * 1.4426950408889634f);
+  return 0;
+}
+
+}  // namespace tfx
