@@ -44,6 +44,12 @@ using IC = std::integral_constant<int, V>;
 constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
 
 #define W4_GAP() __builtin_amdgcn_sched_barrier(0)
+#ifndef W4_SPREAD
+#define W4_SPREAD 0   // 1: the staging instructions are spread over the odd steps' MFMA gaps (experimental: wrong results)
+#endif
+#ifndef W4_ABL
+#define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier
+#endif
 #ifdef W4_ASM_MFMA
 #define W4_PIN(...) asm volatile("" : __VA_ARGS__)
 #else
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)rc * ldq + s * 16 + hi * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) qf[qb][s][e] = (__bf16)((float)qf[qb][s][e] * scale_log2e);
+      asm volatile("" : "+a"(qf[qb][s]));   // home of the Q fragments: the AccVGPRs (srcB of the score MFMAs reads them there)
    // from here on the value lives in the AccVGPRs (one copy, not one per use)
     }
   }
@@ -164,36 +171,34 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)0xffffffffu, 0x00020000);
   const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)0xffffffffu, 0x00020000);
   const int ldk2 = (int)ldk * 2, ldv2 = (int)ldv * 2;
-  auto load_tile = [&](int j) __attribute__((always_inline)) {
+  // piece i (rows t / 16 + 16 i) of tile j: global -> registers.  Rows are clamped to the last valid key (a no-op on full
+  // tiles), tiles to the last tile (the pipeline requests up to two tiles past the end; nobody reads those buffers)
+  auto load_piece = [&](int j, auto Ic, bool k_side) __attribute__((always_inline)) {
+    constexpr int i = decltype(Ic)::value;
     int te = tid;
-    asm volatile("" : "+v"(te));     // offsets rebuilt per tile: as loop invariants they would pin registers
-    const int kr = te >> 4, ch = te & 15;
-    if (j == nkv - 1) {              // last (possibly ragged) tile: rows clamped to the last valid key
-      const int rem = N - 1 - j * W4_KV;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int key = min(kr + 16 * i, rem);
-        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, key * ldk2 + ch * 16, j * W4_KV * ldk2, 0));
-        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, key * ldv2 + ch * 16, j * W4_KV * ldv2, 0));
-      }
-    } else {
-      const int ko = kr * ldk2 + ch * 16, vo = kr * ldv2 + ch * 16;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, ko, (j * W4_KV + 16 * i) * ldk2, 0));
-        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, (j * W4_KV + 16 * i) * ldv2, 0));
-      }
-    }
+    asm volatile("" : "+v"(te));     // offsets rebuilt per piece: as loop invariants they would pin registers
+    const int jj = min(j, nkv - 1);
+    const int key = min((te >> 4) + 16 * i, N - 1 - jj * W4_KV), ch16 = (te & 15) * 16;
+    if (k_side)
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, (int)__umul24(key, ldk2) + ch16, jj * W4_KV * ldk2, 0));
+    else
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, (int)__umul24(key, ldv2) + ch16, jj * W4_KV * ldv2, 0));
+  };
+  auto write_piece = [&](int buf, auto Ic, bool k_side) __attribute__((always_inline)) {
+    constexpr int i = decltype(Ic)::value;
+    const int kr = tid >> 4, ch = tid & 15;
+    if (k_side)
+      *reinterpret_cast<u32x4*>(smem + W4_KBASE + buf * W4_KT + kr * W4_KROW + ch * 16 + i * 16 * W4_KROW) = kreg[i];
+    else
+      *reinterpret_cast<u32x4*>(smem + buf * W4_VT + kr * 256 + ((((ch >> 2) ^ (kr & 3)) << 6) | ((ch & 3) << 4)) + i * 16 * 256) = vreg[i];
+  };
+  auto load_tile = [&](int j) __attribute__((always_inline)) {
+    load_piece(j, IC<0>{}, true); load_piece(j, IC<0>{}, false); load_piece(j, IC<1>{}, true); load_piece(j, IC<1>{}, false);
+    load_piece(j, IC<2>{}, true); load_piece(j, IC<2>{}, false); load_piece(j, IC<3>{}, true); load_piece(j, IC<3>{}, false);
   };
   auto write_tile = [&](int buf) __attribute__((always_inline)) {
-    const int kr = tid >> 4, ch = tid & 15;
-    char* kd = smem + W4_KBASE + buf * W4_KT + kr * W4_KROW + ch * 16;
-    char* vd = smem + buf * W4_VT + kr * 256 + ((((ch >> 2) ^ (kr & 3)) << 6) | ((ch & 3) << 4));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(kd + i * 16 * W4_KROW) = kreg[i];
-      *reinterpret_cast<u32x4*>(vd + i * 16 * 256) = vreg[i];
-    }
+    write_piece(buf, IC<0>{}, true); write_piece(buf, IC<0>{}, false); write_piece(buf, IC<1>{}, true); write_piece(buf, IC<1>{}, false);
+    write_piece(buf, IC<2>{}, true); write_piece(buf, IC<2>{}, false); write_piece(buf, IC<3>{}, true); write_piece(buf, IC<3>{}, false);
   };
   // ---- fragment read addresses: one per-lane base for K, four (d blocks) for the V transpose reads, + immediates
   const char* rK = smem + W4_KBASE + l31 * W4_KROW + hi * 16;
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     qm[0][e] = qm[1][e] = (__bf16)0.f;
   }
   if (hi == 0) kone[0] = (__bf16)1.0f;
-  W4_PIN(W4_ACC(kone), W4_ACC(vone));   // constants of the bookkeeping MFMAs: AccVGPR residents, not re-materialised
+  asm volatile("" : "+a"(kone), "+a"(vone));   // constants of the bookkeeping MFMAs: AccVGPR residents, not re-materialised
   float m_ref[2] = {0.f, 0.f};   // bf16-exact lazy reference maximum per q-block row (exp2 domain); -m_ref sits in qm[.][0]
 
 #ifdef W4_DEBUG_CLEAR_LDS
@@ -269,10 +274,11 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   //   EVEN : (QB == 0) last user of kf / vf -> each register is reloaded right after its use: kf <- K rows at KN, vf <- V rows at VN
   //   FIRST: the q-block's first unit pins the reference to the true row maximum
   //   rag  : this unit's key block reaches past N (last tile only): keys >= N are masked; kb_abs = its first key
-  auto step = [&](auto QBc, auto PVc, auto FIRSTc, auto KNc, auto VNc, bool rag, int kb_abs) __attribute__((always_inline)) {
+  //   STG  : staging spread over this step's MFMA gaps: 1 = tile jst -> LDS buffer (STG >> 2) from the registers, 2 = request tile jst
+  auto step = [&](auto QBc, auto PVc, auto FIRSTc, auto KNc, auto VNc, auto STGc, int jst, bool rag, int kb_abs) __attribute__((always_inline)) {
     constexpr int QB = decltype(QBc)::value, OQ = 1 - QB;
     constexpr bool EVEN = QB == 0, PV = decltype(PVc)::value != 0, FIRST = decltype(FIRSTc)::value != 0;
-    constexpr int KN = decltype(KNc)::value, VN = decltype(VNc)::value;
+    constexpr int KN = decltype(KNc)::value, VN = decltype(VNc)::value, STG = decltype(STGc)::value;
     f32x16& cur = sc[QB];
     f32x16& nxt = sc[OQ];
     if (__builtin_expect(rag, 0)) {
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
         w4_mfma_s(nxt, kf[i - 1], qf[OQ][i - 1]);
         // reload a fragment register two MFMAs after its last reader was ISSUED: an issued MFMA may still be queued behind
         // the one in the pipe when the next instructions issue, and reads its operands only when it starts
-        if constexpr (EVEN && i >= 2) kf[i - 2] = kread(KN, i - 2);
+        if constexpr (EVEN && i >= 2 && !(W4_ABL & 2)) kf[i - 2] = kread(KN, i - 2);
       }
     };
     auto P = [&](auto Ic) __attribute__((always_inline)) {
@@ -303,37 +309,54 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
           w4_mfma_o(o[OQ][db], vf[ks][db], pf[OQ][ks]);
         }
       }
-      if constexpr (EVEN && i >= 1 && (i - 1) % 5 < 4) vf[(i - 1) / 5][(i - 1) % 5] = vread(VN, (i - 1) / 5, (i - 1) % 5);
-      if constexpr (EVEN && i == 9) kf[7] = kread(KN, 7);
+      if constexpr (EVEN && i >= 1 && (i - 1) % 5 < 4 && !(W4_ABL & 2)) vf[(i - 1) / 5][(i - 1) % 5] = vread(VN, (i - 1) / 5, (i - 1) % 5);
+      if constexpr (EVEN && i == 9 && !(W4_ABL & 2)) kf[7] = kread(KN, 7);
     };
-    // scores 2i, 2i+1 -> exponentials (in place); the bf16 pack of pair i - 1 follows them (a transcendental result needs
-    // one instruction before a VALU reads it, and the asm pack is invisible to hipcc's hazard pass)
-    auto E = [&](auto Ic) __attribute__((always_inline)) {
-      constexpr int i = decltype(Ic)::value;
-      if constexpr (i < 8) {
-        cur[2 * i] = __builtin_amdgcn_exp2f(cur[2 * i]);
-        cur[2 * i + 1] = __builtin_amdgcn_exp2f(cur[2 * i + 1]);
+    // VALU stream of the exponentials, one instruction per call, in an order in which every bf16 pack follows its two
+    // v_exp_f32 by at least two instructions (a transcendental result needs one instruction before a VALU reads it, and the asm
+    // pack is invisible to hipcc's hazard pass):  e0 e1 e2 c0 e3 e4 c1 e5 e6 c2 ... e13 e14 c6 e15 c7
+    auto F = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int k = decltype(Ic)::value;
+      if constexpr (W4_ABL & 1) return;
+      constexpr bool is_c = (k == 23) || (k >= 3 && k < 22 && k % 3 == 0);
+      if constexpr (is_c) {
+        constexpr int c = k == 23 ? 7 : k / 3 - 1;
+        pf[QB][c >> 2][c & 3] = w4_cvt_pk(cur[2 * c], cur[2 * c + 1]);
+      } else {
+        constexpr int e = k < 3 ? k : k == 22 ? 15 : k - (k / 3);      // exponentials seen so far = index minus packs before it
+        cur[e] = __builtin_amdgcn_exp2f(cur[e]);
       }
-      if constexpr (i > 0) pf[QB][(i - 1) >> 2][(i - 1) & 3] = w4_cvt_pk(cur[2 * i - 2], cur[2 * i - 1]);
     };
-    float mx;
+    // staging piece of gap g (0..7): K and V chunks alternate
+    auto G = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int g = decltype(Ic)::value;
+      if constexpr (W4_ABL & 4) return;
+      if constexpr ((STG & 3) == 1) write_piece(STG >> 2, IC<g / 2>{}, (g & 1) == 0);
+      if constexpr ((STG & 3) == 2) load_piece(jst, IC<g / 2>{}, (g & 1) == 0);
+    };
+    // one MFMA per scheduling region, each with <= ~24 issue cycles of other work behind it: an MFMA that finds the pipe busy
+    // blocks the wave's issue until the pipe takes it, so work placed behind TWO adjacent MFMAs is not hidden by the first
+    float mx = 0.f;
     S(IC<0>{});
+    if constexpr (!(W4_ABL & 8)) mx = w4_max7(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6]);
+    W4_GAP();
     P(IC<0>{});
-    mx = w4_max7(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6]);
+    if constexpr (!(W4_ABL & 8)) mx = w4_max7(mx, cur[7], cur[8], cur[9], cur[10], cur[11], cur[12]);
     W4_GAP();
     S(IC<1>{});
-    P(IC<1>{});
-    mx = w4_max7(mx, cur[7], cur[8], cur[9], cur[10], cur[11], cur[12]);
+    if constexpr (!(W4_ABL & 8)) mx = w4_max4(mx, cur[13], cur[14], cur[15]);
     W4_GAP();
-    S(IC<2>{});
-    P(IC<2>{});
-    mx = w4_max4(mx, cur[13], cur[14], cur[15]);
-    {
+    P(IC<1>{});
+    if constexpr (!(W4_ABL & 8)) {
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
       mx = w4_max(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // both 32-key halves of the row
     }
     W4_GAP();
-    if (FIRST || !__all(mx <= W4_THR)) {
+    S(IC<2>{});
+    W4_GAP();
+    // out of line: with one wave per SIMD nothing hides the instruction-fetch bubble of a TAKEN branch, so the common
+    // path must be the fall-through
+    if (FIRST || (!(W4_ABL & 8) && __builtin_expect(!__all(mx <= W4_THR), 0))) {
       // move the reference: everything q-block QB accumulated against the old one is rescaled exactly once (no MFMA on
       // o[QB] / ol[QB] is in this step's stream), the scores of this unit are shifted before they are exponentiated
       const float m_new = round_bf(m_ref[QB] + (FIRST ? mx : fmaxf(mx, 0.f)));
@@ -358,34 +381,36 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       }
     }
     W4_GAP();
-    S(IC<3>{});
-    P(IC<3>{});
-    E(IC<0>{});
+    P(IC<2>{});
+    G(IC<0>{});
     W4_GAP();
-    S(IC<4>{});
-    P(IC<4>{});
-    E(IC<1>{});
+    S(IC<3>{}); F(IC<0>{}); F(IC<1>{});
     W4_GAP();
-    S(IC<5>{});
-    P(IC<5>{});
-    E(IC<2>{});
+    P(IC<3>{}); F(IC<2>{}); F(IC<3>{}); G(IC<1>{});
     W4_GAP();
-    S(IC<6>{});
-    P(IC<6>{});
-    E(IC<3>{});
+    S(IC<4>{}); F(IC<4>{}); F(IC<5>{});
     W4_GAP();
-    S(IC<7>{});
-    P(IC<7>{});
-    E(IC<4>{});
+    P(IC<4>{}); F(IC<6>{}); F(IC<7>{}); G(IC<2>{});
     W4_GAP();
-    S(IC<8>{});
-    P(IC<8>{});
-    E(IC<5>{});
+    S(IC<5>{}); F(IC<8>{}); F(IC<9>{});
     W4_GAP();
-    P(IC<9>{});
-    E(IC<6>{});
-    E(IC<7>{});
-    E(IC<8>{});
+    P(IC<5>{}); F(IC<10>{}); F(IC<11>{}); G(IC<3>{});
+    W4_GAP();
+    S(IC<6>{}); F(IC<12>{}); F(IC<13>{});
+    W4_GAP();
+    P(IC<6>{}); F(IC<14>{}); F(IC<15>{}); G(IC<4>{});
+    W4_GAP();
+    S(IC<7>{}); F(IC<16>{}); F(IC<17>{});
+    W4_GAP();
+    P(IC<7>{}); F(IC<18>{}); F(IC<19>{}); G(IC<5>{});
+    W4_GAP();
+    S(IC<8>{}); F(IC<20>{}); F(IC<21>{});
+    W4_GAP();
+    P(IC<8>{}); F(IC<22>{}); G(IC<6>{});
+    W4_GAP();
+    P(IC<9>{}); G(IC<7>{});
+    W4_GAP();
+    F(IC<23>{});
     // the pending weights stay allocated to the end of the step: their registers must not be handed to this step's packs
     // (an issued MFMA reads its operands when it starts, possibly after the next VALU instructions have executed)
     asm volatile("" ::"v"(pf[OQ][0]), "v"(pf[OQ][1]));
@@ -398,18 +423,18 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     constexpr int FIRST = decltype(FIRSTc)::value;
     const bool rag = (j == nkv - 1) && (N & (W4_KV - 1));
     // (kb0, q0): S(kb0, q1);  pending (tile j-1: kb1, q1);  reload kf <- K(j) kb1, vf <- V(j) kb0
-    step(IC<0>{}, IC<!FIRST>{}, IC<FIRST>{}, IC<B * W4_KT + 32 * W4_KROW>{}, IC<B * W4_VT>{}, rag, j * W4_KV);
-    if (j + 2 < nkv) write_tile(WB);         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
+    step(IC<0>{}, IC<!FIRST>{}, IC<FIRST>{}, IC<B * W4_KT + 32 * W4_KROW>{}, IC<B * W4_VT>{}, IC<0>{}, 0, rag, j * W4_KV);
+    if (W4_SPREAD == 0 && j + 2 < nkv && !(W4_ABL & 4)) write_tile(WB);   // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
     // (kb0, q1): S(kb1, q0);  pending (kb0, q0)
-    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, rag, j * W4_KV);
+    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<W4_SPREAD * (1 + 4 * WB)>{}, 0, rag, j * W4_KV);
     // (kb1, q0): S(kb1, q1);  pending (kb0, q1);  reload kf <- K(j+1) kb0, vf <- V(j) kb1
-    step(IC<0>{}, IC<1>{}, IC<0>{}, IC<NB * W4_KT>{}, IC<B * W4_VT + 2 * 16 * 256>{}, rag, j * W4_KV + 32);
-    if (j + 3 < nkv) load_tile(j + 3);
+    step(IC<0>{}, IC<1>{}, IC<0>{}, IC<NB * W4_KT>{}, IC<B * W4_VT + 2 * 16 * 256>{}, IC<0>{}, 0, rag, j * W4_KV + 32);
+    if (W4_SPREAD == 0 && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);
     // (kb1, q1): S(tile j+1: kb0, q0);  pending (kb1, q0)
-    step(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, rag, j * W4_KV + 32);
+    step(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<W4_SPREAD * 2>{}, j + 3, rag, j * W4_KV + 32);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(W4_ABL & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
   tile(0, IC<0>{}, IC<1>{});
