@@ -45,7 +45,7 @@ constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
 
 #define W4_GAP() __builtin_amdgcn_sched_barrier(0)
 #ifndef W4_SPREAD
-#define W4_SPREAD 0   // 1: the staging instructions are spread over the odd steps' MFMA gaps (experimental: wrong results)
+#define W4_SPREAD 0   // staging instructions spread over the odd steps' MFMA gaps: 1 the LDS writes, 2 the global loads
 #endif
 #ifndef W4_ABL
 #define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier
@@ -173,11 +173,19 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   const int ldk2 = (int)ldk * 2, ldv2 = (int)ldv * 2;
   // piece i (rows t / 16 + 16 i) of tile j: global -> registers.  Rows are clamped to the last valid key (a no-op on full
   // tiles), tiles to the last tile (the pipeline requests up to two tiles past the end; nobody reads those buffers)
+  const int stg_ko = (tid >> 4) * ldk2 + (tid & 15) * 16, stg_vo = (tid >> 4) * ldv2 + (tid & 15) * 16;   // full-tile form
   auto load_piece = [&](int j, auto Ic, bool k_side) __attribute__((always_inline)) {
     constexpr int i = decltype(Ic)::value;
+    const int jj = min(j, nkv - 1);
+    if (W4_SPREAD && !(N & (W4_KV - 1))) {      // every tile is full: a loop-invariant per-lane offset, the piece in the scalar offset
+      if (k_side)
+        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, stg_ko, (jj * W4_KV + 16 * i) * ldk2, 0));
+      else
+        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, stg_vo, (jj * W4_KV + 16 * i) * ldv2, 0));
+      return;
+    }
     int te = tid;
     asm volatile("" : "+v"(te));     // offsets rebuilt per piece: as loop invariants they would pin registers
-    const int jj = min(j, nkv - 1);
     const int key = min((te >> 4) + 16 * i, N - 1 - jj * W4_KV), ch16 = (te & 15) * 16;
     if (k_side)
       kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, (int)__umul24(key, ldk2) + ch16, jj * W4_KV * ldk2, 0));
@@ -295,8 +303,8 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
         w4_mfma_s0(nxt, kone, qm[OQ]);
       } else {
         w4_mfma_s(nxt, kf[i - 1], qf[OQ][i - 1]);
-        // reload a fragment register two MFMAs after its last reader was ISSUED: an issued MFMA may still be queued behind
-        // the one in the pipe when the next instructions issue, and reads its operands only when it starts
+        // the register is reloaded two MFMAs after its last reader (tools/ubench/mfma_war: not required by the hardware --
+        // an MFMA's operands are safe once it has issued -- it only spreads the LDS reads over the regions)
         if constexpr (EVEN && i >= 2 && !(W4_ABL & 2)) kf[i - 2] = kread(KN, i - 2);
       }
     };
@@ -334,25 +342,28 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       if constexpr ((STG & 3) == 1) write_piece(STG >> 2, IC<g / 2>{}, (g & 1) == 0);
       if constexpr ((STG & 3) == 2) load_piece(jst, IC<g / 2>{}, (g & 1) == 0);
     };
-    // one MFMA per scheduling region, each with <= ~24 issue cycles of other work behind it: an MFMA that finds the pipe busy
-    // blocks the wave's issue until the pipe takes it, so work placed behind TWO adjacent MFMAs is not hidden by the first
+    // One MFMA per scheduling region, each with <= ~24 issue cycles of other work behind it (an MFMA that finds the pipe busy
+    // blocks the wave's issue until the pipe takes it, so work behind TWO adjacent MFMAs is not hidden by the first).
+    // The score chain runs one MFMA ahead of the P.V group: its last MFMA S(8) is followed by three more MFMAs of this step
+    // and the first of the next before anything reads the scores -- an MFMA result needs ~11 issued instructions before a
+    // VALU read, and hipcc cannot insert that wait in front of the inline-asm maxima (it does not know they are VALU).
     float mx = 0.f;
     S(IC<0>{});
     if constexpr (!(W4_ABL & 8)) mx = w4_max7(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6]);
     W4_GAP();
-    P(IC<0>{});
+    S(IC<1>{});
     if constexpr (!(W4_ABL & 8)) mx = w4_max7(mx, cur[7], cur[8], cur[9], cur[10], cur[11], cur[12]);
     W4_GAP();
-    S(IC<1>{});
+    P(IC<0>{});
     if constexpr (!(W4_ABL & 8)) mx = w4_max4(mx, cur[13], cur[14], cur[15]);
     W4_GAP();
-    P(IC<1>{});
+    S(IC<2>{});
     if constexpr (!(W4_ABL & 8)) {
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
       mx = w4_max(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // both 32-key halves of the row
     }
     W4_GAP();
-    S(IC<2>{});
+    P(IC<1>{});
     W4_GAP();
     // out of line: with one wave per SIMD nothing hides the instruction-fetch bubble of a TAKEN branch, so the common
     // path must be the fall-through
@@ -381,38 +392,36 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       }
     }
     W4_GAP();
-    P(IC<2>{});
-    G(IC<0>{});
-    W4_GAP();
     S(IC<3>{}); F(IC<0>{}); F(IC<1>{});
     W4_GAP();
-    P(IC<3>{}); F(IC<2>{}); F(IC<3>{}); G(IC<1>{});
+    P(IC<2>{}); F(IC<2>{}); F(IC<3>{}); G(IC<0>{});
     W4_GAP();
     S(IC<4>{}); F(IC<4>{}); F(IC<5>{});
     W4_GAP();
-    P(IC<4>{}); F(IC<6>{}); F(IC<7>{}); G(IC<2>{});
+    P(IC<3>{}); F(IC<6>{}); F(IC<7>{}); G(IC<1>{});
     W4_GAP();
     S(IC<5>{}); F(IC<8>{}); F(IC<9>{});
     W4_GAP();
-    P(IC<5>{}); F(IC<10>{}); F(IC<11>{}); G(IC<3>{});
+    P(IC<4>{}); F(IC<10>{}); F(IC<11>{}); G(IC<2>{});
     W4_GAP();
     S(IC<6>{}); F(IC<12>{}); F(IC<13>{});
     W4_GAP();
-    P(IC<6>{}); F(IC<14>{}); F(IC<15>{}); G(IC<4>{});
+    P(IC<5>{}); F(IC<14>{}); F(IC<15>{}); G(IC<3>{});
     W4_GAP();
     S(IC<7>{}); F(IC<16>{}); F(IC<17>{});
     W4_GAP();
-    P(IC<7>{}); F(IC<18>{}); F(IC<19>{}); G(IC<5>{});
+    P(IC<6>{}); F(IC<18>{}); F(IC<19>{}); G(IC<4>{});
     W4_GAP();
     S(IC<8>{}); F(IC<20>{}); F(IC<21>{});
     W4_GAP();
-    P(IC<8>{}); F(IC<22>{}); G(IC<6>{});
+    P(IC<7>{}); F(IC<22>{}); G(IC<5>{});
+    W4_GAP();
+    P(IC<8>{}); G(IC<6>{});
     W4_GAP();
     P(IC<9>{}); G(IC<7>{});
     W4_GAP();
     F(IC<23>{});
-    // the pending weights stay allocated to the end of the step: their registers must not be handed to this step's packs
-    // (an issued MFMA reads its operands when it starts, possibly after the next VALU instructions have executed)
+    // the pending weights stay allocated to the end of the step
     asm volatile("" ::"v"(pf[OQ][0]), "v"(pf[OQ][1]));
     W4_GAP();
   };
@@ -424,14 +433,14 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     const bool rag = (j == nkv - 1) && (N & (W4_KV - 1));
     // (kb0, q0): S(kb0, q1);  pending (tile j-1: kb1, q1);  reload kf <- K(j) kb1, vf <- V(j) kb0
     step(IC<0>{}, IC<!FIRST>{}, IC<FIRST>{}, IC<B * W4_KT + 32 * W4_KROW>{}, IC<B * W4_VT>{}, IC<0>{}, 0, rag, j * W4_KV);
-    if (W4_SPREAD == 0 && j + 2 < nkv && !(W4_ABL & 4)) write_tile(WB);   // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
+    if (!(W4_SPREAD & 1) && j + 2 < nkv && !(W4_ABL & 4)) write_tile(WB);   // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
     // (kb0, q1): S(kb1, q0);  pending (kb0, q0)
-    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<W4_SPREAD * (1 + 4 * WB)>{}, 0, rag, j * W4_KV);
+    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<(W4_SPREAD & 1) * (1 + 4 * WB)>{}, 0, rag, j * W4_KV);
     // (kb1, q0): S(kb1, q1);  pending (kb0, q1);  reload kf <- K(j+1) kb0, vf <- V(j) kb1
     step(IC<0>{}, IC<1>{}, IC<0>{}, IC<NB * W4_KT>{}, IC<B * W4_VT + 2 * 16 * 256>{}, IC<0>{}, 0, rag, j * W4_KV + 32);
-    if (W4_SPREAD == 0 && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);
+    if (!(W4_SPREAD & 2) && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);
     // (kb1, q1): S(tile j+1: kb0, q0);  pending (kb1, q0)
-    step(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<W4_SPREAD * 2>{}, j + 3, rag, j * W4_KV + 32);
+    step(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<(W4_SPREAD & 2)>{}, j + 3, rag, j * W4_KV + 32);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!(W4_ABL & 16)) __builtin_amdgcn_s_barrier();
