@@ -173,24 +173,28 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   const int ldk2 = (int)ldk * 2, ldv2 = (int)ldv * 2;
   // piece i (rows t / 16 + 16 i) of tile j: global -> registers.  Rows are clamped to the last valid key (a no-op on full
   // tiles), tiles to the last tile (the pipeline requests up to two tiles past the end; nobody reads those buffers)
-  const int stg_ko = (tid >> 4) * ldk2 + (tid & 15) * 16, stg_vo = (tid >> 4) * ldv2 + (tid & 15) * 16;   // full-tile form
-  auto load_piece = [&](int j, auto Ic, bool k_side) __attribute__((always_inline)) {
-    constexpr int i = decltype(Ic)::value;
-    const int jj = min(j, nkv - 1);
-    if (W4_SPREAD && !(N & (W4_KV - 1))) {      // every tile is full: a loop-invariant per-lane offset, the piece in the scalar offset
-      if (k_side)
-        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, stg_ko, (jj * W4_KV + 16 * i) * ldk2, 0));
-      else
-        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, stg_vo, (jj * W4_KV + 16 * i) * ldv2, 0));
-      return;
-    }
+  // tile j: global -> registers, piece i = rows t / 16 + 16 i.  Full tiles: one per-lane offset (rebuilt per burst: as a loop
+  // invariant it would pin two registers) and the piece in the scalar offset; the last tile of a ragged N clamps its rows
+  auto load_tile = [&](int j) __attribute__((always_inline)) {
     int te = tid;
-    asm volatile("" : "+v"(te));     // offsets rebuilt per piece: as loop invariants they would pin registers
-    const int key = min((te >> 4) + 16 * i, N - 1 - jj * W4_KV), ch16 = (te & 15) * 16;
-    if (k_side)
-      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, (int)__umul24(key, ldk2) + ch16, jj * W4_KV * ldk2, 0));
-    else
-      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, (int)__umul24(key, ldv2) + ch16, jj * W4_KV * ldv2, 0));
+    asm volatile("" : "+v"(te));
+    const int kr = te >> 4, ch16 = (te & 15) * 16;
+    if (j == nkv - 1 && (N & (W4_KV - 1))) {
+      const int rem = N - 1 - j * W4_KV;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = min(kr + 16 * i, rem);
+        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, (int)__umul24(key, ldk2) + ch16, j * W4_KV * ldk2, 0));
+        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, (int)__umul24(key, ldv2) + ch16, j * W4_KV * ldv2, 0));
+      }
+    } else {
+      const int ko = (int)__umul24(kr, ldk2) + ch16, vo = (int)__umul24(kr, ldv2) + ch16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, ko, (j * W4_KV + 16 * i) * ldk2, 0));
+        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, (j * W4_KV + 16 * i) * ldv2, 0));
+      }
+    }
   };
   auto write_piece = [&](int buf, auto Ic, bool k_side) __attribute__((always_inline)) {
     constexpr int i = decltype(Ic)::value;
@@ -199,10 +203,6 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       *reinterpret_cast<u32x4*>(smem + W4_KBASE + buf * W4_KT + kr * W4_KROW + ch * 16 + i * 16 * W4_KROW) = kreg[i];
     else
       *reinterpret_cast<u32x4*>(smem + buf * W4_VT + kr * 256 + ((((ch >> 2) ^ (kr & 3)) << 6) | ((ch & 3) << 4)) + i * 16 * 256) = vreg[i];
-  };
-  auto load_tile = [&](int j) __attribute__((always_inline)) {
-    load_piece(j, IC<0>{}, true); load_piece(j, IC<0>{}, false); load_piece(j, IC<1>{}, true); load_piece(j, IC<1>{}, false);
-    load_piece(j, IC<2>{}, true); load_piece(j, IC<2>{}, false); load_piece(j, IC<3>{}, true); load_piece(j, IC<3>{}, false);
   };
   auto write_tile = [&](int buf) __attribute__((always_inline)) {
     write_piece(buf, IC<0>{}, true); write_piece(buf, IC<0>{}, false); write_piece(buf, IC<1>{}, true); write_piece(buf, IC<1>{}, false);
@@ -340,7 +340,6 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       constexpr int g = decltype(Ic)::value;
       if constexpr (W4_ABL & 4) return;
       if constexpr ((STG & 3) == 1) write_piece(STG >> 2, IC<g / 2>{}, (g & 1) == 0);
-      if constexpr ((STG & 3) == 2) load_piece(jst, IC<g / 2>{}, (g & 1) == 0);
     };
     // One MFMA per scheduling region, each with <= ~24 issue cycles of other work behind it (an MFMA that finds the pipe busy
     // blocks the wave's issue until the pipe takes it, so work behind TWO adjacent MFMAs is not hidden by the first).
@@ -433,12 +432,15 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     const bool rag = (j == nkv - 1) && (N & (W4_KV - 1));
     // (kb0, q0): S(kb0, q1);  pending (tile j-1: kb1, q1);  reload kf <- K(j) kb1, vf <- V(j) kb0
     step(IC<0>{}, IC<!FIRST>{}, IC<FIRST>{}, IC<B * W4_KT + 32 * W4_KROW>{}, IC<B * W4_VT>{}, IC<0>{}, 0, rag, j * W4_KV);
-    if (!(W4_SPREAD & 1) && j + 2 < nkv && !(W4_ABL & 4)) write_tile(WB);   // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
+    // staging burst: tile j + 2 (requested one tile ago) goes into the buffer tile j - 1 left before the last barrier, and the
+    // registers are refilled at once with tile j + 3 -- four steps (> 1 us) before they are needed: with one wave per SIMD
+    // nothing else runs while a wave waits for memory
+    if (!(W4_SPREAD & 1) && j + 2 < nkv && !(W4_ABL & 4)) write_tile(WB);
+    if (!(W4_SPREAD & 2) && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
     // (kb0, q1): S(kb1, q0);  pending (kb0, q0)
     step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<(W4_SPREAD & 1) * (1 + 4 * WB)>{}, 0, rag, j * W4_KV);
     // (kb1, q0): S(kb1, q1);  pending (kb0, q1);  reload kf <- K(j+1) kb0, vf <- V(j) kb1
     step(IC<0>{}, IC<1>{}, IC<0>{}, IC<NB * W4_KT>{}, IC<B * W4_VT + 2 * 16 * 256>{}, IC<0>{}, 0, rag, j * W4_KV + 32);
-    if (!(W4_SPREAD & 2) && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);
     // (kb1, q1): S(tile j+1: kb0, q0);  pending (kb1, q0)
     step(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<(W4_SPREAD & 2)>{}, j + 3, rag, j * W4_KV + 32);
     __builtin_amdgcn_sched_barrier(0);
