@@ -45,7 +45,7 @@ constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
 
 #define W4_GAP() __builtin_amdgcn_sched_barrier(0)
 #ifndef W4_SPREAD
-#define W4_SPREAD 0   // staging instructions spread over the odd steps' MFMA gaps: 1 the LDS writes, 2 the global loads
+#define W4_SPREAD 1   // 1: the LDS writes of the staged tile are spread over step 1's MFMA gaps (0: one burst before step 1)
 #endif
 #ifndef W4_ABL
 #define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier
@@ -436,13 +436,14 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     // registers are refilled at once with tile j + 3 -- four steps (> 1 us) before they are needed: with one wave per SIMD
     // nothing else runs while a wave waits for memory
     if (!(W4_SPREAD & 1) && j + 2 < nkv && !(W4_ABL & 4)) write_tile(WB);
-    if (!(W4_SPREAD & 2) && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
+    if (!(W4_SPREAD & 1) && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
     // (kb0, q1): S(kb1, q0);  pending (kb0, q0)
     step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<(W4_SPREAD & 1) * (1 + 4 * WB)>{}, 0, rag, j * W4_KV);
+    if ((W4_SPREAD & 1) && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);   // refill behind the spread writes
     // (kb1, q0): S(kb1, q1);  pending (kb0, q1);  reload kf <- K(j+1) kb0, vf <- V(j) kb1
     step(IC<0>{}, IC<1>{}, IC<0>{}, IC<NB * W4_KT>{}, IC<B * W4_VT + 2 * 16 * 256>{}, IC<0>{}, 0, rag, j * W4_KV + 32);
     // (kb1, q1): S(tile j+1: kb0, q0);  pending (kb1, q0)
-    step(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<(W4_SPREAD & 2)>{}, j + 3, rag, j * W4_KV + 32);
+    step(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, 0, rag, j * W4_KV + 32);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!(W4_ABL & 16)) __builtin_amdgcn_s_barrier();
