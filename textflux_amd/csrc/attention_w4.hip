@@ -44,9 +44,6 @@ using IC = std::integral_constant<int, V>;
 constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
 
 #define W4_GAP() __builtin_amdgcn_sched_barrier(0)
-#ifndef W4_SPREAD
-#define W4_SPREAD 1   // 1: the LDS writes of the staged tile are spread over step 1's MFMA gaps (0: one burst before step 1)
-#endif
 #ifndef W4_ABL
 #define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier
 #endif
@@ -168,33 +165,37 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   const int nkv = (N + W4_KV - 1) / W4_KV;
   // ---- staging: thread t moves the 16-byte chunks (row t / 16 + 16 i, chunk t % 16), i = 0..3, of a tile's K and V
   u32x4 kreg[4], vreg[4];
-  const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)0xffffffffu, 0x00020000);
-  const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)0xffffffffu, 0x00020000);
+  // buffer descriptors sized to this head's N valid rows: a request past them (the rows of a ragged last tile, whole tiles
+  // requested past the end of the sequence) returns zeros and moves nothing -- the scores of such keys are masked anyway,
+  // and their zero V rows meet zero weights
   const int ldk2 = (int)ldk * 2, ldv2 = (int)ldv * 2;
+  const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)((uint32_t)(N - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
+  const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((uint32_t)(N - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
   // piece i (rows t / 16 + 16 i) of tile j: global -> registers.  Rows are clamped to the last valid key (a no-op on full
   // tiles), tiles to the last tile (the pipeline requests up to two tiles past the end; nobody reads those buffers)
   // tile j: global -> registers, piece i = rows t / 16 + 16 i.  Full tiles: one per-lane offset (rebuilt per burst: as a loop
   // invariant it would pin two registers) and the piece in the scalar offset; the last tile of a ragged N clamps its rows
-  auto load_tile = [&](int j) __attribute__((always_inline)) {
+  // piece i (rows t / 16 + 16 i) of tile j, K or V side: global -> registers.  ko / vo: per-lane byte offset of (row t / 16,
+  // chunk t % 16); the tile and the piece go into the scalar offset
+  auto load_piece = [&](int j, int ko, int vo, auto Ic, bool k_side) __attribute__((always_inline)) {
+    constexpr int i = decltype(Ic)::value;
+    if (W4_ABL & 32) j = 0;          // timing ablation: every request hits the same (cache-resident) tile
+    if (k_side)
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, ko, (j * W4_KV + 16 * i) * ldk2, 0));
+    else
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, (j * W4_KV + 16 * i) * ldv2, 0));
+  };
+  auto stage_offsets = [&](int& ko, int& vo) __attribute__((always_inline)) {
     int te = tid;
-    asm volatile("" : "+v"(te));
-    const int kr = te >> 4, ch16 = (te & 15) * 16;
-    if (j == nkv - 1 && (N & (W4_KV - 1))) {
-      const int rem = N - 1 - j * W4_KV;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int key = min(kr + 16 * i, rem);
-        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, (int)__umul24(key, ldk2) + ch16, j * W4_KV * ldk2, 0));
-        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, (int)__umul24(key, ldv2) + ch16, j * W4_KV * ldv2, 0));
-      }
-    } else {
-      const int ko = (int)__umul24(kr, ldk2) + ch16, vo = (int)__umul24(kr, ldv2) + ch16;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, ko, (j * W4_KV + 16 * i) * ldk2, 0));
-        vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, (j * W4_KV + 16 * i) * ldv2, 0));
-      }
-    }
+    asm volatile("" : "+v"(te));     // rebuilt where needed: as loop invariants the offsets would pin two registers
+    ko = (int)__umul24(te >> 4, ldk2) + (te & 15) * 16;
+    vo = (int)__umul24(te >> 4, ldv2) + (te & 15) * 16;
+  };
+  auto load_tile = [&](int j) __attribute__((always_inline)) {
+    int ko, vo;
+    stage_offsets(ko, vo);
+    load_piece(j, ko, vo, IC<0>{}, true); load_piece(j, ko, vo, IC<0>{}, false); load_piece(j, ko, vo, IC<1>{}, true); load_piece(j, ko, vo, IC<1>{}, false);
+    load_piece(j, ko, vo, IC<2>{}, true); load_piece(j, ko, vo, IC<2>{}, false); load_piece(j, ko, vo, IC<3>{}, true); load_piece(j, ko, vo, IC<3>{}, false);
   };
   auto write_piece = [&](int buf, auto Ic, bool k_side) __attribute__((always_inline)) {
     constexpr int i = decltype(Ic)::value;
@@ -259,11 +260,9 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   // ---- prologue: tiles 0 and 1 in LDS, tile 2 requested; K fragments of (tile 0, key block 0); S(0)
   load_tile(0);
   write_tile(0);
-  if (nkv > 1) {
-    load_tile(1);
-    write_tile(1);
-  }
-  if (nkv > 2) load_tile(2);
+  load_tile(1);
+  write_tile(1);
+  load_tile(2);
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 8; ++s) kf[s] = kread(0, s);
@@ -335,11 +334,18 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
         cur[e] = __builtin_amdgcn_exp2f(cur[e]);
       }
     };
-    // staging piece of gap g (0..7): K and V chunks alternate
+    // staging stream of the step that moves tile jst - 1 from the registers into LDS buffer STG >> 2 and refills every register
+    // with its piece of tile jst right behind:  W0 W1 L0 W2 L1 W3 L2 ... W7 L6 L7  (piece g = K / V chunk g / 2, K first)
+    int stg_ko = 0, stg_vo = 0;
+    if constexpr ((STG & 3) == 1 && !(W4_ABL & 4)) stage_offsets(stg_ko, stg_vo);
     auto G = [&](auto Ic) __attribute__((always_inline)) {
-      constexpr int g = decltype(Ic)::value;
-      if constexpr (W4_ABL & 4) return;
-      if constexpr ((STG & 3) == 1) write_piece(STG >> 2, IC<g / 2>{}, (g & 1) == 0);
+      constexpr int n = decltype(Ic)::value;            // 0..15
+      if constexpr ((STG & 3) == 1 && !(W4_ABL & 4)) {
+        constexpr bool is_w = n == 0 || n == 1 || (n < 15 && (n & 1));   // W0 W1 | L0 W2 L1 W3 ... L5 W7 | L6 L7
+        constexpr int g = n < 2 ? n : is_w ? (n + 1) / 2 : n == 15 ? 7 : n / 2 - 1;
+        if constexpr (is_w) write_piece(STG >> 2, IC<g / 2>{}, (g & 1) == 0);
+        else load_piece(jst, stg_ko, stg_vo, IC<g / 2>{}, (g & 1) == 0);
+      }
     };
     // One MFMA per scheduling region, each with <= ~24 issue cycles of other work behind it (an MFMA that finds the pipe busy
     // blocks the wave's issue until the pipe takes it, so work behind TWO adjacent MFMAs is not hidden by the first).
@@ -391,33 +397,33 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       }
     }
     W4_GAP();
-    S(IC<3>{}); F(IC<0>{}); F(IC<1>{});
+    S(IC<3>{}); F(IC<0>{}); F(IC<1>{}); G(IC<0>{});
     W4_GAP();
-    P(IC<2>{}); F(IC<2>{}); F(IC<3>{}); G(IC<0>{});
+    P(IC<2>{}); F(IC<2>{}); F(IC<3>{}); G(IC<1>{});
     W4_GAP();
-    S(IC<4>{}); F(IC<4>{}); F(IC<5>{});
+    S(IC<4>{}); F(IC<4>{}); F(IC<5>{}); G(IC<2>{});
     W4_GAP();
-    P(IC<3>{}); F(IC<6>{}); F(IC<7>{}); G(IC<1>{});
+    P(IC<3>{}); F(IC<6>{}); F(IC<7>{}); G(IC<3>{});
     W4_GAP();
-    S(IC<5>{}); F(IC<8>{}); F(IC<9>{});
+    S(IC<5>{}); F(IC<8>{}); F(IC<9>{}); G(IC<4>{});
     W4_GAP();
-    P(IC<4>{}); F(IC<10>{}); F(IC<11>{}); G(IC<2>{});
+    P(IC<4>{}); F(IC<10>{}); F(IC<11>{}); G(IC<5>{});
     W4_GAP();
-    S(IC<6>{}); F(IC<12>{}); F(IC<13>{});
+    S(IC<6>{}); F(IC<12>{}); F(IC<13>{}); G(IC<6>{});
     W4_GAP();
-    P(IC<5>{}); F(IC<14>{}); F(IC<15>{}); G(IC<3>{});
+    P(IC<5>{}); F(IC<14>{}); F(IC<15>{}); G(IC<7>{});
     W4_GAP();
-    S(IC<7>{}); F(IC<16>{}); F(IC<17>{});
+    S(IC<7>{}); F(IC<16>{}); F(IC<17>{}); G(IC<8>{});
     W4_GAP();
-    P(IC<6>{}); F(IC<18>{}); F(IC<19>{}); G(IC<4>{});
+    P(IC<6>{}); F(IC<18>{}); F(IC<19>{}); G(IC<9>{});
     W4_GAP();
-    S(IC<8>{}); F(IC<20>{}); F(IC<21>{});
+    S(IC<8>{}); F(IC<20>{}); F(IC<21>{}); G(IC<10>{});
     W4_GAP();
-    P(IC<7>{}); F(IC<22>{}); G(IC<5>{});
+    P(IC<7>{}); F(IC<22>{}); G(IC<11>{});
     W4_GAP();
-    P(IC<8>{}); G(IC<6>{});
+    P(IC<8>{}); G(IC<12>{}); G(IC<13>{});
     W4_GAP();
-    P(IC<9>{}); G(IC<7>{});
+    P(IC<9>{}); G(IC<14>{}); G(IC<15>{});
     W4_GAP();
     F(IC<23>{});
     // the pending weights stay allocated to the end of the step
@@ -432,14 +438,10 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     const bool rag = (j == nkv - 1) && (N & (W4_KV - 1));
     // (kb0, q0): S(kb0, q1);  pending (tile j-1: kb1, q1);  reload kf <- K(j) kb1, vf <- V(j) kb0
     step(IC<0>{}, IC<!FIRST>{}, IC<FIRST>{}, IC<B * W4_KT + 32 * W4_KROW>{}, IC<B * W4_VT>{}, IC<0>{}, 0, rag, j * W4_KV);
-    // staging burst: tile j + 2 (requested one tile ago) goes into the buffer tile j - 1 left before the last barrier, and the
-    // registers are refilled at once with tile j + 3 -- four steps (> 1 us) before they are needed: with one wave per SIMD
-    // nothing else runs while a wave waits for memory
-    if (!(W4_SPREAD & 1) && j + 2 < nkv && !(W4_ABL & 4)) write_tile(WB);
-    if (!(W4_SPREAD & 1) && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);         // tile j + 2 (requested one tile ago) into the buffer tile j - 1 left before the last barrier
-    // (kb0, q1): S(kb1, q0);  pending (kb0, q0)
-    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<(W4_SPREAD & 1) * (1 + 4 * WB)>{}, 0, rag, j * W4_KV);
-    if ((W4_SPREAD & 1) && j + 3 < nkv && !(W4_ABL & 4)) load_tile(j + 3);   // refill behind the spread writes
+    // (kb0, q1): S(kb1, q0);  pending (kb0, q0);  + staging: tile j + 2 (requested one tile ago) goes into the buffer tile j - 1
+    // left before the last barrier, and each register is refilled with its piece of tile j + 3 right behind its write -- four
+    // steps (> 1 us) before it is needed: with one wave per SIMD nothing else runs while a wave waits for memory
+    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<1 + 4 * WB>{}, j + 3, rag, j * W4_KV);
     // (kb1, q0): S(kb1, q1);  pending (kb0, q1);  reload kf <- K(j+1) kb0, vf <- V(j) kb1
     step(IC<0>{}, IC<1>{}, IC<0>{}, IC<NB * W4_KT>{}, IC<B * W4_VT + 2 * 16 * 256>{}, IC<0>{}, 0, rag, j * W4_KV + 32);
     // (kb1, q1): S(tile j+1: kb0, q0);  pending (kb1, q0)
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     if (j + 1 < nkv) tile(j + 1, IC<2>{}, IC<0>{});
     if (j + 2 < nkv) tile(j + 2, IC<0>{}, IC<0>{});
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requests past the end of the sequence (zeros) still write their registers
   // ---- drain: the pending P.V of the very last unit (last tile: kb1, q1), V fragments already in registers
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
