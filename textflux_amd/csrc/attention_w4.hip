@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   const bf16_t* Vb = Vp + b * v_bs + h * W4_HD;
   bf16_t* Ob = O + b * o_bs + h * W4_HD;
 
-  // ---- Q fragments of the wave's two q-blocks, pre-scaled into the exp2 domain (one extra bf16 rounding of q)
+  // ---- Q fragments of the wave's two q-blocks, pre-scaled into the exp2 domain (one extra bf16 rounding of q).  All sixteen
+  // requests go out before the first conversion: with one wave per SIMD a request-wait-convert loop would pay sixteen memory
+  // round trips per workgroup
   int qrow[2];
   bf16x8 qf[2][8];
 #pragma unroll
@@ -153,14 +155,19 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     qrow[qb] = qblk * 256 + wave * 64 + qb * 32 + l31;
     const int rc = qrow[qb] < N ? qrow[qb] : N - 1;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)rc * ldq + s * 16 + hi * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[qb][s][e] = (__bf16)((float)qf[qb][s][e] * scale_log2e);
-      asm volatile("" : "+a"(qf[qb][s]));   // home of the Q fragments: the AccVGPRs (srcB of the score MFMAs reads them there)
-   // from here on the value lives in the AccVGPRs (one copy, not one per use)
-    }
+    for (int s = 0; s < 8; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)rc * ldq + s * 16 + hi * 8);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  auto convert_q = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[qb][s][e] = (__bf16)((float)qf[qb][s][e] * scale_log2e);
+        asm volatile("" : "+a"(qf[qb][s]));   // home of the Q fragments: the AccVGPRs (srcB of the score MFMAs reads them there)
+      }
+  };
 
   const int nkv = (N + W4_KV - 1) / W4_KV;
   // ---- staging: thread t moves the 16-byte chunks (row t / 16 + 16 i, chunk t % 16), i = 0..3, of a tile's K and V
@@ -259,6 +266,9 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
 #endif
   // ---- prologue: tiles 0 and 1 in LDS, tile 2 requested; K fragments of (tile 0, key block 0); S(0)
   load_tile(0);
+  __builtin_amdgcn_sched_barrier(0);
+  convert_q();                     // under the flight of tile 0
+  __builtin_amdgcn_sched_barrier(0);
   write_tile(0);
   load_tile(1);
   write_tile(1);
