@@ -797,7 +797,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     if (prof) prof_end(1, st);
     return rc ? rc : check_launch("joint_attention");
   }
-  if (g_attn_waves == 30) {
+  if (g_attn_waves == 30 && (a.ldo | a.o_bstride) % 8 == 0) {   // whole-row 16-byte output stores
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
     const int rc = joint_attention_w4(a, st);

@@ -477,22 +477,34 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   }
   W4_DRAIN_MFMA();                               // the last MFMA results before the VALU reads them
 
-  // ---- finish: every row of the ones-block holds the full row sum
+  // ---- finish: every row of the ones-block holds the full row sum.  The normalised bf16 rows go through a wave-private LDS
+  // tile (the K / V ring is free: every wave's last fragment read lies before the last barrier) and leave as whole 256-byte
+  // rows, 16 lanes x 16 bytes each (row-per-lane 8-byte stores touch 32 lines per instruction and queue up at the end of
+  // the block, when every wave of the workgroup stores at once)
+  constexpr int OROW = 272;
+  char* ot = smem + wave * (64 * OROW);
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const float inv = 1.0f / ol[qb][0];
-    if (qrow[qb] < N) {
-      bf16_t* orow = Ob + (int64_t)qrow[qb] * ldo + 4 * hi;
+    char* orow = ot + (qb * 32 + l31) * OROW + 8 * hi;
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          u32x2 w;
-          w[0] = pack_bf2(o[qb][db][qd * 4 + 0] * inv, o[qb][db][qd * 4 + 1] * inv);
-          w[1] = pack_bf2(o[qb][db][qd * 4 + 2] * inv, o[qb][db][qd * 4 + 3] * inv);
-          *reinterpret_cast<u32x2*>(orow + db * 32 + qd * 8) = w;
-        }
-    }
+      for (int qd = 0; qd < 4; ++qd) {
+        u32x2 w;
+        w[0] = pack_bf2(o[qb][db][qd * 4 + 0] * inv, o[qb][db][qd * 4 + 1] * inv);
+        w[1] = pack_bf2(o[qb][db][qd * 4 + 2] * inv, o[qb][db][qd * 4 + 3] * inv);
+        *reinterpret_cast<u32x2*>(orow + db * 64 + qd * 16) = w;
+      }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int row0 = qblk * 256 + wave * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i, row = c >> 4, ch = c & 15;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OROW + ch * 16);
+    if (row0 + row < N) *reinterpret_cast<u32x4*>(Ob + (int64_t)(row0 + row) * ldo + ch * 8) = v;
   }
 }
 
