@@ -219,10 +219,11 @@ def test_attention(ops, B, H, N):
     close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
-@pytest.mark.parametrize("nw", [8, 20])
+@pytest.mark.parametrize("nw", [8, 10, 20])
 def test_attention_waves_variants(ops, nw):
-    """The other kernels of the product library (8: exact online maximum, 20: half-tile software-pipelined) compute the same
-    thing as the default (10: matrix-pipe softmax).  The remaining schedules (4, 9, 12, 16) are bench-only builds."""
+    """The other kernels of the product library (8: exact online maximum, 10: matrix-pipe softmax with 8 waves x 32 rows, 20:
+    half-tile software-pipelined) compute the same thing as the default (30: one wave per SIMD, 64 rows per wave).  The
+    remaining schedules (4, 9, 12, 16) are bench-only builds."""
     B, H, N = 2, 2, 712
     q, k, v = (rnd((B, N, H * 128), s).to(BF) for s in (27, 28, 29))
     qh, kh, vh = (t.float().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
@@ -231,17 +232,52 @@ def test_attention_waves_variants(ops, nw):
     try:
         got = ops.attention(q.cuda(), k.cuda(), v.cuda())
     finally:
-        ops.set_option("attention_waves", 10)
+        ops.set_option("attention_waves", 30)
     close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
-@pytest.mark.parametrize("nw", [8, 10, 20])
+@pytest.mark.parametrize("N", [64, 192, 257, 1000, 4608])
+def test_attention_default_kernel_is_deterministic_and_nan_free(ops, N):
+    """The default kernel's schedule keeps every read of an MFMA result a fixed number of MFMAs behind its producer (hipcc
+    cannot insert that wait in front of inline-asm VALU code); a violation shows up as sporadic stale rows, different from
+    run to run.  Six back-to-back runs, interleaved with a kernel that dirties the register file and LDS differently, must
+    be bit-identical and match fp32 SDPA."""
+    B, H = 1, 3
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(B, N, H * 128, generator=g).to(BF).cuda() for _ in range(3))
+    qh, kh, vh = (t.float().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, N, H * 128)
+    outs = []
+    for i in range(6):
+        outs.append(ops.attention(q, k, v))
+        if i % 2:
+            torch.nn.functional.scaled_dot_product_attention(qh, kh, vh)      # another kernel's leftovers in between
+    for o in outs:
+        assert torch.isfinite(o.float()).all()
+        assert torch.equal(o, outs[0])
+    close(outs[0], ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+
+
+def test_attention_unaligned_output_rows_take_the_fallback_kernel(ops):
+    """The default kernel stores whole rows in 16-byte pieces; an output view whose row stride is not a multiple of 8
+    elements is served by the 8-wave kernel instead (same result)."""
+    B, H, N = 1, 2, 300
+    q, k, v = (rnd((B, N, H * 128), s).to(BF).cuda() for s in (31, 32, 33))
+    a = ops.attention(q, k, v)
+    buf = torch.zeros(B, N, H * 128 + 4, dtype=BF, device="cuda")
+    b = ops.attention(q, k, v, out=buf[:, :, :H * 128])
+    close(b, a.float().cpu().to(BF), max_rel=2e-2, mae_rel=4e-3)
+    assert (buf[:, :, H * 128:] == 0).all()
+
+
+@pytest.mark.parametrize("nw", [8, 10, 20, 30])
 def test_attention_reference_maximum_paths_vs_fp64(ops, nw):
     """Inputs that drive every path of the (lazy) reference-maximum logic, against an fp64 softmax: scores that are all
     very negative (first tile must pin the reference to the true maximum: no underflow of the row sum), a maximum that
     grows in every tile, isolated spikes in late tiles (everything accumulated so far is rescaled exactly once), and a
-    peaked distribution.  Same bound for the exact-online-max kernel (8), the matrix-pipe kernel (10) and the half-tile
-    pipelined kernel (20: the reference can move in the middle of a pending P.V there)."""
+    peaked distribution.  Same bound for the exact-online-max kernel (8), the matrix-pipe kernels (10, and the default 30 whose
+    two q-blocks per wave move their references independently) and the half-tile pipelined kernel (20: the reference can move
+    in the middle of a pending P.V there)."""
     B, H, N = 2, 2, 1216
     g = torch.Generator().manual_seed(77)
     q, k, v = (torch.randn(B, N, H * 128, generator=g).to(BF) for _ in range(3))
@@ -266,7 +302,7 @@ def test_attention_reference_maximum_paths_vs_fp64(ops, nw):
             assert err.max().item() <= 2e-2 * ref.abs().max().item() + 1e-3, (name, err.max().item())
             assert err.mean().item() <= 6e-3 * ref.abs().mean().item() + 1e-5, (name, err.mean().item(), ref.abs().mean().item())
     finally:
-        ops.set_option("attention_waves", 10)
+        ops.set_option("attention_waves", 30)
 
 
 def test_attention_online_softmax_rescale_branch(ops):

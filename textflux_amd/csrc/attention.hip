@@ -770,7 +770,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
 
 #endif  // TFX_BENCH
 
-static int g_attn_waves = 10;  // 10 (default) matrix-pipe softmax; 8 exact-online-max lock-step kernel; 4 / 12 = 4-wave workgroups of 8 / 10; 9 = 128 keys per barrier; 16 = ping-pong
+static int g_attn_waves = 30;  // 30 (default) one wave per SIMD, 64 rows per wave (attention_w4.hip); 10 matrix-pipe softmax, 8 waves x 32 rows; 8 exact-online-max lock-step kernel; 4 / 12 = 4-wave workgroups of 8 / 10; 9 = 128 keys per barrier; 16 = ping-pong
 static unsigned long long* g_attn_dbg = nullptr;  // bench-only phase timing buffer
 void set_attention_debug(void* p) {
   g_attn_dbg = (unsigned long long*)p;
@@ -780,8 +780,9 @@ static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
 void set_attention_waves(int nw) { g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || nw == 30) ? nw : 16; }
 
-// The product library carries the default kernel (10: matrix-pipe softmax), the textbook exact-online-maximum kernel (8: the
-// second implementation the tests compare it with) and the half-tile pipelined kernel (20, attention_hp.hip).  The other
+// The product library carries the default kernel (30: attention_w4.hip; it needs 16-byte aligned output rows and falls back to
+// 10 otherwise), its predecessor (10: matrix-pipe softmax, 8 waves x 32 rows), the textbook exact-online-maximum kernel (8: the
+// independent implementation the tests compare them with) and the half-tile pipelined kernel (20, attention_hp.hip).  The other
 // schedules tried on the way (4 / 12: two 4-wave workgroups per CU, 9: 128 keys per barrier, 16: ping-pong) and the timing
 // ablations are compiled only with -DTFX_BENCH (`make bench` -> libtextflux_hip_bench.so, used by tools/).
 int joint_attention(const AttnArgs& a, hipStream_t st) {
@@ -809,7 +810,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     return fail("attention: kernel variant %d is a bench-only schedule (build with -DTFX_BENCH)", g_attn_waves);
   if (g_attn_abl) return fail("attention: ablations are bench-only (build with -DTFX_BENCH)");
 #endif
-  const int NW = (g_attn_waves == 16 || g_attn_waves == 9 || g_attn_waves == 10) ? 8 : g_attn_waves == 12 ? 4 : g_attn_waves;
+  const int NW = (g_attn_waves == 16 || g_attn_waves == 9 || g_attn_waves == 10 || g_attn_waves == 30) ? 8 : g_attn_waves == 12 ? 4 : g_attn_waves;
   const int qblk = NW * 32;
   static bool attr_set = false;
   if (!attr_set) {
@@ -874,7 +875,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     attn_kernel<4><<<grid, 256, ATT_LDS, st>>>(ATT_ARGS);
   } else
 #endif
-  if (g_attn_waves == 10)            // matrix-pipe softmax, one 8-wave workgroup per CU (default)
+  if (g_attn_waves == 10 || g_attn_waves == 30)   // matrix-pipe softmax, one 8-wave workgroup per CU (30 lands here when its alignment needs are not met)
     attn_mx_kernel<8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS);
   else                               // exact online maximum
     attn_kernel<8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS);
