@@ -282,19 +282,19 @@ def main():
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_note = None, None
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (bench.py cannot collect PMCs itself)
-            with open(os.path.join(REPO, "profiles", "r01_gemm_pmc_traffic.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r02_gemm_pmc_traffic.json")) as f:
                 pm = json.load(f)["shapes"][0]
             traffic = pm["hbm_bytes_per_launch"]
             traffic_note = (f"PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the most expensive shape "
                             f"M={pm['M']} N={pm['N']} K={pm['K']} (algorithmic bytes {pm['algorithmic_bytes']}); "
-                            f"profiles/r01_gemm_pmc_traffic.json")
+                            f"profiles/r02_gemm_pmc_traffic.json")
         except Exception:
             pass
         mfma_pmc = None
         try:  # matrix-pipe busy fraction of the DiT kernels from the committed SQ_VALU_MFMA_BUSY_CYCLES pass over this bench
-            with open(os.path.join(REPO, "profiles", "r01_mfma_util.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r02_mfma_util.json")) as f:
                 mu = json.load(f)
-            mfma_pmc = {"dit_kernels": mu["dit_kernels_total"]["mfma_util"], "source": "profiles/r01_mfma_util.json (" + mu["formula"] + ")"}
+            mfma_pmc = {"dit_kernels": mu["dit_kernels_total"]["mfma_util"], "source": "profiles/r02_mfma_util.json (" + mu["formula"] + ")"}
         except Exception:
             pass
         rec = {

@@ -87,3 +87,16 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+
+
+def test_no_torch_compute_left_in_the_package():
+    """the convolution / normalisation / attention arithmetic of the path runs on the library's kernels, not
+    on torch's (round 1 still routed the VAE's conv_in, mid-block attention and tiny configs through torch / MIOpen)."""
+    import glob
+    import re
+    banned = re.compile(r"F\.conv2d|F\.group_norm|F\.layer_norm|scaled_dot_product_attention|torch\.nn\.functional\.(conv2d|group_norm|layer_norm)")
+    for path in glob.glob(os.path.join(REPO, "textflux_amd", "*.py")):
+        with open(path) as f:
+            for i, line in enumerate(f, 1):
+                code = line.split("#")[0]
+                assert not banned.search(code), f"{path}:{i}: {line.strip()}"

@@ -1,25 +1,49 @@
-// One-wave-per-SIMD joint attention (attention_waves = 30): same math and matrix-pipe softmax bookkeeping as
+// One-wave-per-SIMD joint attention (attention_waves = 30, the default): same math and matrix-pipe softmax bookkeeping as
 // attn_mx_kernel (attention.hip), rebuilt around the SIMD's ISSUE budget.
 //
 // attn_mx_kernel gives every wave 32 query rows; per 64-key tile a wave issues 38 MFMAs (304 issue cycles), 32 v_exp_f32
-// (8 cycles each), ~60 other VALU instructions and 48 LDS fragment reads -- more issue cycles than the 1216 matrix-pipe
-// cycles the MFMAs occupy, so the pipe idles (53 % busy) whatever the schedule (tools/ubench/mfma_fill: one wave hides
-// <= ~24 issue cycles of other work behind each 32-cycle MFMA; two waves on a SIMD are served oldest-first, not
-// interleaved).  The K / V fragment reads and the staging traffic are per WAVE, not per row, so here
+// (8 cycles each), ~60 other VALU instructions and 48 LDS fragment reads -- about as many issue cycles as the 1216
+// matrix-pipe cycles its MFMAs occupy, and with two waves per SIMD (served oldest-first, not interleaved) the two streams
+// add up instead of overlapping: the pipe is 53-57 % busy whatever the schedule.  What does overlap is work issued by the
+// SAME wave behind its own MFMA (tools/ubench/mfma_fill: one wave hides ~24 issue cycles behind each 32-cycle MFMA: four
+// simple VALU instructions, or two v_exp_f32 and one more, or two LDS reads and two VALU).  The K / V fragment reads and
+// the staging traffic are per WAVE, not per row, so here
 //   * a workgroup is 4 waves (one per SIMD, the whole 512-register file each), a wave owns 64 query rows = two 32-row
 //     q-blocks: every K / V fragment read from LDS feeds two MFMAs, staging per row halves;
 //   * the tile loop is software-pipelined at the granularity of a UNIT = (32-key block, q-block): in step u the MFMA stream
-//     is S(u+1) = K Q^T - m_ref (1 + 8 MFMAs, a dependent chain) alternating with O^T += V^T P(u-1)^T, l += 1^T P(u-1)^T
+//     is S(u+1) = K Q^T - m_ref (1 + 8 MFMAs, a dependent chain) interleaved with O^T += V^T P(u-1)^T, l += 1^T P(u-1)^T
 //     (2 x (4 + 1) MFMAs, independent accumulators), and the VALU stream in their shadow is the softmax of unit u
 //     (row maximum -> [rarely] move the lazy reference -> 16 v_exp_f32 + 8 v_cvt_pk_bf16_f32).  Consecutive units
 //     alternate between the two q-blocks, so the unit whose reference may move (u) never has MFMAs in flight on its own
 //     accumulators: moving the reference rescales O / l of q-block u & 1 only;
 //   * units run (kb0,q0) (kb0,q1) (kb1,q0) (kb1,q1): the K fragments of a key block serve two consecutive S chains and
-//     the V fragments two consecutive P.V groups; each fragment register is reloaded right after its last use, one whole
-//     step (~600 cycles) before its next, so no LDS latency is ever waited for and no fragment is double-buffered.
+//     the V fragments two consecutive P.V groups; each fragment register is reloaded shortly after its last use, one whole
+//     step (~600 cycles) before its next, so no LDS latency is ever waited for and no fragment is double-buffered;
+//   * ONE MFMA per scheduling region (sched_barrier), each followed by <= ~24 issue cycles of other work: an MFMA that finds
+//     the pipe busy blocks its wave's issue until the pipe takes it, so work placed behind two adjacent MFMAs is not hidden
+//     by the first.  Common path = fall-through (the reference move and the ragged mask are out of line): with one wave
+//     per SIMD nothing hides the instruction-fetch bubble of a taken branch.
+// Register files: the MFMAs are hipcc builtins and this file is compiled with -mllvm -amdgpu-mfma-vgpr-form (Makefile): the
+// scores must come out in ArchVGPRs (the VALU reads them; the AGPR form costs a v_accvgpr_read per score), hipcc then keeps
+// C / D of every MFMA in ArchVGPRs (O + l = 160, scores 32, weights 16) and most K / V fragments, the staging registers and
+// -- pinned by an empty asm -- the 64 Q registers in the AccVGPRs, which srcA / srcB read directly (256 + ~165 registers).
+// A hazard hipcc cannot see: the row maxima and the bf16 packs are inline asm (so that they stay where the schedule puts
+// them); an MFMA result needs ~11 issued instructions before a VALU read and the hazard pass does not know those asm
+// statements are VALU.  The score chain therefore runs one MFMA AHEAD of the P.V group: its last MFMA is followed by three
+// MFMAs of its own step and the first of the next before the scores are read (reading earlier returned stale rows,
+// sporadically: tests/test_kernels_gpu.py::test_attention_default_kernel_is_deterministic_and_nan_free); the only read
+// right behind a chain (prologue) and the output sit behind an explicit drain.  (An MFMA's A / B operands, on the other
+// hand, are safe as soon as it has issued: tools/ubench/mfma_war.)
 // LDS: ring of 3 tiles (K rows padded to 272 B -> conflict-free b128 reads from ONE per-lane base register + immediates;
-// V rows 256 B with their 64-byte segments XOR-swizzled for the transpose reads), one barrier per 64-key tile.  Tile j + 2 is
-// written (global -> registers -> LDS) while tile j is consumed.
+// V rows 256 B with their 64-byte segments XOR-swizzled for the transpose reads; 0 bank conflicts in PMC), one barrier per
+// 64-key tile.  Staging global -> registers -> LDS runs as a stream in the MFMA gaps of step 1 of every tile: piece g of tile
+// j + 2 goes to LDS and its register is refilled with the same piece of tile j + 3 right behind, four steps (> 1 us) before
+// it is needed -- with one wave per SIMD nothing else runs while a wave waits for memory.  The buffer descriptors are sized
+// to the N valid rows, so the rows of a ragged last tile and whole tiles requested past the end read as zeros without any
+// clamping code (their scores are masked / their weights are zero).
+// Measured (MI355X, B = 8, H = 24, N = 4608, random data): 1.12-1.14 PFLOP/s vs 1.04-1.07 for attn_mx_kernel on the same
+// box, 480 vs 495 ms per 57-block DiT forward; on zero data (no power cap) 1.44 PFLOP/s.  Both are power-limited on random
+// data: 1.9 GHz at 1300 W.
 #include <type_traits>
 
 #include "common.h"
@@ -47,12 +71,6 @@ constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
 #ifndef W4_ABL
 #define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier
 #endif
-#ifdef W4_ASM_MFMA
-#define W4_PIN(...) asm volatile("" : __VA_ARGS__)
-#else
-#define W4_PIN(...)
-#endif
-#define W4_ACC "+a"
 // wait until every issued MFMA has written its result (there is no counter for the matrix pipe): 24 x 16 idle issue slots,
 // used twice per workgroup (before the first softmax, before the output)
 #define W4_DRAIN_MFMA()                                                                                                 \
@@ -60,29 +78,6 @@ constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
                "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"      \
                "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 
-// The MFMAs are inline asm so that the register FILE of every operand is ours to choose: a wave owns all 512 registers, the
-// O / l accumulators (160) and the Q fragments (64) live in the AccVGPRs for the whole kernel, everything the VALU touches
-// (scores, weights) and the K / V fragments in the ArchVGPRs.  (hipcc's builtin takes one form for the whole function:
-// all-AGPR accumulators cost a v_accvgpr_read per score, all-VGPR ones overflow the 256 ArchVGPRs.)
-// Hazards the assembler does not see: an MFMA result needs >= 11 issued instructions before a VALU / memory read -- the
-// schedule below keeps every such read more than a dozen instructions away from the producing MFMA (S(u+1) completes at
-// the end of step u and is first read in step u+1; O of q-block QB is written in the steps of the OTHER q-block).
-#ifdef W4_ASM_MFMA
-// Operand files: srcA (K / V fragments, the constant ones) from the AccVGPRs, srcB (Q, P: what the VALU produces) from the
-// ArchVGPRs, C / D of the score chains in the ArchVGPRs, of the O / l accumulators in the AccVGPRs.
-__device__ __forceinline__ void w4_mfma_s0(f32x16& d, const bf16x8& k, const bf16x8& q) {        // S = k . q   (C = 0)
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(k), "v"(q));
-}
-__device__ __forceinline__ void w4_mfma_s(f32x16& d, const bf16x8& k, const bf16x8& q) {         // S += k . q
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(k), "v"(q));
-}
-__device__ __forceinline__ void w4_mfma_o(f32x16& d, const bf16x8& v, const u32x4& p) {          // O += v . p
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(v), "v"(p));
-}
-__device__ __forceinline__ void w4_mfma_l(f32x16& d, const bf16x8& ones, const u32x4& p) {       // l += 1 . p
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(ones), "v"(p));
-}
-#else
 __device__ __forceinline__ void w4_mfma_s0(f32x16& d, const bf16x8& k, const bf16x8& q) {
   f32x16 z;
 #pragma unroll
@@ -98,7 +93,6 @@ __device__ __forceinline__ void w4_mfma_o(f32x16& d, const bf16x8& v, const u32x
 __device__ __forceinline__ void w4_mfma_l(f32x16& d, const bf16x8& ones, const u32x4& p) {
   d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8, p), d, 0, 0, 0);
 }
-#endif
 // single-instruction VALU helpers: hipcc would canonicalise MFMA outputs (v_max x, x) in front of fmaxf and sink the
 // exponentials / conversions to their first use in the NEXT step -- these stay where the schedule puts them
 __device__ __forceinline__ float w4_max7(float a, float b, float c, float d, float e, float f, float g) {
@@ -243,11 +237,6 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
 #pragma unroll
       for (int db = 0; db < 4; ++db) o[qb][db][r] = 0.f;
     }
-  // materialise the zeros in the AccVGPRs HERE: hipcc would otherwise sink each accumulator's initialisation to just in
-  // front of its first (inline-asm) MFMA, with no wait states between the v_accvgpr_write and the MFMA's read of srcC
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-    W4_PIN(W4_ACC(ol[qb]), W4_ACC(o[qb][0]), W4_ACC(o[qb][1]), W4_ACC(o[qb][2]), W4_ACC(o[qb][3]));
   bf16x8 kone, vone, qm[2], kf[8], vf[2][4];
   u32x4 pf[2][2];                // bf16 weights of the pending / the current unit, per q-block and 16-key step
 #pragma unroll
@@ -312,8 +301,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
         w4_mfma_s0(nxt, kone, qm[OQ]);
       } else {
         w4_mfma_s(nxt, kf[i - 1], qf[OQ][i - 1]);
-        // the register is reloaded two MFMAs after its last reader (tools/ubench/mfma_war: not required by the hardware --
-        // an MFMA's operands are safe once it has issued -- it only spreads the LDS reads over the regions)
+        // reloaded two MFMAs after its last reader: spreads the LDS reads over the regions
         if constexpr (EVEN && i >= 2 && !(W4_ABL & 2)) kf[i - 2] = kread(KN, i - 2);
       }
     };
@@ -393,17 +381,12 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       for (int r = 0; r < 16; ++r) cur[r] -= d;
       if constexpr (!FIRST) {
         const float f = __builtin_amdgcn_exp2f(-d);
-        // one accumulator at a time through 16 ArchVGPRs; the empty asm statements pin each AccVGPR <-> VGPR round trip
-        // inside this (rare) branch
-        auto rescale = [&](f32x16& acc) __attribute__((always_inline)) {
-          W4_PIN(W4_ACC(acc));
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] *= f;
-          W4_PIN(W4_ACC(acc));
-        };
-        rescale(ol[QB]);
+        for (int r = 0; r < 16; ++r) {
+          ol[QB][r] *= f;
 #pragma unroll
-        for (int db = 0; db < 4; ++db) rescale(o[QB][db]);
+          for (int db = 0; db < 4; ++db) o[QB][db][r] *= f;
+        }
       }
     }
     W4_GAP();
@@ -436,8 +419,6 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     P(IC<9>{}); G(IC<14>{}); G(IC<15>{});
     W4_GAP();
     F(IC<23>{});
-    // the pending weights stay allocated to the end of the step
-    asm volatile("" ::"v"(pf[OQ][0]), "v"(pf[OQ][1]));
     W4_GAP();
   };
 

@@ -180,13 +180,20 @@ class FluxFillPipeline:
             return _NullBar()
 
     def maybe_free_model_hooks(self):
-        pass
+        pass                         # nothing is offloaded (reference: D/pipelines/pipeline_utils.py offload hooks)
+
+    def _vae_memory_knob(self, name):
+        import warnings
+        if not getattr(self, "_warned_vae_knob", False):
+            self._warned_vae_knob = True
+            warnings.warn(f"{name}() has no effect here: the VAE runs untiled / unsliced at every supported geometry "
+                          "(288 GB of HBM per MI355X); the call is accepted for drop-in compatibility", stacklevel=3)
 
     def enable_vae_slicing(self):
-        pass
+        self._vae_memory_knob("enable_vae_slicing")
 
     def enable_vae_tiling(self):
-        pass
+        self._vae_memory_knob("enable_vae_tiling")
 
     @property
     def guidance_scale(self):

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-2 profile collection on one MI355X box (every --pmc pass is its own run, counters + kernel trace only).
+# usage (from the repo root on the GPU box): bash tools/run_r02_profiles.sh ; results under gpurun_out/r02/
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/r02; mkdir -p $out
+# 1. kernel-trace summary of the default bench run (eager, so that every launch is in the trace) + its bench line
+rocprofv3 --kernel-trace --stats -d $out/trace -o r02 --output-format csv -- python bench.py --no-cpu-baseline --no-graph --steps 1 --warmup 1 > $out/bench_under_rocprof.log 2>&1
+tail -1 $out/bench_under_rocprof.log > $out/r02_bench_under_rocprof.json
+cp $out/trace/*kernel_stats.csv $out/r02_bench_kernel_stats.csv 2>/dev/null
+# 2. matrix-pipe busy over a 2-step bench
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/mfma -o r02 --output-format csv -- python bench.py --no-cpu-baseline --no-graph --steps 1 --warmup 0 --denoise-steps 2 > $out/mfma.log 2>&1
+python tools/pmc_bench_util.py $out/mfma/r02_counter_collection.csv $out/r02_mfma_util.json > $out/mfma_util.log 2>&1
+# 3. GEMM traffic at the three dominant shapes (separate passes)
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --kernel-trace -d $out/gemm_$n -o r02 --output-format csv -- python tools/bench_gemm_one.py > $out/gemm_$n.log 2>&1
+done
+# 4. attention: default kernel (30) vs its predecessor (10)
+for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES"; do
+  n=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --kernel-trace -d $out/attn_$n -o r02 --output-format csv -- python tools/pmc_attn.py > $out/attn_$n.log 2>&1
+done
+python tools/r02_pmc_summary.py $out
+ls $out
