@@ -264,14 +264,21 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        if k == a.steps - 1 and rank == 0:
-            ops.prof_enable(True)   # per-launch HIP events on the GEMM / attention launches of the last timed call
         out = one_call()
     torch.cuda.synchronize()
     tdist.barrier()
     torch.cuda.synchronize()
     elapsed = tdist.max_over_ranks(time.perf_counter() - t0, dev)
+    # roofline sample: ONE MORE call, untimed and eager (the library's per-launch HIP events only see eager launches; a
+    # replayed graph's kernels are not individually timed), so that the sample is every GEMM / attention launch of a whole
+    # call -- 30 steps, VAE, text encoders -- not just the eager first step of a graph-replayed call
+    pipe.enable_hip_graph(False)
+    if rank == 0:
+        ops.prof_enable(True)
+    one_call()
+    torch.cuda.synchronize()
     ops.prof_enable(False)
+    pipe.enable_hip_graph(not a.no_graph)
     seen = tdist.ranks_seen(dev)   # ranks that answered an RCCL all-reduce
 
     if rank == 0:
@@ -318,6 +325,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "tfx::gemm8pp_kernel (persistent MFMA GEMM, all epilogues; + gemm8p_kernel for K % 128 != 0)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS * (2 if a.fp8 else 1), "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_TFLOPS * (2 if a.fp8 else 1)),
                          "traffic": None if a.fp8 else traffic, "traffic_note": None if a.fp8 else traffic_note, "mfma_busy_pmc": None if a.fp8 else mfma_pmc, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                         "sample": "HIP events around every GEMM launch of one extra, untimed, eager call after the timed region (graph-replayed launches are not individually timed)",
                          "flops_per_launch": gemm_fl / max(gemm_n, 1),
                          "attention": {"achieved": att_fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0,
                                        "launches": att_n, "avg_launch_ms": att_ms / max(att_n, 1)}},
