@@ -493,8 +493,12 @@ int joint_attention_w4(const AttnArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, (const void*)attn_w4_kernel);
+    if (hipFuncGetAttributes(&fa, (const void*)attn_w4_kernel) != hipSuccess) return fail("attention: no attn_w4_kernel in this build");
     (void)hipGetLastError();
+    // built without -mllvm -amdgpu-mfma-vgpr-form (see Makefile) the accumulators land in the AccVGPRs and ~500 registers spill
+    if (fa.localSizeBytes != 0)
+      return fail("attention: attn_w4_kernel spills %zu bytes per lane -- attention_w4.hip must be compiled with "
+                  "-mllvm -amdgpu-mfma-vgpr-form", (size_t)fa.localSizeBytes);
     if (hipFuncSetAttribute((const void*)attn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_W4) != hipSuccess)
       return fail("attention: cannot raise dynamic LDS limit to %d bytes", ATT_LDS_W4);
     attr_set = true;

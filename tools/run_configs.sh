@@ -1,5 +1,5 @@
 #!/bin/bash
-# Re-measures the rows of profiles/r01_configs.md (one bench.py line each) into gpurun_out/configs.jsonl
+# Re-measures the rows of profiles/r0N_configs.md (one bench.py line each) into gpurun_out/configs.jsonl
 out=gpurun_out/configs.jsonl; : > $out
 run() { timeout 600 python bench.py --no-cpu-baseline "$@" 2>&1 | grep '^{"metric"' | tail -1 >> $out; }
 run --batch 1
@@ -9,6 +9,8 @@ run --batch 1 --height 2048 --width 1024
 run --batch 8 --height 2048 --width 1024
 run --batch 4 --height 1184 --width 1024 --sampler amo
 run --fp8 --batch 1
+run --fp8
+run --fp8 --denoise-steps 50
 python - <<'PY'
 import json
 for l in open("gpurun_out/configs.jsonl"):
