@@ -287,15 +287,19 @@ int tfx_add_into_f32(float* x, const void* y, int64_t n, int32_t mode, tfx_strea
 int tfx_mul_act(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int32_t cols,
                 int32_t mode, tfx_stream stream);
 
-/* ---- tuning knobs (no reference counterpart).  "attention_waves" selects the attention kernel: 10 (default) = one
- *      512-thread workgroup of 256 query rows per CU with the softmax bookkeeping on the matrix pipe (pre-scaled Q, lazy
- *      reference maximum subtracted by an extra MFMA k-step, row sums from a ones-block of the PV MFMA); 8 = the same
- *      schedule with the textbook exact online maximum; 12 / 4 = two independent 256-thread workgroups per CU of 10 / 8;
- *      9 = 8 with 128 keys per barrier; 16 = softmax / MFMA ping-pong between the wave groups.  All compute the same
- *      softmax; 10 and 12 differ from the others in rounding only (one extra bf16 rounding of q * scale, row sums of the
- *      bf16 weights).  "gemm_group_m": row tiles per group of the GEMM tile order (default 4).  "gemm_place": slot
- *      assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip).  "gemm_splitk": 0 disables the
- *      split-K path of few-tile GEMMs (default 1). */
+/* ---- tuning knobs (no reference counterpart).  "attention_waves" selects the attention kernel: 30 (default) = one
+ *      256-thread workgroup per CU -- one wave per SIMD, 64 query rows per wave, the tile loop pipelined per (32-key block,
+ *      32-row q-block) unit (attention_w4.hip); it stores whole output rows in 16-byte pieces, so output views whose row or
+ *      batch stride is not a multiple of 8 elements are served by 10.  10 = one 512-thread workgroup of 256 query rows per
+ *      CU, 32 rows per wave; both keep the softmax bookkeeping on the matrix pipe (pre-scaled Q, lazy reference maximum
+ *      subtracted by an extra MFMA k-step, row sums from a ones-block of the PV MFMA).  8 = the 512-thread schedule with the
+ *      textbook exact online maximum (the independent implementation the tests compare with); 20 = 10 pipelined per
+ *      half-tile (attention_hp.hip).  Bench builds only (-DTFX_BENCH): 12 / 4 = two independent 256-thread workgroups per
+ *      CU of 10 / 8; 9 = 8 with 128 keys per barrier; 16 = softmax / MFMA ping-pong between the wave groups.  All compute
+ *      the same softmax; 10, 12, 20 and 30 differ from the others in rounding only (one extra bf16 rounding of q * scale,
+ *      row sums of the bf16 weights).  "gemm_group_m": row tiles per group of the GEMM tile order (default 4).
+ *      "gemm_place": slot assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip).
+ *      "gemm_splitk": 0 disables the split-K path of few-tile GEMMs (default 1). */
 int tfx_set_option(const char* name, int value);
 
 /* ---- measurement hooks (no reference counterpart: the reference has no profiling) --------------------
