@@ -798,7 +798,10 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     if (prof) prof_end(1, st);
     return rc ? rc : check_launch("joint_attention");
   }
-  if (g_attn_waves == 30 && (a.ldo | a.o_bstride) % 8 == 0) {   // whole-row 16-byte output stores
+  // option 30: whole-row 16-byte output stores; its K / V buffer descriptors cover one head's rows with a 32-bit byte count
+  const bool w4_ok = (a.ldo | a.o_bstride) % 8 == 0 && (uint64_t)(a.N - 1) * (uint64_t)a.ldk * 2 + 256 < (1ull << 32) &&
+                     (uint64_t)(a.N - 1) * (uint64_t)a.ldv * 2 + 256 < (1ull << 32);
+  if (g_attn_waves == 30 && w4_ok) {
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
     const int rc = joint_attention_w4(a, st);
