@@ -240,6 +240,14 @@ int tfx_any_negative(const void* x, int32_t dtype, int64_t n, int32_t* flag, tfx
 int tfx_prep_image(const void* img, int32_t img_dtype, const void* mask, int32_t mask_dtype, void* out, int32_t B, int32_t C,
                    int32_t H, int32_t W, int32_t mask_batch, int32_t norm_mode, int32_t binarize, const int32_t* neg_flag,
                    tfx_stream stream);
+/* The callers' composition step on the device (reference: /root/reference/run_inference.py:409-467 and
+ * scripts/run_eval.py:143-198 stack the rendered glyph image and the scene -- glyph first -- and a black mask for the glyph part
+ * over the scene's mask; IP's do_convert_grayscale then takes PIL's "L" of the RGB mask): canvas [B, H, W, 3] u8 and
+ * cmask [B, H, W] u8 from glyph [B, gh, gw, 3], scene [B, sh, sw, 3] and the scene's RGB mask [B, sh, sw, 3] (u8,
+ * interleaved).  direction 0: vertical, H = gh + sh, W = gw = sw; 1: horizontal, W = gw + sw, H = gh = sh.  Grey value =
+ * Pillow's (19595 R + 38470 G + 7471 B + 0x8000) >> 16.  The outputs feed tfx_prep_image (dtype 2) / tfx_pack_mask. */
+int tfx_compose_canvas(const void* glyph, const void* scene, const void* scene_mask_rgb, void* canvas, void* cmask, int32_t B,
+                       int32_t gh, int32_t gw, int32_t sh, int32_t sw, int32_t direction, tfx_stream stream);
 /* out[b, t, col0 + (i*8+j)*4 + py*2+px] = mask[(2ty+py)*8 + i, (2tx+px)*8 + j]  (P:1563-1580: 8x8 pixel blocks -> channels,
  * then _pack_latents), t = ty * (W/16) + tx, row stride ld. */
 int tfx_pack_mask(const void* mask, int32_t mask_dtype, void* out, int32_t B, int32_t H, int32_t W, int32_t mask_batch,

@@ -105,8 +105,11 @@ def test_batch_driver_matches_single_image_calls(env, tmp_path):
     ri.PIPE = None
     pipe = ri.load_flux_pipeline()
     items, singles = [], []
-    for i, word in enumerate(["ALPHA", "BETA", "GAMMA"]):
-        scene, mask = _scene(10 + i)
+    # the fourth scene's height makes glyph strip + scene a multiple of 32: no resize, the canvas is composed on the device
+    # (a geometry of its own: batches are formed per pipeline size)
+    h_dev = 160 - int(320 * glyph.TEXT_HEIGHT_RATIO)
+    for i, word in enumerate(["ALPHA", "BETA", "GAMMA", "DELTA"]):
+        scene, mask = _scene(10 + i) if i < 3 else _scene(10 + i, 320, h_dev)
         sp, mp = str(tmp_path / f"s{i}.png"), str(tmp_path / f"m{i}.png")
         scene.save(sp)
         mask.save(mp)
@@ -118,13 +121,14 @@ def test_batch_driver_matches_single_image_calls(env, tmp_path):
     os.makedirs(out_dir)
     calls = []
     real_call = pipe.__class__.__call__
-    pipe.__class__.__call__ = lambda self, *a, **k: (calls.append(len(k["image"]) if isinstance(k.get("image"), list) else 1), real_call(self, *a, **k))[1]
+    count = lambda im: (len(im), "pil") if isinstance(im, list) else (im.shape[0], "device") if isinstance(im, torch.Tensor) and im.dtype == torch.uint8 else (1, "pil")
+    pipe.__class__.__call__ = lambda self, *a, **k: (calls.append(count(k.get("image"))), real_call(self, *a, **k))[1]
     try:
         res = batch_driver.run_items(items, pipe, str(out_dir), batch_size=2, num_inference_steps=3, guidance_scale=30.0, seed=42)
     finally:
         pipe.__class__.__call__ = real_call
-    assert res["all_done"] == [0, 1, 2] and calls == [2, 1]
-    for i in range(3):
+    assert res["all_done"] == [0, 1, 2, 3] and calls == [(2, "pil"), (1, "pil"), (1, "device")]
+    for i in range(4):
         got = np.asarray(Image.open(out_dir / f"{i:06d}.png")).astype(np.float32)
         assert got.shape == singles[i].shape
         d = np.abs(got - singles[i]).mean() / 255.0

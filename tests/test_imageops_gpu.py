@@ -149,3 +149,57 @@ def test_transpose_and_row_softmax(ops):
         got = ops.row_softmax(s.cuda(), 0.0442, out).float().cpu()
         assert (got[:, :N] - ref).abs().max().item() <= 2 ** -8 * ref.max().item() + 1e-7
         assert torch.count_nonzero(got[:, N:]).item() == 0 and abs(got.sum(-1) - 1).max().item() < 5e-3
+
+
+def test_compose_canvas_is_the_host_stacking_bit_for_bit():
+    """tfx_compose_canvas against the host composition of the reference's callers: numpy stacking of glyph + scene, a black
+    mask over the glyph part, PIL's convert("L") of the RGB mask (random grey-ish RGB values, not only black / white)."""
+    import numpy as np
+    from PIL import Image
+    from textflux_amd import ops
+    rng = np.random.default_rng(3)
+    for horizontal, (gh, gw, sh, sw) in ((False, (40, 96, 64, 96)), (True, (64, 48, 64, 80))):
+        B = 3
+        g = rng.integers(0, 256, (B, gh, gw, 3), dtype=np.uint8)
+        s = rng.integers(0, 256, (B, sh, sw, 3), dtype=np.uint8)
+        m = rng.integers(0, 256, (B, sh, sw, 3), dtype=np.uint8)
+        canvas, cmask = ops.compose_canvas(torch.from_numpy(g).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(m).cuda(), horizontal)
+        stack = np.hstack if horizontal else np.vstack
+        for b in range(B):
+            ref_img = stack((g[b], s[b]))
+            ref_mask = np.array(Image.fromarray(stack((np.zeros_like(g[b]), m[b]))).convert("L"))
+            assert np.array_equal(canvas[b].cpu().numpy(), ref_img)
+            assert np.array_equal(cmask[b].cpu().numpy(), ref_mask)
+
+
+def test_pipeline_conditioning_from_a_device_canvas_equals_the_pil_path():
+    """FluxFillPipeline._encode_conditioning fed with the device-composed uint8 canvas gives bit-identical conditioning
+    latents to the PIL inputs the reference's callers build on the host."""
+    import numpy as np
+    from PIL import Image
+    from textflux_amd import ops
+    from textflux_amd.pipeline import FluxFillPipeline
+    from textflux_amd.vae import AutoencoderKL
+    from textflux_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    vae = AutoencoderKL(block_out_channels=(64, 64, 128, 128), layers_per_block=1, latent_channels=16, norm_num_groups=16).init_random_(seed=2, device="cuda")
+    pipe = FluxFillPipeline(scheduler=FlowMatchEulerDiscreteScheduler(), vae=vae, text_encoder=None, tokenizer=None, text_encoder_2=None,
+                            tokenizer_2=None, transformer=None)
+    pipe._device = torch.device("cuda")
+    rng = np.random.default_rng(4)
+    B, gh, sh, W = 2, 32, 96, 64
+    g = rng.integers(0, 256, (B, gh, W, 3), dtype=np.uint8)
+    s = rng.integers(0, 256, (B, sh, W, 3), dtype=np.uint8)
+    m = np.zeros((B, sh, W, 3), np.uint8)
+    m[:, 20:60, 8:40] = 255
+    m[:, 70:80, 10:50] = rng.integers(0, 256, (B, 10, 40, 3), dtype=np.uint8)        # grey values around the binarisation threshold
+    pil_i = [Image.fromarray(np.vstack((g[b], s[b]))) for b in range(B)]
+    pil_m = [Image.fromarray(np.vstack((np.zeros_like(g[b]), m[b]))) for b in range(B)]
+    canvas, cmask = ops.compose_canvas(torch.from_numpy(g).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(m).cuda(), False)
+    H = gh + sh
+    outs = []
+    for img, msk in ((pil_i, pil_m), (canvas, cmask)):
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        cond, h, w = pipe._encode_conditioning(img, msk, H, W, B, 1, torch.bfloat16, "cuda", gen)
+        assert (h, w) == (H, W)
+        outs.append(cond)
+    assert torch.equal(outs[0], outs[1])

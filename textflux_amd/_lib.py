@@ -123,6 +123,8 @@ SIGNATURES = {
     "tfx_any_negative": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "tfx_prep_image": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                c_int32, c_int32, c_void_p, c_void_p]),
+    "tfx_compose_canvas": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                   c_int32, c_void_p]),
     "tfx_pack_mask": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
                               c_void_p]),
     "tfx_vae_sample_pack": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,

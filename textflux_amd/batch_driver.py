@@ -4,8 +4,10 @@ Counterpart of the reference's scripts/run_eval.py:76-247.  The reference starts
 holds a full replica (incl. the 9.5 GB T5 encoder), pulls ONE item at a time from a multiprocessing queue, encodes its own
 prompts and calls the pipeline at batch 1.  Here (one process per GPU, launched by torchrun / `--gpus N`):
 
-* items are composed on the host (glyph strip / multi-line render, concat, /32 resize: the reference's own steps) and
-  grouped by pipeline geometry into batches of up to `batch_size` -- the engine's batch-8 rate is 13 % above its batch-1
+* the glyph image of every item is rendered on the host (font rasteriser); the canvas -- glyph and scene stacked, black mask
+  over the glyph part, grey value of the RGB mask -- is composed ON THE DEVICE for a whole batch at once
+  (`ops.compose_canvas`) whenever the stacked size already is a multiple of 32 (otherwise the reference's PIL resize
+  runs on the host first); items are grouped by pipeline geometry into batches of up to `batch_size` -- the engine's batch-8 rate is 13 % above its batch-1
   rate, and the captured step graph is reused across batches of one geometry;
 * batches are dealt round-robin to the ranks; in each round rank 0 encodes the T5 prompts of ALL ranks' batches (the CLIP
   prompt is the one fixed template: encoded once, broadcast once) and scatters them -- 4 MiB per prompt over xGMI against
@@ -32,11 +34,12 @@ from . import glyph
 @dataclass
 class Work:
     index: int                       # position in the item list
-    image: Any                       # composed PIL image at pipeline size
+    image: Any                       # composed PIL image at pipeline size (None when `parts` is set)
     mask: Any
     prompt: str                      # T5 prompt (generate_prompt(words))
     meta: Dict[str, Any]
     size: Tuple[int, int]            # (width, height) given to the pipeline
+    parts: Any = None                # (glyph, scene, mask uint8 arrays, horizontal): composed on the device per batch
 
 
 @dataclass
@@ -45,15 +48,45 @@ class Batch:
     items: List[Work] = field(default_factory=list)
 
 
-def prepare_item(index: int, item: Dict[str, Any], loader: Optional[Callable] = None) -> Work:
-    """Host-side composition of one item (run_inference.py:395-467 up to the pipeline call)."""
+def prepare_item(index: int, item: Dict[str, Any], loader: Optional[Callable] = None, device_compose: bool = False) -> Work:
+    """Host-side preparation of one item (run_inference.py:395-467 up to the pipeline call).  With device_compose the
+    stacking is left to the device when no resize is involved."""
     from PIL import Image
     load = loader or (lambda p: Image.open(p))
     scene, mask = load(item["image"]).convert("RGB"), load(item["mask"]).convert("RGB")
     words = glyph.read_words_from_text(item["text"])
-    combined, cmask, meta = glyph.compose(scene, mask, words)
-    w, h = glyph.pipe_size(combined)
-    return Work(index, combined.resize((w, h)), cmask.resize((w, h)), glyph.generate_prompt(words), meta, (w, h))
+    g, s_, m, horizontal, meta = glyph.compose_parts(scene, mask, words)
+    H, W = (s_.shape[0], g.shape[1] + s_.shape[1]) if horizontal else (g.shape[0] + s_.shape[0], s_.shape[1])
+    w, h = (W // 32) * 32, (H // 32) * 32
+    prompt = glyph.generate_prompt(words)
+    if device_compose and (w, h) == (W, H):
+        return Work(index, None, None, prompt, meta, (w, h), parts=(g, s_, m, horizontal))
+    import numpy as np
+    stack = np.hstack if horizontal else np.vstack
+    combined, cmask = Image.fromarray(stack((g, s_))), Image.fromarray(stack((np.zeros_like(g), m)))
+    return Work(index, combined.resize((w, h)), cmask.resize((w, h)), prompt, meta, (w, h))
+
+
+def _batch_inputs(items: Sequence[Work], device):
+    """(image, mask_image) arguments of the pipeline call for one batch: device-composed uint8 canvases when every item of
+    the batch brought its parts and they agree in shape, else the PIL lists."""
+    import numpy as np
+    from . import ops
+    if all(w.parts is not None for w in items):
+        shapes = {(w.parts[0].shape, w.parts[1].shape, w.parts[3]) for w in items}
+        if len(shapes) == 1:
+            up = lambda k: torch.from_numpy(np.stack([w.parts[k] for w in items])).to(device)
+            return ops.compose_canvas(up(0), up(1), up(2), horizontal=items[0].parts[3])
+    from PIL import Image
+    imgs, masks = [], []
+    for w in items:
+        if w.parts is None:
+            imgs.append(w.image), masks.append(w.mask)
+        else:
+            g, s_, m, horizontal = w.parts
+            stack = np.hstack if horizontal else np.vstack
+            imgs.append(Image.fromarray(stack((g, s_)))), masks.append(Image.fromarray(stack((np.zeros_like(g), m))))
+    return imgs, masks
 
 
 def plan_batches(works: Sequence[Work], batch_size: int) -> List[Batch]:
@@ -90,7 +123,7 @@ def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], bat
     works, failed = [], []
     for i, it in enumerate(items):
         try:
-            works.append(prepare_item(i, it, loader))
+            works.append(prepare_item(i, it, loader, device_compose=bool(getattr(pipe, "supports_device_compose", False))))
         except Exception as e:       # per-item failures do not stop the run (reference :195-198)
             failed.append(i)
             if rank == 0:
@@ -140,8 +173,9 @@ def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], bat
             boxes = [glyph.crop_box(w.size, w.meta) for w in mine.items]
             same_box = all(bx == boxes[0] for bx in boxes)      # one crop window for the whole batch: applied on the device
             kw = dict(output_crop=boxes[0]) if same_box and getattr(pipe, "supports_output_crop", False) else {}
-            images = pipe(height=mine.size[1], width=mine.size[0], image=[w.image for w in mine.items],
-                          mask_image=[w.mask for w in mine.items], num_inference_steps=num_inference_steps, generator=gens,
+            img_in, mask_in = _batch_inputs(mine.items, device)
+            images = pipe(height=mine.size[1], width=mine.size[0], image=img_in,
+                          mask_image=mask_in, num_inference_steps=num_inference_steps, generator=gens,
                           max_sequence_length=max_sequence_length, guidance_scale=guidance_scale,
                           prompt_embeds=pe_mine[:n], pooled_prompt_embeds=pooled1.expand(n, -1).contiguous(), **kw).images
             for w, img, bx in zip(mine.items, images, boxes):

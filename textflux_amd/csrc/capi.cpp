@@ -385,6 +385,11 @@ int tfx_prep_image(const void* img, int32_t img_dtype, const void* mask, int32_t
   if (!img || !out) return fail("tfx_prep_image: null pointer");
   return prep_image(img, img_dtype, mask, mask_dtype, out, B, C, H, W, mask_batch, norm_mode, binarize, neg_flag, S(stream));
 }
+int tfx_compose_canvas(const void* glyph, const void* scene, const void* scene_mask_rgb, void* canvas, void* cmask, int32_t B,
+                       int32_t gh, int32_t gw, int32_t sh, int32_t sw, int32_t direction, tfx_stream stream) {
+  if (!glyph || !scene || !scene_mask_rgb || !canvas || !cmask) return fail("tfx_compose_canvas: null pointer");
+  return compose_canvas(glyph, scene, scene_mask_rgb, canvas, cmask, B, gh, gw, sh, sw, direction, S(stream));
+}
 int tfx_pack_mask(const void* mask, int32_t mask_dtype, void* out, int32_t B, int32_t H, int32_t W, int32_t mask_batch,
                   int32_t binarize, int64_t ld, int32_t col0, tfx_stream stream) {
   if (!mask || !out) return fail("tfx_pack_mask: null pointer");

@@ -294,6 +294,48 @@ int prep_image(const void* img, int img_dtype, const void* mask, int mask_dtype,
   return check_launch("prep_image");
 }
 
+// Composition of the pipeline's input canvas out of its parts (reference: run_inference.py:409-467 -- the rendered glyph
+// image and the scene are stacked, glyph first, the glyph part of the mask is black -- and PIL's convert("L") of the RGB mask
+// in VaeImageProcessor.preprocess): canvas [B, H, W, 3] u8, cmask [B, H, W] u8 from glyph [B, gh, gw, 3], scene [B, sh, sw, 3]
+// and the scene's RGB mask [B, sh, sw, 3], all u8 interleaved.  dir 0: vertical (H = gh + sh, W = gw = sw), 1: horizontal.
+// The grey value is Pillow's integer formula (L24 = 19595 R + 38470 G + 7471 B + 0x8000) >> 16, bit for bit.
+__global__ __launch_bounds__(256) void compose_canvas_kernel(const uint8_t* __restrict__ glyph, const uint8_t* __restrict__ scene,
+                                                             const uint8_t* __restrict__ smask, uint8_t* __restrict__ canvas,
+                                                             uint8_t* __restrict__ cmask, int B, int gh, int gw, int sh, int sw,
+                                                             int dir) {
+  const int H = dir ? sh : gh + sh, W = dir ? gw + sw : sw;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * H * W) return;
+  const int x = (int)(i % W);
+  const int64_t by = i / W;
+  const int y = (int)(by % H), b = (int)(by / H);
+  const bool in_glyph = dir ? x < gw : y < gh;
+  uint8_t r, g, bl, m = 0;
+  if (in_glyph) {
+    const uint8_t* p = glyph + (((int64_t)b * gh + y) * gw + x) * 3;
+    r = p[0]; g = p[1]; bl = p[2];
+  } else {
+    const int sy = dir ? y : y - gh, sx = dir ? x - gw : x;
+    const int64_t o = (((int64_t)b * sh + sy) * sw + sx) * 3;
+    r = scene[o]; g = scene[o + 1]; bl = scene[o + 2];
+    m = (uint8_t)((19595u * smask[o] + 38470u * smask[o + 1] + 7471u * smask[o + 2] + 0x8000u) >> 16);
+  }
+  uint8_t* c = canvas + i * 3;
+  c[0] = r; c[1] = g; c[2] = bl;
+  cmask[i] = m;
+}
+
+int compose_canvas(const void* glyph, const void* scene, const void* smask, void* canvas, void* cmask, int B, int gh, int gw, int sh,
+                   int sw, int dir, hipStream_t st) {
+  if (dir != 0 && dir != 1) return fail("compose_canvas: direction 0 (vertical) or 1 (horizontal)");
+  if (dir == 0 ? gw != sw : gh != sh) return fail("compose_canvas: glyph and scene must share the side they are stacked along");
+  const int64_t n = (int64_t)B * (dir ? sh : gh + sh) * (dir ? gw + sw : sw);
+  if (n <= 0) return 0;
+  compose_canvas_kernel<<<blocks_for(n), 256, 0, st>>>((const uint8_t*)glyph, (const uint8_t*)scene, (const uint8_t*)smask,
+                                                       (uint8_t*)canvas, (uint8_t*)cmask, B, gh, gw, sh, sw, dir);
+  return check_launch("compose_canvas");
+}
+
 int pack_mask(const void* mask, int mask_dtype, void* out, int B, int H, int W, int mask_b, int binarize, int64_t ld, int col0,
               hipStream_t st) {
   if (H % 16 || W % 16) return fail("pack_mask: H and W must be multiples of 16");

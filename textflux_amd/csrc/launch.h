@@ -108,6 +108,8 @@ int copy_rows(const void* src, int64_t sld, int64_t sbs, void* dst, int64_t dld,
 int any_negative(const void* x, int dtype, int64_t n, int* flag, hipStream_t st);
 int prep_image(const void* img, int img_dtype, const void* mask, int mask_dtype, void* out, int B, int C, int H, int W,
                int mask_b, int norm_mode, int binarize, const int* neg_flag, hipStream_t st);
+int compose_canvas(const void* glyph, const void* scene, const void* smask, void* canvas, void* cmask, int B, int gh, int gw, int sh,
+                   int sw, int dir, hipStream_t st);
 int pack_mask(const void* mask, int mask_dtype, void* out, int B, int H, int W, int mask_b, int binarize, int64_t ld, int col0,
               hipStream_t st);
 int sample_pack(const void* moments, const void* eps, int eps_dtype, void* out, int B, int h, int w, int L, float shift,

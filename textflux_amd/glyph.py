@@ -242,21 +242,26 @@ def choose_concat_direction(height: int, width: int) -> str:
     return "horizontal" if height > width else "vertical"
 
 
-def compose(scene: Image.Image, mask: Image.Image, words: Sequence[str], font_path: Optional[str] = None):
-    """-> (combined image, combined mask, meta).  Glyph image goes first (top / left); its mask is black."""
+def compose_parts(scene: Image.Image, mask: Image.Image, words: Sequence[str], font_path: Optional[str] = None):
+    """-> (glyph, scene, mask as uint8 [h, w, 3] arrays, horizontal, meta): what `compose` stacks.  The rendering of the glyph
+    image is the only step that needs the host (font rasteriser); the stacking itself can run on the device
+    (ops.compose_canvas / tfx_compose_canvas)."""
     scene, mask = scene.convert("RGB"), mask.convert("RGB")
     if len(words) > 1:
         glyph = render_multiline(scene, mask, words, font_path)
         direction = choose_concat_direction(scene.size[1], scene.size[0])
-        stack = np.hstack if direction == "horizontal" else np.vstack
         meta = dict(mode="multiline", direction=direction)
     else:
         glyph, strip_h = render_single_line(scene, words, font_path)
-        stack, meta = np.vstack, dict(mode="singleline", direction="vertical", strip=strip_h, orig_h=scene.size[1])
-    black = Image.new("RGB", glyph.size, "black")
-    image = Image.fromarray(stack((np.array(glyph), np.array(scene))))
-    cmask = Image.fromarray(stack((np.array(black), np.array(mask))))
-    return image, cmask, meta
+        direction, meta = "vertical", dict(mode="singleline", direction="vertical", strip=strip_h, orig_h=scene.size[1])
+    return np.array(glyph.convert("RGB")), np.array(scene), np.array(mask), direction == "horizontal", meta
+
+
+def compose(scene: Image.Image, mask: Image.Image, words: Sequence[str], font_path: Optional[str] = None):
+    """-> (combined image, combined mask, meta).  Glyph image goes first (top / left); its mask is black."""
+    g, s, m, horizontal, meta = compose_parts(scene, mask, words, font_path)
+    stack = np.hstack if horizontal else np.vstack
+    return Image.fromarray(stack((g, s))), Image.fromarray(stack((np.zeros_like(g), m))), meta
 
 
 def pipe_size(image: Image.Image) -> Tuple[int, int]:

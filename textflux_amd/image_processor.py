@@ -66,6 +66,15 @@ class VaeImageProcessor:
         """Same input handling as `preprocess` (formats, lists, resize, RGB / grayscale conversion) WITHOUT the arithmetic:
         returns uint8 [B, H, W, C] ([B, H, W] for grayscale) for PIL inputs, float32 [B, C, H, W] for numpy / torch
         inputs.  Normalisation / binarisation are left to the device kernels."""
+        if isinstance(image, torch.Tensor) and image.dtype == torch.uint8:
+            # already-decoded pixels, the layout the PIL branch below produces ([B, H, W, 3], or [B, H, W] for a grey mask) --
+            # e.g. a canvas composed on the device (ops.compose_canvas); no resize on this path
+            want = 3 if self.do_convert_grayscale else 4
+            if image.ndim != want or (want == 4 and image.shape[-1] != 3):
+                raise ValueError(f"uint8 tensor input must be [B, H, W{', 3' if want == 4 else ''}], got {tuple(image.shape)}")
+            if height is not None and width is not None and tuple(image.shape[1:3]) != (height, width):
+                raise ValueError(f"uint8 tensor input is {tuple(image.shape[1:3])}, the call asks for {(height, width)}: resize before composing")
+            return image
         if self.do_convert_grayscale and isinstance(image, (torch.Tensor, np.ndarray)) and image.ndim == 3:
             if isinstance(image, torch.Tensor):
                 image = image.unsqueeze(1)

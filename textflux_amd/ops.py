@@ -369,6 +369,23 @@ def prep_image(img: torch.Tensor, mask: Optional[torch.Tensor] = None, norm_mode
     return out
 
 
+def compose_canvas(glyph: torch.Tensor, scene: torch.Tensor, scene_mask_rgb: torch.Tensor, horizontal: bool = False):
+    """uint8 [B, gh, gw, 3] glyph images + [B, sh, sw, 3] scenes + the scenes' RGB masks -> (canvas [B, H, W, 3] u8, mask
+    [B, H, W] u8): glyph first (top / left), its mask black, PIL's "L" of the RGB mask elsewhere."""
+    _chk_dev(glyph, scene, scene_mask_rgb)
+    for t in (glyph, scene, scene_mask_rgb):
+        assert t.dtype == torch.uint8 and t.dim() == 4 and t.shape[-1] == 3 and t.is_contiguous()
+    B, gh, gw, _ = glyph.shape
+    _, sh, sw, _ = scene.shape
+    assert scene.shape[0] == B and scene_mask_rgb.shape == scene.shape
+    H, W = (sh, gw + sw) if horizontal else (gh + sh, sw)
+    canvas = torch.empty(B, H, W, 3, dtype=torch.uint8, device=glyph.device)
+    cmask = torch.empty(B, H, W, dtype=torch.uint8, device=glyph.device)
+    L.check(L.lib().tfx_compose_canvas(glyph.data_ptr(), scene.data_ptr(), scene_mask_rgb.data_ptr(), canvas.data_ptr(),
+                                       cmask.data_ptr(), B, gh, gw, sh, sw, 1 if horizontal else 0, _stream()), "compose_canvas")
+    return canvas, cmask
+
+
 def pack_mask(mask: torch.Tensor, out: torch.Tensor, col0: int, B: int, H: int, W: int, binarize: bool = True) -> torch.Tensor:
     """out[b, :, col0 : col0 + 256] = packed mask (out: [B, S, ld] bf16)."""
     _chk_dev(mask, out)

@@ -95,6 +95,7 @@ class _NullBar:
 class FluxFillPipeline:
     _callback_tensor_inputs = ["latents", "prompt_embeds"]
     supports_output_crop = True
+    supports_device_compose = True   # image / mask_image may be uint8 device tensors [B, H, W, 3] / [B, H, W] (ops.compose_canvas)
     model_index_name = "model_index.json"
 
     def __init__(self, scheduler, vae, text_encoder, tokenizer, text_encoder_2, tokenizer_2,
