@@ -245,9 +245,22 @@ int tfx_prep_image(const void* img, int32_t img_dtype, const void* mask, int32_t
  * over the scene's mask; IP's do_convert_grayscale then takes PIL's "L" of the RGB mask): canvas [B, H, W, 3] u8 and
  * cmask [B, H, W] u8 from glyph [B, gh, gw, 3], scene [B, sh, sw, 3] and the scene's RGB mask [B, sh, sw, 3] (u8,
  * interleaved).  direction 0: vertical, H = gh + sh, W = gw = sw; 1: horizontal, W = gw + sw, H = gh = sh.  Grey value =
- * Pillow's (19595 R + 38470 G + 7471 B + 0x8000) >> 16.  The outputs feed tfx_prep_image (dtype 2) / tfx_pack_mask. */
+ * Pillow's (19595 R + 38470 G + 7471 B + 0x8000) >> 16.  mask_rgb != 0: cmask is [B, H, W, 3] and keeps the RGB values (a
+ * resize follows: the reference resizes the RGB mask, then takes "L").  The outputs feed tfx_prep_image (dtype 2) /
+ * tfx_pack_mask, directly or through tfx_resample_u8 + tfx_rgb_to_grey_u8. */
 int tfx_compose_canvas(const void* glyph, const void* scene, const void* scene_mask_rgb, void* canvas, void* cmask, int32_t B,
-                       int32_t gh, int32_t gw, int32_t sh, int32_t sw, int32_t direction, tfx_stream stream);
+                       int32_t gh, int32_t gw, int32_t sh, int32_t sw, int32_t direction, int32_t mask_rgb, tfx_stream stream);
+/* out [pixels] u8 = PIL convert("L") of interleaved RGB u8 [pixels][3]. */
+int tfx_rgb_to_grey_u8(const void* rgb, void* out, int64_t pixels, tfx_stream stream);
+/* One pass of Pillow's 8-bit convolution resampler (PIL.Image.resize of "RGB" / "L" images; the callers' resize to a multiple
+ * of 32, /root/reference/run_inference.py:65-69) along the middle axis of in [outer][in_len][inner] u8 -> out
+ * [outer][out_len][inner]: horizontal pass of [B, H, W, C]: outer = B H, len = W, inner = C; vertical pass: outer = B, len = H,
+ * inner = W C (Pillow runs the horizontal pass first; both round to u8).  bounds [out_len][2] = (first input index, count),
+ * coeffs [out_len][ksize] = the filter weights in fixed point with 22 fractional bits, computed on the host exactly as
+ * libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc do (textflux_amd/image_processor.py::pil_resample_tables);
+ * out = clip8((2^21 + sum in * k) >> 22): integer arithmetic, bit-identical to Pillow. */
+int tfx_resample_u8(const void* in, void* out, const int32_t* bounds, const int32_t* coeffs, int32_t ksize, int64_t outer,
+                    int32_t in_len, int32_t out_len, int32_t inner, tfx_stream stream);
 /* out[b, t, col0 + (i*8+j)*4 + py*2+px] = mask[(2ty+py)*8 + i, (2tx+px)*8 + j]  (P:1563-1580: 8x8 pixel blocks -> channels,
  * then _pack_latents), t = ty * (W/16) + tx, row stride ld. */
 int tfx_pack_mask(const void* mask, int32_t mask_dtype, void* out, int32_t B, int32_t H, int32_t W, int32_t mask_batch,

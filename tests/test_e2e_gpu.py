@@ -105,8 +105,8 @@ def test_batch_driver_matches_single_image_calls(env, tmp_path):
     ri.PIPE = None
     pipe = ri.load_flux_pipeline()
     items, singles = [], []
-    # the fourth scene's height makes glyph strip + scene a multiple of 32: no resize, the canvas is composed on the device
-    # (a geometry of its own: batches are formed per pipeline size)
+    # every canvas is composed on the device; the first three need the callers' resize 168 -> 160 (Pillow bicubic on the
+    # device), the fourth (a geometry of its own: batches are formed per pipeline size) is a multiple of 32 already
     h_dev = 160 - int(320 * glyph.TEXT_HEIGHT_RATIO)
     for i, word in enumerate(["ALPHA", "BETA", "GAMMA", "DELTA"]):
         scene, mask = _scene(10 + i) if i < 3 else _scene(10 + i, 320, h_dev)
@@ -127,7 +127,7 @@ def test_batch_driver_matches_single_image_calls(env, tmp_path):
         res = batch_driver.run_items(items, pipe, str(out_dir), batch_size=2, num_inference_steps=3, guidance_scale=30.0, seed=42)
     finally:
         pipe.__class__.__call__ = real_call
-    assert res["all_done"] == [0, 1, 2, 3] and calls == [(2, "pil"), (1, "pil"), (1, "device")]
+    assert res["all_done"] == [0, 1, 2, 3] and calls == [(2, "device"), (1, "device"), (1, "device")]
     for i in range(4):
         got = np.asarray(Image.open(out_dir / f"{i:06d}.png")).astype(np.float32)
         assert got.shape == singles[i].shape

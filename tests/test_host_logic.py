@@ -202,3 +202,31 @@ def test_encode_prompt_with_tiny_text_encoders():
     p.text_encoder = None
     with pytest.raises(ValueError):
         p.encode_prompt(prompt="a", prompt_2=None, device="cpu")
+
+
+def test_pil_resample_tables_reproduce_pillow_bicubic():
+    """image_processor.pil_resample_tables + the two integer passes tfx_resample_u8 runs (restated in numpy) == PIL.Image.resize,
+    bit for bit: the host half of the device-side resize of the batch driver."""
+    import numpy as np
+    from PIL import Image
+    from textflux_amd.image_processor import pil_resample_tables
+
+    def one_pass(a, bounds, kk, axis):
+        a = np.moveaxis(a, axis, 0).astype(np.int64)
+        out = np.empty((len(bounds),) + a.shape[1:], np.int64)
+        for xx, (xmin, xmax) in enumerate(bounds):
+            ss = np.full(a.shape[1:], 1 << 21, np.int64)
+            for x in range(xmax):
+                ss += a[xmin + x] * int(kk[xx, x])
+            out[xx] = np.clip(ss >> 22, 0, 255)
+        return np.moveaxis(out, 0, axis).astype(np.uint8)
+
+    rng = np.random.default_rng(1)
+    for (h, w, ho, wo) in [(168, 256, 160, 256), (74, 100, 64, 96), (50, 60, 64, 64)]:
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        x = a
+        if wo != w:
+            x = one_pass(x, *pil_resample_tables(w, wo), axis=1)
+        if ho != h:
+            x = one_pass(x, *pil_resample_tables(h, ho), axis=0)
+        assert np.array_equal(x, np.array(Image.fromarray(a).resize((wo, ho))))

@@ -203,3 +203,20 @@ def test_pipeline_conditioning_from_a_device_canvas_equals_the_pil_path():
         assert (h, w) == (H, W)
         outs.append(cond)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("h,w,ho,wo", [(168, 256, 160, 256), (592, 512, 576, 512), (200, 330, 192, 320), (100, 90, 128, 96), (77, 131, 64, 160)])
+def test_resample_u8_is_pillow_bicubic_bit_for_bit(h, w, ho, wo):
+    """tfx_resample_u8 with the host-built coefficient tables against PIL.Image.resize (default filter), RGB and grey, down-
+    and up-scaling on either axis."""
+    import numpy as np
+    from PIL import Image
+    from textflux_amd import ops
+    rng = np.random.default_rng(h * 1000 + w)
+    a = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    got = ops.resample_u8(torch.from_numpy(a).cuda(), (ho, wo)).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(got[b], np.array(Image.fromarray(a[b]).resize((wo, ho))))
+    grey = ops.rgb_to_grey(torch.from_numpy(a).cuda()).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(grey[b], np.array(Image.fromarray(a[b]).convert("L")))

@@ -124,7 +124,9 @@ SIGNATURES = {
     "tfx_prep_image": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                c_int32, c_int32, c_void_p, c_void_p]),
     "tfx_compose_canvas": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                   c_int32, c_void_p]),
+                                   c_int32, c_int32, c_void_p]),
+    "tfx_rgb_to_grey_u8": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "tfx_resample_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "tfx_pack_mask": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
                               c_void_p]),
     "tfx_vae_sample_pack": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,

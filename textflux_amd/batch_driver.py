@@ -6,8 +6,8 @@ prompts and calls the pipeline at batch 1.  Here (one process per GPU, launched 
 
 * the glyph image of every item is rendered on the host (font rasteriser); the canvas -- glyph and scene stacked, black mask
   over the glyph part, grey value of the RGB mask -- is composed ON THE DEVICE for a whole batch at once
-  (`ops.compose_canvas`) whenever the stacked size already is a multiple of 32 (otherwise the reference's PIL resize
-  runs on the host first); items are grouped by pipeline geometry into batches of up to `batch_size` -- the engine's batch-8 rate is 13 % above its batch-1
+  (`ops.compose_canvas`), including the callers' resize to a multiple of 32 (`ops.resample_u8`: Pillow's bicubic resampler
+  in its own fixed-point arithmetic, bit-identical); items are grouped by pipeline geometry into batches of up to `batch_size` -- the engine's batch-8 rate is 13 % above its batch-1
   rate, and the captured step graph is reused across batches of one geometry;
 * batches are dealt round-robin to the ranks; in each round rank 0 encodes the T5 prompts of ALL ranks' batches (the CLIP
   prompt is the one fixed template: encoded once, broadcast once) and scatters them -- 4 MiB per prompt over xGMI against
@@ -59,7 +59,7 @@ def prepare_item(index: int, item: Dict[str, Any], loader: Optional[Callable] = 
     H, W = (s_.shape[0], g.shape[1] + s_.shape[1]) if horizontal else (g.shape[0] + s_.shape[0], s_.shape[1])
     w, h = (W // 32) * 32, (H // 32) * 32
     prompt = glyph.generate_prompt(words)
-    if device_compose and (w, h) == (W, H):
+    if device_compose:               # stacking, the resize to (w, h) and the grey mask happen on the device, per batch
         return Work(index, None, None, prompt, meta, (w, h), parts=(g, s_, m, horizontal))
     import numpy as np
     stack = np.hstack if horizontal else np.vstack
@@ -76,7 +76,11 @@ def _batch_inputs(items: Sequence[Work], device):
         shapes = {(w.parts[0].shape, w.parts[1].shape, w.parts[3]) for w in items}
         if len(shapes) == 1:
             up = lambda k: torch.from_numpy(np.stack([w.parts[k] for w in items])).to(device)
-            return ops.compose_canvas(up(0), up(1), up(2), horizontal=items[0].parts[3])
+            wh = items[0].size
+            canvas, cmask = ops.compose_canvas(up(0), up(1), up(2), horizontal=items[0].parts[3], mask_rgb=True)
+            if (canvas.shape[2], canvas.shape[1]) != wh:     # the callers' resize to a multiple of 32 (PIL bicubic, bit-exact)
+                canvas, cmask = ops.resample_u8(canvas, (wh[1], wh[0])), ops.resample_u8(cmask, (wh[1], wh[0]))
+            return canvas, ops.rgb_to_grey(cmask)
     from PIL import Image
     imgs, masks = [], []
     for w in items:
@@ -85,7 +89,8 @@ def _batch_inputs(items: Sequence[Work], device):
         else:
             g, s_, m, horizontal = w.parts
             stack = np.hstack if horizontal else np.vstack
-            imgs.append(Image.fromarray(stack((g, s_)))), masks.append(Image.fromarray(stack((np.zeros_like(g), m))))
+            imgs.append(Image.fromarray(stack((g, s_))).resize(w.size))
+            masks.append(Image.fromarray(stack((np.zeros_like(g), m))).resize(w.size))
     return imgs, masks
 
 

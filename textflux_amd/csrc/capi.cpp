@@ -386,9 +386,18 @@ int tfx_prep_image(const void* img, int32_t img_dtype, const void* mask, int32_t
   return prep_image(img, img_dtype, mask, mask_dtype, out, B, C, H, W, mask_batch, norm_mode, binarize, neg_flag, S(stream));
 }
 int tfx_compose_canvas(const void* glyph, const void* scene, const void* scene_mask_rgb, void* canvas, void* cmask, int32_t B,
-                       int32_t gh, int32_t gw, int32_t sh, int32_t sw, int32_t direction, tfx_stream stream) {
+                       int32_t gh, int32_t gw, int32_t sh, int32_t sw, int32_t direction, int32_t mask_rgb, tfx_stream stream) {
   if (!glyph || !scene || !scene_mask_rgb || !canvas || !cmask) return fail("tfx_compose_canvas: null pointer");
-  return compose_canvas(glyph, scene, scene_mask_rgb, canvas, cmask, B, gh, gw, sh, sw, direction, S(stream));
+  return compose_canvas(glyph, scene, scene_mask_rgb, canvas, cmask, B, gh, gw, sh, sw, direction, mask_rgb, S(stream));
+}
+int tfx_rgb_to_grey_u8(const void* rgb, void* out, int64_t pixels, tfx_stream stream) {
+  if (!rgb || !out) return fail("tfx_rgb_to_grey_u8: null pointer");
+  return rgb_to_grey(rgb, out, pixels, S(stream));
+}
+int tfx_resample_u8(const void* in, void* out, const int32_t* bounds, const int32_t* coeffs, int32_t ksize, int64_t outer,
+                    int32_t in_len, int32_t out_len, int32_t inner, tfx_stream stream) {
+  if (!in || !out || !bounds || !coeffs) return fail("tfx_resample_u8: null pointer");
+  return resample_u8(in, out, bounds, coeffs, ksize, outer, in_len, out_len, inner, S(stream));
 }
 int tfx_pack_mask(const void* mask, int32_t mask_dtype, void* out, int32_t B, int32_t H, int32_t W, int32_t mask_batch,
                   int32_t binarize, int64_t ld, int32_t col0, tfx_stream stream) {

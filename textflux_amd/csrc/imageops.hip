@@ -302,7 +302,7 @@ int prep_image(const void* img, int img_dtype, const void* mask, int mask_dtype,
 __global__ __launch_bounds__(256) void compose_canvas_kernel(const uint8_t* __restrict__ glyph, const uint8_t* __restrict__ scene,
                                                              const uint8_t* __restrict__ smask, uint8_t* __restrict__ canvas,
                                                              uint8_t* __restrict__ cmask, int B, int gh, int gw, int sh, int sw,
-                                                             int dir) {
+                                                             int dir, int mask_rgb) {
   const int H = dir ? sh : gh + sh, W = dir ? gw + sw : sw;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)B * H * W) return;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void compose_canvas_kernel(const uint8_t* __re
   const int64_t by = i / W;
   const int y = (int)(by % H), b = (int)(by / H);
   const bool in_glyph = dir ? x < gw : y < gh;
-  uint8_t r, g, bl, m = 0;
+  uint8_t r, g, bl, m0 = 0, m1 = 0, m2 = 0;
   if (in_glyph) {
     const uint8_t* p = glyph + (((int64_t)b * gh + y) * gw + x) * 3;
     r = p[0]; g = p[1]; bl = p[2];
@@ -318,22 +318,72 @@ __global__ __launch_bounds__(256) void compose_canvas_kernel(const uint8_t* __re
     const int sy = dir ? y : y - gh, sx = dir ? x - gw : x;
     const int64_t o = (((int64_t)b * sh + sy) * sw + sx) * 3;
     r = scene[o]; g = scene[o + 1]; bl = scene[o + 2];
-    m = (uint8_t)((19595u * smask[o] + 38470u * smask[o + 1] + 7471u * smask[o + 2] + 0x8000u) >> 16);
+    m0 = smask[o]; m1 = smask[o + 1]; m2 = smask[o + 2];
   }
   uint8_t* c = canvas + i * 3;
   c[0] = r; c[1] = g; c[2] = bl;
-  cmask[i] = m;
+  if (mask_rgb) {            // the mask stays RGB when a resize follows (the reference resizes the RGB mask, then takes "L")
+    uint8_t* mm = cmask + i * 3;
+    mm[0] = m0; mm[1] = m1; mm[2] = m2;
+  } else {
+    cmask[i] = (uint8_t)((19595u * m0 + 38470u * m1 + 7471u * m2 + 0x8000u) >> 16);
+  }
+}
+
+// PIL's convert("L") of interleaved RGB u8: (19595 R + 38470 G + 7471 B + 0x8000) >> 16.
+__global__ __launch_bounds__(256) void rgb_to_grey_kernel(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* p = rgb + i * 3;
+  out[i] = (uint8_t)((19595u * p[0] + 38470u * p[1] + 7471u * p[2] + 0x8000u) >> 16);
+}
+
+// One pass of Pillow's 8-bit convolution resampler (libImaging/Resample.c: ImagingResampleHorizontal_8bpc / Vertical_8bpc)
+// along the middle axis of in [outer][in_len][inner] -> out [outer][out_len][inner]: per output position xx the window
+// [bounds[2xx], + bounds[2xx+1]) and its ksize fixed-point coefficients (22 fractional bits, precomputed on the host exactly as
+// precompute_coeffs + normalize_coeffs_8bpc do), ss = 2^21 + sum in * k, out = clip8(ss >> 22).  Integer arithmetic: bit-exact.
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          const int* __restrict__ bounds, const int* __restrict__ coeffs, int ksize,
+                                                          int64_t outer, int in_len, int out_len, int inner) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= outer * out_len * inner) return;
+  const int e = (int)(i % inner);
+  const int64_t ox = i / inner;
+  const int xx = (int)(ox % out_len);
+  const int64_t o = ox / out_len;
+  const int xmin = bounds[2 * xx], xmax = bounds[2 * xx + 1];
+  const int* k = coeffs + (int64_t)xx * ksize;
+  const uint8_t* src = in + ((o * in_len + xmin) * inner + e);
+  int ss = 1 << 21;
+  for (int x = 0; x < xmax; ++x) ss += (int)src[(int64_t)x * inner] * k[x];
+  ss >>= 22;
+  out[i] = (uint8_t)(ss < 0 ? 0 : ss > 255 ? 255 : ss);
 }
 
 int compose_canvas(const void* glyph, const void* scene, const void* smask, void* canvas, void* cmask, int B, int gh, int gw, int sh,
-                   int sw, int dir, hipStream_t st) {
+                   int sw, int dir, int mask_rgb, hipStream_t st) {
   if (dir != 0 && dir != 1) return fail("compose_canvas: direction 0 (vertical) or 1 (horizontal)");
   if (dir == 0 ? gw != sw : gh != sh) return fail("compose_canvas: glyph and scene must share the side they are stacked along");
   const int64_t n = (int64_t)B * (dir ? sh : gh + sh) * (dir ? gw + sw : sw);
   if (n <= 0) return 0;
   compose_canvas_kernel<<<blocks_for(n), 256, 0, st>>>((const uint8_t*)glyph, (const uint8_t*)scene, (const uint8_t*)smask,
-                                                       (uint8_t*)canvas, (uint8_t*)cmask, B, gh, gw, sh, sw, dir);
+                                                       (uint8_t*)canvas, (uint8_t*)cmask, B, gh, gw, sh, sw, dir, mask_rgb);
   return check_launch("compose_canvas");
+}
+
+int rgb_to_grey(const void* rgb, void* out, int64_t n, hipStream_t st) {
+  if (n <= 0) return 0;
+  rgb_to_grey_kernel<<<blocks_for(n), 256, 0, st>>>((const uint8_t*)rgb, (uint8_t*)out, n);
+  return check_launch("rgb_to_grey");
+}
+
+int resample_u8(const void* in, void* out, const int* bounds, const int* coeffs, int ksize, int64_t outer, int in_len, int out_len,
+                int inner, hipStream_t st) {
+  if (ksize < 1 || in_len < 1 || out_len < 1 || inner < 1) return fail("resample_u8: bad geometry");
+  const int64_t n = outer * out_len * inner;
+  if (n <= 0) return 0;
+  resample_u8_kernel<<<blocks_for(n), 256, 0, st>>>((const uint8_t*)in, (uint8_t*)out, bounds, coeffs, ksize, outer, in_len, out_len, inner);
+  return check_launch("resample_u8");
 }
 
 int pack_mask(const void* mask, int mask_dtype, void* out, int B, int H, int W, int mask_b, int binarize, int64_t ld, int col0,

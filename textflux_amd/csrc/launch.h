@@ -109,7 +109,10 @@ int any_negative(const void* x, int dtype, int64_t n, int* flag, hipStream_t st)
 int prep_image(const void* img, int img_dtype, const void* mask, int mask_dtype, void* out, int B, int C, int H, int W,
                int mask_b, int norm_mode, int binarize, const int* neg_flag, hipStream_t st);
 int compose_canvas(const void* glyph, const void* scene, const void* smask, void* canvas, void* cmask, int B, int gh, int gw, int sh,
-                   int sw, int dir, hipStream_t st);
+                   int sw, int dir, int mask_rgb, hipStream_t st);
+int rgb_to_grey(const void* rgb, void* out, int64_t n, hipStream_t st);
+int resample_u8(const void* in, void* out, const int* bounds, const int* coeffs, int ksize, int64_t outer, int in_len, int out_len,
+                int inner, hipStream_t st);
 int pack_mask(const void* mask, int mask_dtype, void* out, int B, int H, int W, int mask_b, int binarize, int64_t ld, int col0,
               hipStream_t st);
 int sample_pack(const void* moments, const void* eps, int eps_dtype, void* out, int B, int h, int w, int L, float shift,

@@ -20,6 +20,45 @@ _RESAMPLE = {"lanczos": PIL.Image.LANCZOS, "bilinear": PIL.Image.BILINEAR, "bicu
              "nearest": PIL.Image.NEAREST}
 
 
+def pil_resample_tables(in_size: int, out_size: int):
+    """Window bounds [out, 2] and fixed-point coefficients [out, ksize] (int32, 22 fractional bits) of Pillow's BICUBIC
+    resampling of one axis from in_size to out_size -- libImaging/Resample.c: bicubic_filter (a = -0.5, support 2),
+    precompute_coeffs, normalize_coeffs_8bpc, evaluated in the same order in C doubles (= Python floats).  PIL.Image.resize's
+    default filter for "RGB" / "L" images; consumed by tfx_resample_u8."""
+    import math
+
+    def bicubic(x: float) -> float:
+        a = -0.5
+        x = -x if x < 0.0 else x
+        if x < 1.0:
+            return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+        if x < 2.0:
+            return (((x - 5) * x + 8) * x - 4) * a
+        return 0.0
+
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + k * (1 << 22)) if k < 0 else int(0.5 + k * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
 class VaeImageProcessor:
     def __init__(self, do_resize: bool = True, vae_scale_factor: int = 8, vae_latent_channels: int = 4,
                  resample: str = "lanczos", do_normalize: bool = True, do_binarize: bool = False,

@@ -369,9 +369,50 @@ def prep_image(img: torch.Tensor, mask: Optional[torch.Tensor] = None, norm_mode
     return out
 
 
-def compose_canvas(glyph: torch.Tensor, scene: torch.Tensor, scene_mask_rgb: torch.Tensor, horizontal: bool = False):
+_RESAMPLE_TABLES = {}
+
+
+def resample_u8(x: torch.Tensor, size) -> torch.Tensor:
+    """PIL.Image.resize((W, H)) (BICUBIC, the default) of uint8 [B, H, W, C] images on the device, bit-identical to Pillow:
+    horizontal pass, then vertical pass, each rounding to uint8 (tfx_resample_u8)."""
+    from .image_processor import pil_resample_tables
+    _chk_dev(x)
+    assert x.dtype == torch.uint8 and x.dim() == 4 and x.is_contiguous()
+    B, H, W, Cc = x.shape
+    Ho, Wo = size
+    for axis, (n_in, n_out) in ((2, (W, Wo)), (1, (H, Ho))):
+        if n_in == n_out:
+            continue
+        key = (n_in, n_out, str(x.device))
+        if key not in _RESAMPLE_TABLES:
+            b, k = pil_resample_tables(n_in, n_out)
+            _RESAMPLE_TABLES[key] = (torch.from_numpy(b).to(x.device), torch.from_numpy(k).to(x.device))
+        b, k = _RESAMPLE_TABLES[key]
+        Bc, Hc, Wc, _ = x.shape
+        if axis == 2:
+            out, outer, inner = torch.empty(Bc, Hc, n_out, Cc, dtype=torch.uint8, device=x.device), Bc * Hc, Cc
+        else:
+            out, outer, inner = torch.empty(Bc, n_out, Wc, Cc, dtype=torch.uint8, device=x.device), Bc, Wc * Cc
+        L.check(L.lib().tfx_resample_u8(x.data_ptr(), out.data_ptr(), b.data_ptr(), k.data_ptr(), k.shape[1], outer, n_in, n_out,
+                                        inner, _stream()), "resample_u8")
+        x = out
+    return x
+
+
+def rgb_to_grey(x: torch.Tensor) -> torch.Tensor:
+    """PIL convert("L") of uint8 [..., 3] -> uint8 [...]."""
+    _chk_dev(x)
+    assert x.dtype == torch.uint8 and x.shape[-1] == 3 and x.is_contiguous()
+    out = torch.empty(x.shape[:-1], dtype=torch.uint8, device=x.device)
+    L.check(L.lib().tfx_rgb_to_grey_u8(x.data_ptr(), out.data_ptr(), out.numel(), _stream()), "rgb_to_grey")
+    return out
+
+
+def compose_canvas(glyph: torch.Tensor, scene: torch.Tensor, scene_mask_rgb: torch.Tensor, horizontal: bool = False,
+                   mask_rgb: bool = False):
     """uint8 [B, gh, gw, 3] glyph images + [B, sh, sw, 3] scenes + the scenes' RGB masks -> (canvas [B, H, W, 3] u8, mask
-    [B, H, W] u8): glyph first (top / left), its mask black, PIL's "L" of the RGB mask elsewhere."""
+    [B, H, W] u8): glyph first (top / left), its mask black, PIL's "L" of the RGB mask elsewhere.  mask_rgb: the mask canvas
+    keeps its three channels ([B, H, W, 3]) for a resize before the grey conversion."""
     _chk_dev(glyph, scene, scene_mask_rgb)
     for t in (glyph, scene, scene_mask_rgb):
         assert t.dtype == torch.uint8 and t.dim() == 4 and t.shape[-1] == 3 and t.is_contiguous()
@@ -380,9 +421,10 @@ def compose_canvas(glyph: torch.Tensor, scene: torch.Tensor, scene_mask_rgb: tor
     assert scene.shape[0] == B and scene_mask_rgb.shape == scene.shape
     H, W = (sh, gw + sw) if horizontal else (gh + sh, sw)
     canvas = torch.empty(B, H, W, 3, dtype=torch.uint8, device=glyph.device)
-    cmask = torch.empty(B, H, W, dtype=torch.uint8, device=glyph.device)
+    cmask = torch.empty((B, H, W, 3) if mask_rgb else (B, H, W), dtype=torch.uint8, device=glyph.device)
     L.check(L.lib().tfx_compose_canvas(glyph.data_ptr(), scene.data_ptr(), scene_mask_rgb.data_ptr(), canvas.data_ptr(),
-                                       cmask.data_ptr(), B, gh, gw, sh, sw, 1 if horizontal else 0, _stream()), "compose_canvas")
+                                       cmask.data_ptr(), B, gh, gw, sh, sw, 1 if horizontal else 0, 1 if mask_rgb else 0,
+                                       _stream()), "compose_canvas")
     return canvas, cmask
 
 
