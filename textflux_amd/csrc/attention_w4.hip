@@ -254,14 +254,32 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   __syncthreads();
 #endif
   // ---- prologue: tiles 0 and 1 in LDS, tile 2 requested; K fragments of (tile 0, key block 0); S(0)
+  // Tiles 0 AND 1 are requested together (tile 1 into the sixteen registers of the K / V fragments, idle until the first
+  // fragment read) and the Q conversion runs under their flight: one memory round trip in front of the first MFMA, not three
   load_tile(0);
+  u32x4 k1[4], v1[4];
+  {
+    int ko, vo;
+    stage_offsets(ko, vo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      k1[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, ko, (W4_KV + 16 * i) * ldk2, 0));
+      v1[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, (W4_KV + 16 * i) * ldv2, 0));
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
-  convert_q();                     // under the flight of tile 0
+  convert_q();
   __builtin_amdgcn_sched_barrier(0);
   write_tile(0);
-  load_tile(1);
-  write_tile(1);
   load_tile(2);
+  {
+    const int kr = tid >> 4, ch = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(smem + W4_KBASE + W4_KT + kr * W4_KROW + ch * 16 + i * 16 * W4_KROW) = k1[i];
+      *reinterpret_cast<u32x4*>(smem + W4_VT + kr * 256 + ((((ch >> 2) ^ (kr & 3)) << 6) | ((ch & 3) << 4)) + i * 16 * 256) = v1[i];
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < 8; ++s) kf[s] = kread(0, s);
