@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   u32x4 kreg[4], vreg[4];
   // buffer descriptors sized to this head's N valid rows: a request past them (the rows of a ragged last tile, whole tiles
   // requested past the end of the sequence) returns zeros and moves nothing -- the scores of such keys are masked anyway,
-  // and their zero V rows meet zero weights
+  // and their zero V rows meet zero weights.  (The range check covers VGPR + SGPR offset: tools/ubench/buffer_range.hip.)
   const int ldk2 = (int)ldk * 2, ldv2 = (int)ldv * 2;
   const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)((uint32_t)(N - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
   const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((uint32_t)(N - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
