@@ -290,7 +290,13 @@ int tfx_row_softmax(const float* s, int64_t lds, void* p, int64_t ldp, int32_t r
 /* ---- text encoders of encode_prompt (P:1411-1503: CLIP-L pooled output of `prompt`, T5-XXL sequence of `prompt_2`).  The
  *      reference calls third-party `transformers` (pinned 4.43.3: models/t5/modeling_t5.py T5Stack / T5Block / T5Attention /
  *      T5LayerNorm / T5DenseGatedActDense; models/clip/modeling_clip.py CLIPTextTransformer / CLIPEncoderLayer / CLIPAttention /
- *      CLIPMLP); the Linear layers run on tfx_gemm_bf16 / tfx_gemm_bf16_f32, LayerNorm on tfx_ln_modulate, and: */
+ *      CLIPMLP); the Linear layers run on tfx_gemm_bf16 (residual adds in its epilogue: the bf16 residual stream of a
+ *      torch_dtype = bfloat16 load), and: */
+/* nn.LayerNorm(D, eps) with elementwise affine over bf16 rows: out[r, :] = bf16((x[r, :] - mean) * rstd * gamma + beta), fp32
+ * arithmetic and ONE rounding (what F.layer_norm does on bf16 tensors; CLIPEncoderLayer.layer_norm1 / 2, final_layer_norm).
+ * Any gamma (no (1 + scale) re-parameterisation).  D % 8 == 0, D <= 3072, ldx / ldo in elements, multiples of 8. */
+int tfx_layernorm(const void* x, int64_t ldx, void* out, int64_t ldo, const void* gamma, const void* beta, int64_t rows,
+                  int32_t D, float eps, tfx_stream stream);
 /* softmax(scale * q k^T + bias) v for heads of dim 64 and N <= 512 keys (tfx_attn_args with 64-wide heads: element (b, n, h, d)
  * at base + b*bstride + n*ld + h*64 + d).  rel_bias: NULL or fp32 [H, 2N-1], bias(h, query, key) = rel_bias[h][key - query +
  * N - 1] (T5Attention.compute_bias: a function of key - query only); causal != 0 masks key > query (CLIP). */
@@ -300,7 +306,8 @@ int tfx_rmsnorm(const void* x, int32_t x_dtype, int64_t ldx, const void* w, void
                 float eps, tfx_stream stream);
 /* out[i, :] = table[ids[i], :] (bf16 rows of D elements, ids int64 clamped to [0, vocab)): nn.Embedding. */
 int tfx_gather_rows(const void* table, const int64_t* ids, void* out, int64_t n, int32_t D, int64_t vocab, tfx_stream stream);
-/* fp32 residual stream of T5 under torch_dtype = bf16 (`wo` is kept in fp32, bf16 + fp32 promotes): mode 0 x += y (bf16),
+/* fp32 accumulation buffer helper (T5 under torch_dtype = float16 keeps `wo` in fp32 and its residual stream promotes to fp32;
+ * under bfloat16 -- what the reference loads -- the stream is bf16 and this is not on the path): mode 0 x += y (bf16),
  * 1 x += y (f32), 2 x = y (bf16 -> f32). */
 int tfx_add_into_f32(float* x, const void* y, int64_t n, int32_t mode, tfx_stream stream);
 /* mode 0: out = a * b (T5DenseGatedActDense: gelu(wi_0 x) * wi_1 x), mode 1: out = a * sigmoid(1.702 a) (CLIP quick_gelu);

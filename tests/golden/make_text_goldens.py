@@ -33,6 +33,18 @@ out["t5.ids"] = ids
 out["t5.out"] = t5(ids)[0]
 for k, v in t5.state_dict().items():
     out["t5.sd." + k] = v.clone()
+# what the reference actually runs: from_pretrained(torch_dtype=bfloat16).  `_keep_in_fp32_modules = ["wo"]` only applies when
+# the requested dtype is float16 (transformers modeling_utils: "will upcast to fp32 only if the requested dtype is fp16"; the
+# pinned 4.43.3 has the same float16-only condition), so EVERY weight incl. DenseReluDense.wo is bf16 and the residual stream
+# is rounded to bf16 after every sublayer.  No RNG draw here: the tensors below this line are unchanged.
+import copy
+t5_bf = copy.deepcopy(t5).to(torch.bfloat16)
+assert t5_bf.encoder.block[0].layer[1].DenseReluDense.wo.weight.dtype == torch.bfloat16
+# explicit matmul / softmax / matmul attention, the only form the pinned 4.43.3 T5 has (5.x would pick a fused SDPA kernel,
+# whose bf16 rounding points are the backend's business); 5.15's eager T5 takes the softmax of the bf16 scores directly where
+# 4.43.3 upcasts first -- on the CPU both round the fp32 softmax once, the same values
+t5_bf.config._attn_implementation = "eager"
+out["t5.out_bf16"] = t5_bf(ids)[0]
 clip = CLIPTextModel(CLIPTextConfig(**CLIP)).eval()
 for p in clip.parameters():
     p.add_(torch.randn_like(p) * 0.05)
@@ -44,6 +56,10 @@ cids[1, 76] = 119
 out["clip.ids"] = cids
 r = clip(cids)
 out["clip.last"], out["clip.pooled"] = r.last_hidden_state, r.pooler_output
+clip_bf = copy.deepcopy(clip).to(torch.bfloat16)
+clip_bf.config._attn_implementation = "eager"
+rb = clip_bf(cids)
+out["clip.last_bf16"], out["clip.pooled_bf16"] = rb.last_hidden_state, rb.pooler_output
 for k, v in clip.state_dict().items():      # on-disk key names of the pinned 4.43.3 layout (text_model.* prefix; 5.x dropped it)
     out["clip.sd." + (k if k.startswith("text_model.") else "text_model." + k)] = v.clone()
 save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(OUT, "g10_text.safetensors"))

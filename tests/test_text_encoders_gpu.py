@@ -53,6 +53,11 @@ def test_t5_tiny_matches_oracle_and_transformers_golden(golden):
     e_bf, e_f32, gap = rel_mae(out, ref_bf), rel_mae(out, g["t5.out"]), rel_mae(ref_bf, g["t5.out"])
     print(f"T5 tiny: engine vs bf16-loaded oracle {e_bf:.2e}, vs transformers fp32 {e_f32:.2e}; oracle bf16 vs fp32 {gap:.2e}")
     assert e_f32 <= 1.5 * gap + 1e-3 and e_bf <= 1.5 * gap + 1e-3
+    # transformers' own bf16 run (all-bf16 load, bf16 residual stream): the engine rounds the stream at the same points
+    assert torch.equal(ref_bf, g["t5.out_bf16"])
+    e_gold = rel_mae(out, g["t5.out_bf16"])
+    print(f"T5 tiny: engine vs transformers bf16 golden {e_gold:.2e}")
+    assert e_gold <= gap + 1e-3
 
 
 def test_clip_tiny_matches_oracle_and_transformers_golden(golden):
@@ -70,6 +75,42 @@ def test_clip_tiny_matches_oracle_and_transformers_golden(golden):
     print(f"CLIP tiny pooled: engine vs transformers fp32 {e:.2e}; oracle bf16 vs fp32 {gap:.2e}")
     assert r.pooler_output.shape == (2, 128) and e <= 1.5 * gap + 1e-3
     assert rel_mae(r.last_hidden_state, g["clip.last"]) <= 1.5 * rel_mae(last_bf, g["clip.last"]) + 1e-3
+    assert rel_mae(r.pooler_output, g["clip.pooled_bf16"]) <= gap + 1e-3
+
+
+def test_clip_layernorm_any_gamma(golden):
+    """LayerNorm weights far from 1 -- in (0, 0.5), negative, large -- load and compute (round 2 re-parameterised gamma as
+    1 + scale and refused what that could not represent exactly; real CLIP-L checkpoints hold such values)."""
+    from textflux_amd import ops
+    from textflux_amd.text_encoders import CLIPTextModel
+    g = golden("g10_text")
+    sd = {k: v.clone() for k, v in sub(g, "clip.sd.").items()}
+    gen = torch.Generator().manual_seed(3)
+    for k in sd:
+        if "layer_norm" in k and k.endswith(".weight"):
+            n = sd[k].numel()
+            w = torch.empty(n)
+            w[0::4] = torch.rand(n // 4, generator=gen) * 0.5                 # (0, 0.5)
+            w[1::4] = -torch.rand(n // 4, generator=gen) * 1.5                # negative
+            w[2::4] = 2.0 + 3.0 * torch.rand(n // 4, generator=gen)           # > 2
+            w[3::4] = 1.0 + 0.01 * torch.randn(n // 4, generator=gen)
+            sd[k] = w
+    cfg = dict(vocab_size=120, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+               max_position_embeddings=77, hidden_act="quick_gelu", eos_token_id=2)
+    r = CLIPTextModel(cfg).load_state_dict(sd, device="cuda")(g["clip.ids"].cuda())
+    ocfg = to.ClipCfg(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2)
+    last32, pooled32 = to.clip_encode(sd, ocfg, g["clip.ids"])
+    last_bf, pooled_bf = to.clip_encode({k: v.to(BF) for k, v in sd.items()}, ocfg, g["clip.ids"])
+    e, gap = rel_mae(r.last_hidden_state, last32), rel_mae(last_bf, last32)
+    print(f"CLIP with wild LayerNorm weights: engine vs fp32 oracle {e:.2e}; bf16 oracle vs fp32 {gap:.2e}")
+    assert torch.isfinite(r.last_hidden_state.float()).all() and e <= 1.5 * gap + 1e-3
+    # the kernel alone: one rounding, as F.layer_norm on bf16 tensors
+    x = torch.randn(5, 77, 128, generator=gen).to(BF)
+    ga, be = sd["text_model.final_layer_norm.weight"].to(BF), sd["text_model.final_layer_norm.bias"].to(BF)
+    ref = torch.nn.functional.layer_norm(x, (128,), ga, be, 1e-5)
+    got = ops.layernorm(x.cuda(), ga.cuda(), be.cuda(), 1e-5).cpu()
+    d = (got.float() - ref.float()).abs()
+    assert (d <= 2 ** -7 * ref.float().abs() + 1e-6).all() and (d > 0).float().mean().item() < 0.02
 
 
 def _seeded(shapes, seed, std=0.02):
@@ -83,7 +124,7 @@ def _seeded(shapes, seed, std=0.02):
 
 def test_t5_xxl_layer_shapes_match_oracle():
     """Two layers at the T5-XXL geometry (d_model 4096, 64 heads x 64, d_ff 10240), 512 tokens: the production GEMM /
-    attention shapes, against the oracle under the reference's bf16 load semantics (fp32 `wo` + fp32 residual stream)."""
+    attention shapes, against the oracle under the reference's bf16 load semantics (every weight and the residual stream in bf16)."""
     from textflux_amd.text_encoders import T5EncoderModel
     D, Hh, dff, L, V, T = 4096, 64, 10240, 2, 1000, 512
     shapes = {"shared.weight": (V, D), "encoder.final_layer_norm.weight": (D,),

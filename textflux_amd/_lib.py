@@ -94,6 +94,7 @@ SIGNATURES = {
                                       c_int32, c_void_p]),
     "tfx_ln_modulate": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                 c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "tfx_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "tfx_rmsnorm_rope": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "tfx_joint_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),

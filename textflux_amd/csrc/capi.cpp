@@ -291,6 +291,13 @@ int tfx_ln_modulate(const void* x, int64_t ldx, int64_t x_bstride, void* out, in
                      S(stream));
 }
 
+int tfx_layernorm(const void* x, int64_t ldx, void* out, int64_t ldo, const void* gamma, const void* beta, int64_t rows,
+                  int32_t D, float eps, tfx_stream stream) {
+  if (!x || !out || !gamma || !beta) return fail("tfx_layernorm: null pointer");
+  if (ldx % 8 || ldo % 8) return fail("tfx_layernorm: row strides must be multiples of 8 elements");
+  return layernorm_affine(x, out, gamma, beta, rows, D, ldx, ldo, eps, S(stream));
+}
+
 int tfx_rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int32_t q_off, int32_t k_off, int32_t H, int32_t Ntok,
                      int32_t T, int32_t B, const void* wq_img, const void* wk_img, const void* wq_txt,
                      const void* wk_txt, const float* cos_tab, const float* sin_tab, float eps, tfx_stream stream) {

@@ -2,6 +2,8 @@
 // flow-matching Euler / AMO scheduler steps, sinusoidal timestep embedding, SiLU, bf16 add.
 // All loads/stores are 16 B per lane (bf16x8); math is fp32; every bf16 rounding point of the
 // reference's unfused op chain is reproduced so results track the bf16 reference.
+#include <algorithm>
+
 #include "common.h"
 #include "launch.h"
 
@@ -14,7 +16,10 @@ namespace tfx {
 // One wave per token row, row held in registers (<= NCH*8*64 elements), two-pass statistics.
 // F8: instead of the bf16 row, write its per-row absmax e4m3 quantisation (quant_rows_fp8_kernel of the SAME bf16 values,
 // bit for bit) to q8 / q8_scale -- the fp8 mode's fused LayerNorm -> GEMM operand path.
-template <int NCH, bool F8 = false>
+// AFFINE: nn.LayerNorm with elementwise affine instead -- out = bf16((x - mean) * rstd * gamma + beta), fp32 throughout and
+// ONE rounding, which is what F.layer_norm does on bf16 tensors (scale = gamma, shift = beta, mod_bstride = 0; the CLIP text
+// model's LayerNorms, transformers models/clip/modeling_clip.py CLIPEncoderLayer / final_layer_norm).
+template <int NCH, bool F8 = false, bool AFFINE = false>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ shift,
                                                           const bf16_t* __restrict__ scale, int64_t mod_bstride,
@@ -69,6 +74,10 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restri
       unpack8(*reinterpret_cast<const u32x4*>(sh + ch * 8), h8);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        if (AFFINE) {
+          o8[i] = (v[c][i] - mean) * rstd * s8[i] + h8[i];    // rounded once, by pack8
+          continue;
+        }
         const float xn = round_bf((v[c][i] - mean) * rstd);   // F.layer_norm output, bf16
         const float t = round_bf(1.0f + s8[i]);               // (1 + scale), bf16
         o8[i] = round_bf(xn * t) + h8[i];                     // product rounded, sum rounded by pack8
@@ -375,6 +384,16 @@ int ln_modulate(const void* x, void* out, const void* shift, const void* scale, 
       (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)shift, (const bf16_t*)scale, mod_bstride, rows_per_batch, rows, D,
       ldx, x_bstride, ldo, o_bstride, eps);
   return check_launch("ln_modulate");
+}
+
+int layernorm_affine(const void* x, void* out, const void* gamma, const void* beta, int64_t rows, int D, int64_t ldx, int64_t ldo,
+                     float eps, hipStream_t st) {
+  if (D % 8 || D > 6 * 512) return fail("layernorm: D must be a multiple of 8 and <= 3072");
+  if (rows <= 0) return 0;
+  ln_modulate_kernel<6, false, true><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(
+      (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)beta, (const bf16_t*)gamma, 0, (int)std::min<int64_t>(rows, 1 << 30), rows, D,
+      ldx, 0, ldo, 0, eps);
+  return check_launch("layernorm");
 }
 
 int ln_modulate_fp8(const void* x, void* q8, float* q8_scale, const void* shift, const void* scale, int64_t mod_bstride,

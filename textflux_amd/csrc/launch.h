@@ -93,6 +93,9 @@ int groupnorm_silu_nhwc(const void* x, void* out, const void* gamma, const void*
 int ln_modulate(const void* x, void* out, const void* shift, const void* scale, int64_t mod_bstride,
                 int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldo,
                 int64_t o_bstride, float eps, hipStream_t st);
+// nn.LayerNorm with elementwise affine on [rows, D] bf16 rows: ONE bf16 rounding, as F.layer_norm (CLIP text model)
+int layernorm_affine(const void* x, void* out, const void* gamma, const void* beta, int64_t rows, int D, int64_t ldx, int64_t ldo,
+                     float eps, hipStream_t st);
 int rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int q_off, int k_off, int H, int Ntok, int T, int B,
                  const void* wq_img, const void* wk_img, const void* wq_txt, const void* wk_txt, const float* cosT,
                  const float* sinT, float eps, hipStream_t st);

@@ -142,6 +142,19 @@ def ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: 
     return out
 
 
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.LayerNorm with elementwise affine over the last dim of x [.., D] bf16 (contiguous rows): one bf16 rounding."""
+    _chk_dev(x, gamma, beta, out)
+    assert x.dtype == BF16 and gamma.dtype == BF16 and beta.dtype == BF16 and x.is_contiguous()
+    D = x.shape[-1]
+    assert gamma.numel() == D and beta.numel() == D
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.lib().tfx_layernorm(x.data_ptr(), D, out.data_ptr(), D, gamma.data_ptr(), beta.data_ptr(), x.numel() // D, D, eps,
+                                  _stream()), "layernorm")
+    return out
+
+
 def ln_modulate_fp8(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, eps: float = 1e-6):
     """ln_modulate followed by quantize_rows_fp8 in one pass: returns (q uint8 [B,R,D], scale f32 [B,R])."""
     _chk_dev(x, shift, scale)

@@ -6,12 +6,15 @@ pooled embedding, :1493-1496).  Their arithmetic is third-party `transformers` (
 models/t5/modeling_t5.py, models/clip/modeling_clip.py); the classes below keep those two call signatures and read the same
 checkpoint layout (config.json + model.safetensors, or the sharded form with model.safetensors.index.json), and run the
 arithmetic in libtextflux_hip.so:
-  Linear layers      tfx_gemm_bf16 (q | k | v and wi_1 | wi_0 fused by row concatenation at load, GELU-tanh in the epilogue)
-  T5 `wo`            tfx_gemm_bf16_f32: transformers keeps DenseReluDense.wo in fp32 under torch_dtype=bf16
-                     (_keep_in_fp32_modules), so its product reaches the residual stream unrounded and the stream is fp32
+  Linear layers      tfx_gemm_bf16 (q | k | v and wi_1 | wi_0 fused by row concatenation at load, GELU-tanh in the epilogue,
+                     the residual add of `o` / `wo` / out_proj / fc2 in the epilogue: Linear output rounded to bf16, then the
+                     bf16 sum -- the reference's rounding points)
+  residual stream    bf16 in both models.  T5's `_keep_in_fp32_modules = ["wo"]` only applies to a float16 load (transformers
+                     modeling_utils, 4.43.3 and 5.x alike); the reference loads with torch_dtype=bfloat16, so `wo` is bf16 and
+                     the stream is rounded to bf16 after every sublayer
   attention          tfx_attention64 (heads of 64; T5: unscaled scores + bucketed relative-position bias; CLIP: causal)
-  norms              tfx_rmsnorm (T5LayerNorm), tfx_ln_modulate with (gamma - 1, beta) as (scale, shift) (nn.LayerNorm)
-  embeddings etc.    tfx_gather_rows, tfx_add, tfx_add_into_f32, tfx_mul_act
+  norms              tfx_rmsnorm (T5LayerNorm), tfx_layernorm (nn.LayerNorm with its affine, one rounding, any gamma)
+  embeddings etc.    tfx_gather_rows, tfx_add, tfx_mul_act
 Tokenizers stay `transformers` objects (host string processing).  Parity: oracle/text_oracle.py restates both models and is
 pinned against `transformers` (tests/test_text_oracle.py); tests/test_text_encoders_gpu.py compares these classes with it.
 """
@@ -101,8 +104,6 @@ class T5EncoderModel(_Encoder):
             w[f"{i}.qkv"] = torch.cat([g(a + "q.weight"), g(a + "k.weight"), g(a + "v.weight")], 0).contiguous()
             w[f"{i}.o"] = g(a + "o.weight").contiguous()
             w[f"{i}.wi"] = torch.cat([g(f + "wi_1.weight"), g(f + "wi_0.weight")], 0).contiguous()   # [linear ; gelu] rows
-            # `wo` is the fp32 module of the reference load; a bf16 checkpoint upcast to fp32 holds bf16-exact values, and the
-            # fp32-output GEMM multiplies bf16 operands exactly and accumulates in fp32 -- the same product, unrounded
             w[f"{i}.wo"] = g(f + "wo.weight").contiguous()
         self.w, self.device = w, dev
         self._bias_tables = {}
@@ -163,18 +164,17 @@ class T5EncoderModel(_Encoder):
         ids = input_ids.to(self.device, torch.int64)
         B, T = ids.shape
         D, inner, dff = c.d_model, c.num_heads * 64, c.d_ff
-        x32 = torch.empty(B * T, D, dtype=torch.float32, device=self.device)
-        ops.add_into_f32_(x32, ops.gather_rows(w["embed"], ids), assign=True)
+        x = ops.gather_rows(w["embed"], ids)                                   # [B * T, D] bf16: the residual stream
         bias = self._rel_bias(T)
         for i in range(c.num_layers):
-            h = ops.rmsnorm(x32, w[f"{i}.ln0"], c.layer_norm_epsilon)
+            h = ops.rmsnorm(x, w[f"{i}.ln0"], c.layer_norm_epsilon)
             qkv = ops.gemm(h, w[f"{i}.qkv"], None).view(B, T, 3 * inner)
             a = ops.attention64(qkv[:, :, :inner], qkv[:, :, inner:2 * inner], qkv[:, :, 2 * inner:], 1.0, rel_bias=bias)
-            ops.add_into_f32_(x32, ops.gemm(a.view(B * T, inner), w[f"{i}.o"], None))
-            h = ops.rmsnorm(x32, w[f"{i}.ln1"], c.layer_norm_epsilon)
+            x = ops.gemm(a.view(B * T, inner), w[f"{i}.o"], None, epilogue=ops.EPI_BIAS_RES, res=x)
+            h = ops.rmsnorm(x, w[f"{i}.ln1"], c.layer_norm_epsilon)
             u = ops.gemm(h, w[f"{i}.wi"], None, epilogue=ops.EPI_BIAS_GELU, gelu_from_col=dff)       # [wi_1 x | gelu(wi_0 x)]
-            ops.add_into_f32_(x32, ops.gemm_f32(ops.mul(u[:, dff:], u[:, :dff]), w[f"{i}.wo"]).contiguous())
-        out = ops.rmsnorm(x32, w["final_ln"], c.layer_norm_epsilon).view(B, T, D)
+            x = ops.gemm(ops.mul(u[:, dff:], u[:, :dff]), w[f"{i}.wo"], None, epilogue=ops.EPI_BIAS_RES, res=x)
+        out = ops.rmsnorm(x, w["final_ln"], c.layer_norm_epsilon).view(B, T, D)
         return (out,)
 
 
@@ -199,12 +199,8 @@ class CLIPTextModel(_Encoder):
         p = "text_model." if any(k.startswith("text_model.") for k in sd) else ""
         g = lambda k: sd[p + k].to(dev, BF16).contiguous()
 
-        def ln(name, key):   # nn.LayerNorm(gamma, beta) as LN * (1 + scale) + shift: gamma - 1 is exact in bf16 for gamma in [0.5, 2]
-            gamma = sd[p + key + ".weight"].to(dev, BF16)
-            scale = (gamma.float() - 1.0).to(BF16)
-            if not torch.equal((1.0 + scale.float()).to(BF16), gamma):
-                raise ValueError(f"{key}: LayerNorm weight outside the exactly representable range of the modulation form")
-            w[name + ".scale"], w[name + ".shift"] = scale[None].contiguous(), g(key + ".bias")[None].contiguous()
+        def ln(name, key):   # nn.LayerNorm's own (gamma, beta): any value loads (tfx_layernorm)
+            w[name + ".gamma"], w[name + ".beta"] = g(key + ".weight"), g(key + ".bias")
 
         w: Dict[str, torch.Tensor] = {"tok": g("embeddings.token_embedding.weight"), "pos": g("embeddings.position_embedding.weight")}
         for i in range(c.num_hidden_layers):
@@ -228,7 +224,7 @@ class CLIPTextModel(_Encoder):
         w = {"tok": rnd(c.vocab_size, D, scale=1.0), "pos": rnd(c.max_position_embeddings, D, scale=0.1)}
         names = [f"{i}.{n}" for i in range(c.num_hidden_layers) for n in ("ln1", "ln2")] + ["final"]
         for n in names:
-            w[n + ".scale"], w[n + ".shift"] = rnd(1, D, scale=0.05), rnd(1, D, scale=0.05)
+            w[n + ".gamma"], w[n + ".beta"] = (1.0 + rnd(D, scale=0.05).float()).to(BF16), rnd(D, scale=0.05)
         for i in range(c.num_hidden_layers):
             w[f"{i}.qkv.w"], w[f"{i}.qkv.b"] = rnd(3 * D, D), rnd(3 * D)
             w[f"{i}.o.w"], w[f"{i}.o.b"] = rnd(D, D), rnd(D)
@@ -238,9 +234,7 @@ class CLIPTextModel(_Encoder):
         return self
 
     def _ln(self, x, name):
-        w = self.w
-        B = x.shape[0]
-        return ops.ln_modulate(x, w[name + ".shift"].expand(B, -1), w[name + ".scale"].expand(B, -1), eps=self.config.layer_norm_eps)
+        return ops.layernorm(x.contiguous(), self.w[name + ".gamma"], self.w[name + ".beta"], eps=self.config.layer_norm_eps)
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, attention_mask=None, output_hidden_states: bool = False, **_):

@@ -163,6 +163,27 @@ class AutoencoderKL:
             x = ops.gemm(x.view(B * H * W, C), self.hw[p + ".conv_shortcut.weight"], self.sd[p + ".conv_shortcut.bias"]).view(B, H, W, -1)
         return self._conv(h, p + ".conv2", res=x)
 
+    def _attend(self, q, k, v):
+        """softmax(q k^T / sqrt(C)) v for ONE head of dim C, q / k / v [B, N, C] bf16 (AttnProcessor2_0,
+        D/models/attention_processor.py:2799-2881).  Scores stay fp32 between the two GEMMs (a flash kernel would keep them
+        in registers); token counts are padded to a multiple of 64 with zero weights / zero v^T columns so that the P v
+        product takes the MFMA kernel for any h * w; one image at a time through reused [N, Np] score / weight buffers."""
+        B, N, C = q.shape
+        Np = (N + 63) // 64 * 64
+        vt = torch.zeros(B, C, Np, dtype=torch.bfloat16, device=q.device) if Np != N else torch.empty(B, C, N, dtype=torch.bfloat16, device=q.device)
+        ops.transpose(v, out=vt[:, :, :N])
+        if self._scores is None or self._scores[0].shape != (N, Np):
+            self._scores = None                                          # release before re-allocating
+            self._scores = (torch.empty(N, Np, dtype=torch.float32, device=q.device),
+                            torch.zeros(N, Np, dtype=torch.bfloat16, device=q.device))
+        s, pw = self._scores
+        o = torch.empty(B, N, C, dtype=torch.bfloat16, device=q.device)
+        for b in range(B):
+            ops.gemm_f32(q[b], k[b], out=s[:, :N])
+            ops.row_softmax(s[:, :N], C ** -0.5, pw)
+            ops.gemm(pw, vt[b], None, out=o[b])
+        return o
+
     def _mid(self, x, p):
         x = self._res(x, p + ".resnets.0")
         B, H, W, C = x.shape
@@ -171,21 +192,7 @@ class AutoencoderKL:
         tok = x.view(B, N, C)
         h = self._gn(tok, a + ".group_norm", silu=False)
         q, k, v = (ops.gemm(h, self.sd[f"{a}.{n}.weight"], self.sd[f"{a}.{n}.bias"]) for n in ("to_q", "to_k", "to_v"))
-        # scores stay fp32 between the two GEMMs (a flash kernel would keep them in registers); token counts are padded to
-        # a multiple of 64 with zero weights / zero v^T columns so that the P v product takes the MFMA kernel for any h * w
-        Np = (N + 63) // 64 * 64
-        vt = torch.zeros(B, C, Np, dtype=torch.bfloat16, device=x.device) if Np != N else torch.empty(B, C, N, dtype=torch.bfloat16, device=x.device)
-        ops.transpose(v, out=vt[:, :, :N])
-        if self._scores is None or self._scores[0].shape != (N, Np):
-            self._scores = None                                          # release before re-allocating
-            self._scores = (torch.empty(N, Np, dtype=torch.float32, device=x.device),
-                            torch.zeros(N, Np, dtype=torch.bfloat16, device=x.device))
-        s, pw = self._scores
-        o = torch.empty(B, N, C, dtype=torch.bfloat16, device=x.device)
-        for b in range(B):
-            ops.gemm_f32(q[b], k[b], out=s[:, :N])
-            ops.row_softmax(s[:, :N], C ** -0.5, pw)
-            ops.gemm(pw, vt[b], None, out=o[b])
+        o = self._attend(q, k, v)
         x = ops.gemm(o, self.sd[a + ".to_out.0.weight"], self.sd[a + ".to_out.0.bias"], epilogue=ops.EPI_BIAS_RES,
                      res=tok).view(B, H, W, C)
         return self._res(x, p + ".resnets.1")
