@@ -16,10 +16,6 @@ import os
 import sys
 import time
 
-# MIOpen (VAE convolutions, torch ops this round): use the find-db / heuristic "fast" find mode instead of benchmarking
-# every solver (incl. the naive one) on first use -- that exhaustive search cost minutes of warm-up per process.
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -192,7 +188,9 @@ def main():
         sch.set_overshot_func(lambda t, dt: t + dt)
     # text encoders at their real geometry (T5-XXL: 24 x d_model 4096 / 64 heads / d_ff 10240, 4.7 B parameters; CLIP-L: 12 x 768),
     # random-init; the tokenizers' vocabulary files are not available offline, so token ids come from a stand-in tokenizer
-    # (host string processing is not what is measured).  Rank 0 encodes, the embeddings are broadcast (multi-GPU).
+    # (host string processing is not what is measured).  Every rank holds a T5 (9.5 GB of 288 GB) and encodes the prompts of
+    # ITS OWN images; the CLIP prompt is one fixed template for every image: rank 0 encodes it, RCCL broadcasts the pooled
+    # embedding (multi-GPU) -- no rank does another rank's work, no rank waits for more than that broadcast.
     te = te2 = tok = tok2 = None
     use_te = not a.no_text_encoders
     if use_te:
@@ -214,13 +212,13 @@ def main():
                 return SimpleNamespace(input_ids=torch.stack(rows))
 
         tok, tok2 = _Tok(77, 49408), _Tok(512, 32128)
+        from textflux_amd.text_encoders import CLIPTextModel, T5EncoderModel
         if rank == 0:
-            from textflux_amd.text_encoders import CLIPTextModel, T5EncoderModel
             te = CLIPTextModel(dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
                                     num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu",
                                     eos_token_id=2)).init_random_(seed=11, device=dev)
-            te2 = T5EncoderModel(dict(vocab_size=32128, d_model=4096, d_kv=64, d_ff=10240, num_layers=24, num_heads=64,
-                                      feed_forward_proj="gated-gelu")).init_random_(seed=12, device=dev)
+        te2 = T5EncoderModel(dict(vocab_size=32128, d_model=4096, d_kv=64, d_ff=10240, num_layers=24, num_heads=64,
+                                  feed_forward_proj="gated-gelu")).init_random_(seed=12, device=dev)
     pipe = FluxFillPipeline(scheduler=sch, vae=vae, text_encoder=te, tokenizer=tok, text_encoder_2=te2,
                             tokenizer_2=tok2, transformer=tr)
     pipe.set_progress_bar_config(disable=True)
@@ -247,13 +245,11 @@ def main():
 
     def one_call():
         pe_c, pooled_c = pe, pooled
-        if use_te:     # inside the timed region: B T5-XXL prompts + the CLIP template, encoded on rank 0, broadcast over RCCL
-            if rank == 0:
-                with torch.no_grad():
-                    pe_c, pooled_c, _ = pipe.encode_prompt(prompt=[glyph.PROMPT_TEMPLATE2] * B, prompt_2=prompts2, device=dev,
-                                                           max_sequence_length=T_TXT)
-            pe_c, pooled_c = tdist.broadcast_conditioning(pe_c if rank == 0 else None, pooled_c if rank == 0 else None,
-                                                          (B, T_TXT, 4096), (B, 768), torch.bfloat16, dev)
+        if use_te:     # inside the timed region: the CLIP template on rank 0 -> RCCL broadcast; B T5-XXL prompts on every rank
+            with torch.no_grad():
+                pooled_c = pipe._get_clip_prompt_embeds([glyph.PROMPT_TEMPLATE2], 1, dev) if rank == 0 else None
+                pooled_c = tdist.broadcast_tensor(pooled_c, (1, 768), torch.bfloat16, dev).expand(B, -1).contiguous()
+                pe_c = pipe._get_t5_prompt_embeds(prompts2, 1, T_TXT, dev)
         return pipe(prompt_embeds=pe_c, pooled_prompt_embeds=pooled_c, image=image, mask_image=mask, height=H, width=W,
                     num_inference_steps=n, guidance_scale=30.0, generator=gen, output_type="pt").images
 
@@ -287,21 +283,39 @@ def main():
         total_images = world * B * a.steps
         ips = total_images / elapsed
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # Counter- and power-derived fields cannot be collected by bench.py itself (rocprofv3 --pmc needs its own passes,
+        # rocm-smi its own sustained loops): they are READ from the newest committed profile and say so -- "live": false,
+        # the file, and the round it was collected in -- so that no future run can pass them off as measured by this run.
+        def committed(stem):
+            for rnd in ("r03", "r02"):
+                fn = os.path.join(REPO, "profiles", f"{rnd}_{stem}.json")
+                if os.path.exists(fn):
+                    with open(fn) as f:
+                        return json.load(f), f"profiles/{rnd}_{stem}.json", rnd
+            return None, None, None
+
         traffic, traffic_note = None, None
-        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (bench.py cannot collect PMCs itself)
-            with open(os.path.join(REPO, "profiles", "r02_gemm_pmc_traffic.json")) as f:
-                pm = json.load(f)["shapes"][0]
+        try:
+            pmj, fn, rnd = committed("gemm_pmc_traffic")
+            pm = pmj["shapes"][0]
             traffic = pm["hbm_bytes_per_launch"]
-            traffic_note = (f"PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the most expensive shape "
-                            f"M={pm['M']} N={pm['N']} K={pm['K']} (algorithmic bytes {pm['algorithmic_bytes']}); "
-                            f"profiles/r02_gemm_pmc_traffic.json")
+            traffic_note = {"live": False, "collected_in_round": rnd, "file": fn,
+                            "what": (f"PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE of the most expensive shape M={pm['M']} "
+                                     f"N={pm['N']} K={pm['K']} (algorithmic bytes {pm['algorithmic_bytes']})")}
         except Exception:
             pass
         mfma_pmc = None
         try:  # matrix-pipe busy fraction of the DiT kernels from the committed SQ_VALU_MFMA_BUSY_CYCLES pass over this bench
-            with open(os.path.join(REPO, "profiles", "r02_mfma_util.json")) as f:
-                mu = json.load(f)
-            mfma_pmc = {"dit_kernels": mu["dit_kernels_total"]["mfma_util"], "source": "profiles/r02_mfma_util.json (" + mu["formula"] + ")"}
+            mu, fn, rnd = committed("mfma_util")
+            mfma_pmc = {"dit_kernels": mu["dit_kernels_total"]["mfma_util"], "live": False, "collected_in_round": rnd,
+                        "file": fn, "formula": mu["formula"]}
+        except Exception:
+            pass
+        power_peak = None
+        try:  # the rate of a kernel that does nothing but MFMAs on random bf16 data at the board's power cap (tools/power_profile.py)
+            pw, fn, rnd = committed("power")
+            if pw.get("power_capped_peak_tflops"):
+                power_peak = {"tflops": pw["power_capped_peak_tflops"], "live": False, "collected_in_round": rnd, "file": fn}
         except Exception:
             pass
         rec = {
@@ -315,15 +329,16 @@ def main():
                                       "injected random prompt embeddings; text encoders bypassed)"),
             "config": {"workload": f"{'P1024' if (H, W) == (1024, 1024) else f'{H}x{W}'}: FluxFillPipeline.__call__ {H}x{W}, {n} {a.sampler} steps, guidance 30, "
                                    f"batch {B}/GPU (S={S} image + 512 text tokens), "
-                                   + ("T5-XXL + CLIP-L prompt encoding, " if use_te else "") + "VAE encode+decode included"
+                                   + ("T5-XXL (8 prompts per rank) + CLIP-L prompt encoding, " if use_te else "") + "VAE encode+decode included"
                                    + ("" if full else f" [REDUCED MODEL {a.layers} - not a valid headline]")
                                    + (" [fp8 linears: BASELINE config 5 precision, not the bf16 headline]" if a.fp8 else ""),
-                       "global_batch": world * B, "parallelism": f"dp{world} (batch shards, conditioning broadcast over RCCL)"},
+                       "global_batch": world * B, "parallelism": f"dp{world} (batch shards; shared CLIP conditioning broadcast over RCCL, T5 prompts encoded per rank)"},
             "rccl_ranks_seen": seen,
             "sec_per_img_per_gpu": elapsed / (B * a.steps),
             "dit_algorithmic_tflops_per_gpu": dit_flops(S) * n * B * a.steps / elapsed / 1e12 if full else None,
             "roofline": {"bound": "mfma", "kernel": "tfx::gemm8pp_kernel (persistent MFMA GEMM, all epilogues; + gemm8p_kernel for K % 128 != 0)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS * (2 if a.fp8 else 1), "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_TFLOPS * (2 if a.fp8 else 1)),
+                         "power_capped_peak": None if a.fp8 else power_peak,
                          "traffic": None if a.fp8 else traffic, "traffic_note": None if a.fp8 else traffic_note, "mfma_busy_pmc": None if a.fp8 else mfma_pmc, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "sample": "HIP events around every GEMM launch of one extra, untimed, eager call after the timed region (graph-replayed launches are not individually timed)",
                          "flops_per_launch": gemm_fl / max(gemm_n, 1),
@@ -333,8 +348,8 @@ def main():
         rec["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(H, W, n)   # rank 0 at N = 1 only
         if rec["cpu_baseline"] is not None:
             try:   # the full BASELINE config-1 run (minutes of CPU): measured once per round by `--cpu-baseline-c1`, committed
-                with open(os.path.join(REPO, "profiles", "r02_cpu_baseline_c1.json")) as f:
-                    rec["cpu_baseline"]["c1_full_run"] = json.load(f)["cpu_baseline_c1"]
+                c1, fn, rnd = committed("cpu_baseline_c1")
+                rec["cpu_baseline"]["c1_full_run"] = dict(c1["cpu_baseline_c1"], live=False, collected_in_round=rnd, file=fn)
             except Exception:
                 pass
         print(json.dumps(rec), flush=True)

@@ -49,15 +49,26 @@ def _embed(prompt: str) -> torch.Tensor:
 
 
 class StubPipe:
-    """encode_prompt: deterministic function of the T5 prompt string, rank 0 only.  __call__: one flat-colour image per
-    item whose grey level encodes the mean of the embedding it was handed (so a mix-up of prompts is visible)."""
+    """encode_prompt: deterministic function of the T5 prompt string.  __call__: one flat-colour image per item whose grey
+    level encodes the mean of the embedding it was handed (so a mix-up of prompts is visible).
+    has_t5: this rank holds a T5 encoder (`text_encoder_2`); without one only rank 0 may be asked to encode.
+    slow_encode: seconds every encode_prompt call sleeps (rank 0 as a would-be straggler); fail_on: a substring of a T5
+    prompt whose encoding raises."""
 
-    def __init__(self, rank):
-        self.rank, self.calls = rank, []
+    def __init__(self, rank, has_t5=True, slow_encode=0.0, fail_on=None):
+        self.rank, self.calls, self.encodes = rank, [], []
+        self.text_encoder_2 = object() if has_t5 else None
+        self.slow_encode, self.fail_on = slow_encode, fail_on
 
     def encode_prompt(self, prompt, prompt_2, device=None, max_sequence_length=512, **kw):
-        assert self.rank == 0, "only rank 0 may encode prompts"
+        assert self.text_encoder_2 is not None or self.rank == 0, "a rank without T5 was asked to encode"
         p2 = [prompt_2] if isinstance(prompt_2, str) else prompt_2
+        if self.fail_on and any(self.fail_on in p for p in p2):
+            raise RuntimeError("tokenizer exploded")
+        if self.slow_encode:
+            import time
+            time.sleep(self.slow_encode)
+        self.encodes.append(len(p2))
         return torch.stack([_embed(p) for p in p2]), torch.full((len(p2), P), 3.0), torch.zeros(T, 3)
 
     def __call__(self, height, width, image, mask_image, num_inference_steps, generator, max_sequence_length, guidance_scale,
@@ -89,30 +100,55 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="local"):
+    import time
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     tdist.init_from_env(backend="gloo")
-    pipe = StubPipe(rank)
-    saved = {}
+    if mode == "local":          # every rank holds T5; rank 0's encoder is SLOW: nobody else may feel it
+        pipe = StubPipe(rank, has_t5=True, slow_encode=1.0 if rank == 0 else 0.0)
+        real_scatter = dist.scatter
+        dist.scatter = lambda *a, **k: (_ for _ in ()).throw(AssertionError("local encoding must not scatter"))
+    elif mode == "rank0":        # ranks > 0 without T5: rank 0 encodes for all and scatters
+        pipe = StubPipe(rank, has_t5=(rank == 0))
+    else:                        # "rank0_fail": the prompts of batch 1 (owned by rank 1) cannot be encoded
+        pipe = StubPipe(rank, has_t5=(rank == 0), fail_on="WORD6")
+    saved, stamps = {}, []
+    t0 = time.time()
+
+    def save(i, img):
+        saved[i] = (img.size, int(np.array(img)[0, 0, 0]))
+        stamps.append(time.time() - t0)
+
     res = bd.run_items(_items(), pipe, None, batch_size=4, num_inference_steps=3, guidance_scale=30.0, seed=42, device="cpu",
-                       loader=_loader, save=lambda i, img: saved.__setitem__(i, (img.size, int(np.array(img)[0, 0, 0]))))
-    q.put((rank, res, saved, pipe.calls))
+                       loader=_loader, save=save)
+    q.put((rank, res, saved, pipe.calls, pipe.encodes, stamps))
     dist.destroy_process_group()
 
 
-def test_two_rank_batched_driver_on_gloo():
+def _run_world(world, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    out = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, r0, s0, c0), (_, r1, s1, c1) = out
+    return out
+
+
+def test_two_rank_batched_driver_on_gloo():
+    out = _run_world(2, "local")
+    (_, r0, s0, c0, e0, t0), (_, r1, s1, c1, e1, t1) = out
+    # every rank encodes its OWN batches (rank 0: the template + batches 0 and 2; rank 1: batch 1) -- no scatter happened
+    # (the worker turns dist.scatter into an assertion) -- and rank 1 finished its images without ever waiting for rank 0's
+    # slow encoder (3 calls x 1 s on rank 0; only the template broadcast at the start is shared)
+    assert r0["encode"] == r1["encode"] == "local"
+    assert e0 == [1, 4, 3] and e1 == [2]
+    assert max(t1) < 2.0 and max(t0) > 2.9, (t0, t1)
     # 3 batches dealt round-robin: rank 0 gets batches 0 and 2, rank 1 batch 1; two rounds
     assert r0["batches"] == 3 and r0["rounds"] == 2
     assert sorted(r0["done"]) == [0, 1, 2, 3, 4, 5, 8] and sorted(r1["done"]) == [6, 7]
@@ -125,6 +161,84 @@ def test_two_rank_batched_driver_on_gloo():
         want = int(round(float(_embed(glyph.generate_prompt(words)).mean()) * 1000)) % 256
         assert level == want, (i, level, want)
         assert size == ((256, 256) if i % 3 == 2 else (512, 244))   # 320 - int(320 * 80 / 336): the reference's crop arithmetic
+
+
+def test_rank0_encode_mode_scatters_and_survives_an_encode_failure():
+    """Ranks > 0 without a T5: rank 0 encodes for everybody and scatters (the round-2 pattern, kept for that case).  When the
+    encode of a batch fails on rank 0, the owner marks the batch failed and every collective still matches (no hang)."""
+    (_, r0, s0, c0, e0, _), (_, r1, s1, c1, e1, _) = _run_world(2, "rank0")
+    assert r0["encode"] == r1["encode"] == "rank0" and e1 == [] and e0 == [1, 4, 2, 3]
+    assert r0["all_done"] == list(range(9)) and sorted(r1["done"]) == [6, 7]
+    items = _items()
+    for i, (size, level) in {**s0, **s1}.items():
+        words = glyph.read_words_from_text(items[i]["text"])
+        assert level == int(round(float(_embed(glyph.generate_prompt(words)).mean()) * 1000)) % 256
+    (_, r0, s0, c0, e0, _), (_, r1, s1, c1, e1, _) = _run_world(2, "rank0_fail")
+    assert sorted(r1["failed"]) == [6, 7] and r1["done"] == [] and c1 == []
+    assert sorted(r0["done"]) == [0, 1, 2, 3, 4, 5, 8] and r0["all_done"] == [0, 1, 2, 3, 4, 5, 8]
+
+
+def test_world8_dry_run_every_rank_same_critical_path():
+    """The 8-rank shape of `bench.py --gpus 8` / `run_eval.py --num_gpus 8`, dry (gloo, stub pipeline): 9 items in 3 batches
+    over 8 ranks -- one round, ranks 3..7 idle, no rank encodes for another."""
+    out = _run_world(8, "local")
+    assert out[0][1]["rounds"] == 1 and out[0][1]["all_done"] == list(range(9))
+    assert [o[4] for o in out] == [[1, 4]] + [[2], [3]] + [[]] * 5
+
+
+def test_eval_schema_items_follow_the_reference_rule(tmp_path):
+    """annos.json entries (reference scripts/run_eval.py:76-140, 168-190): strip height int(w * ratio) of the WIDTH, polygon
+    mask, stacking, /32 sizes, prompt, full_images/ + cropped_images/ outputs with the reference's crop arithmetic; entries
+    with incomplete annotations are not queued (:229-231)."""
+    data = [dict(img_name="sub/a.png", annotations=[dict(text="HELLO", polygon=[[100, 60], [400, 60], [400, 120], [100, 120]])]),
+            dict(img_name="b.png", annotations=[dict(text="", polygon=[[0, 0], [1, 1], [2, 0]])]),
+            dict(img_name="c.png", annotations=[]),
+            dict(img_name="d.png", annotations=[dict(text="WORLD", polygon=[[10, 10], [200, 30], [180, 90]]), dict(text="IGNORED", polygon=[[0, 0], [5, 5], [9, 0]])])]
+    assert [bd.eval_item_complete(d) for d in data] == [True, False, False, True]
+    scenes = {"sub/a.png": (520, 260), "b.png": (64, 64), "c.png": (64, 64), "d.png": (520, 260)}
+    loader = lambda p: Image.fromarray(np.full((scenes[os.path.relpath(p, "imgs")][1], scenes[os.path.relpath(p, "imgs")][0], 3), 77, np.uint8))
+    font = glyph.load_font(None)
+    cfg = dict(original_images_dir="imgs", font=font, text_height_ratio=0.1667)
+    w = bd.prepare_item(0, data[0], loader, eval_cfg=cfg)
+    strip = int(520 * 0.1667)                                              # 86: a fraction of the WIDTH
+    assert w.meta["strip"] == strip == 86 and w.meta["orig_h"] == 260 and w.name == "a.png"
+    assert w.size == ((520 // 32) * 32, ((260 + 86) // 32) * 32) == (512, 320)
+    assert w.image.size == (512, 320) and w.mask.size == (512, 320)
+    assert w.prompt == glyph.generate_prompt(["HELLO"])
+    assert glyph.crop_box(w.size, w.meta) == (0, int(320 * (86 / (260 + 86))), 512, 320) == (0, 79, 512, 320)
+    m = np.array(w.mask.convert("L"))
+    assert m[:70].max() == 0                                               # the glyph part's mask is black
+    wd = bd.prepare_item(3, data[3], loader, device_compose=True, eval_cfg=cfg)
+    g, sc, mk, horizontal = wd.parts
+    assert g.shape == (86, 520, 3) and sc.shape == (260, 520, 3) and mk.shape == (260, 520, 3) and not horizontal
+    assert mk[60:121, 100:401].min() == 0 and mk[20, 100, 0] == 255       # d's own triangle, not a's rectangle
+    mk_a = glyph.fill_polygon(260, 520, data[0]["annotations"][0]["polygon"])
+    assert mk_a[60:121, 100:401].min() == 255 and mk_a.sum() == 255 * 3 * 61 * 301   # rectangle filled inclusive of its border
+    # the whole driver on the two complete items
+    pipe, out = StubPipe(0), tmp_path
+    os.makedirs(out / "full_images"), os.makedirs(out / "cropped_images")
+    res = bd.run_items([data[0], data[3]], pipe, str(out), batch_size=8, device="cpu", loader=loader, eval_cfg=cfg)
+    assert res["all_done"] == [0, 1] and pipe.calls == [(512, 320, 2)]
+    for name in ("a.png", "d.png"):
+        assert Image.open(out / "full_images" / name).size == (512, 320)
+        assert Image.open(out / "cropped_images" / name).size == (512, 320 - 79)
+
+
+def test_run_eval_cli_speaks_the_reference_flags(tmp_path):
+    sys.path.insert(0, os.path.join(REPO, "scripts"))
+    import importlib
+    re_ = importlib.import_module("run_eval")
+    a = re_.build_parser().parse_args(["--json_path", "annos.json", "--original_images_dir", "o", "--weights_path", "w"])
+    assert (a.output_dir, a.font_path, a.text_height_ratio, a.steps, a.guidance_scale, a.seed, a.num_gpus, a.scheduler) == (
+        "visualization_results", "./resource/font/Arial-Unicode-Regular.ttf", 0.1667, 30, 30, 42, 4, "")
+    jp = tmp_path / "annos.json"
+    jp.write_text('{"data_list": [{"img_name": "x.png", "annotations": [{"text": "A", "polygon": [[0,0],[4,0],[4,4]]}]}, {"img_name": "y.png"}]}')
+    lst = re_.load_data_from_json(str(jp))
+    tasks, skipped = re_.select_tasks(lst)
+    assert [t["img_name"] for t in tasks] == ["x.png"] and skipped == ["y.png"]
+    assert re_.load_data_from_json(str(tmp_path / "missing.json")) == []
+    (tmp_path / "bad.json").write_text("{nope")
+    assert re_.load_data_from_json(str(tmp_path / "bad.json")) == []
 
 
 def test_single_process_driver_needs_no_process_group():

@@ -1,0 +1,88 @@
+"""Build-time check of the emitted gfx950 ISA (no GPU needed: hipcc cross-compiles): no VALU / memory instruction -- the ones
+inside inline asm included, which hipcc's own hazard recogniser cannot see -- touches an MFMA result inside the wait-state
+window the hardware does not interlock (tools/check_mfma_hazard.py).  The default attention kernel reads its scores from
+inline asm; round 2 guarded that by a distance the compiler did not know about.  Now: a compiler-visible read (W4_TOUCH)
+in front of the asm reads makes hipcc pad by construction, and this test fails the build if the property is ever lost --
+demonstrated on a deliberately shortened distance (-DW4_NO_TOUCH -DW4_HAZARD_SELFTEST)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "textflux_amd", "csrc")
+sys.path.insert(0, os.path.join(REPO, "tools"))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+
+
+def isa(src, tmp_path, *flags):
+    out = tmp_path / (os.path.basename(src) + "".join(f.replace("-", "_") for f in flags) + ".s")
+    extra = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if src.endswith("attention_w4.hip") else []     # as the Makefile builds it
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only", "-S", *extra, *flags,
+                        "-o", str(out), os.path.join(CSRC, src)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return out.read_text()
+
+
+def test_default_attention_kernel_has_no_mfma_result_hazard(tmp_path):
+    import check_mfma_hazard as ck
+    asm = isa("attention_w4.hip", tmp_path)
+    (name, n, n_mfma, rep), = ck.check_all(asm)
+    assert "attn_w4_kernel" in name and n_mfma > 250 and n > 3000      # the kernel was really parsed
+    assert asm.count("v_readfirstlane_b32") >= 16                       # the compiler-visible touches are in the stream
+    assert rep == [], rep[:5]
+
+
+def test_checker_catches_a_shortened_distance(tmp_path):
+    """The self-test variant reads a score from inline asm right behind its chain's last MFMA, with the touch removed."""
+    import check_mfma_hazard as ck
+    asm = isa("attention_w4.hip", tmp_path, "-DW4_NO_TOUCH", "-DW4_HAZARD_SELFTEST")
+    (_, _, _, rep), = ck.check_all(asm)
+    assert len(rep) >= 4 and all("mfma write" in r for r in rep), rep[:3]
+    # ... and the touch alone is what makes the compiler pad: same shortened read, touch in place right behind the MFMA
+    padded = isa("attention_w4.hip", tmp_path, "-DW4_HAZARD_SELFTEST")
+    (_, _, _, rep2), = ck.check_all(padded)
+    assert len(rep2) == len(rep)          # the unprotected asm read is still flagged (the touch sits in front of the REAL reads only)
+
+
+def test_checker_agrees_with_hipcc_on_visible_instructions(tmp_path):
+    """Stripping the s_nop padding hipcc itself inserted in front of compiler-visible VALU reads must trip the checker: the
+    rule implemented here is the compiler's rule (passes + 4 wait states on gfx950), not a looser one."""
+    import re
+    import check_mfma_hazard as ck
+    asm = isa("textenc.hip", tmp_path)
+    assert all(rep == [] for _, _, _, rep in ck.check_all(asm))
+    stripped = re.sub(r"^\s*s_nop \d+\s*$", "", asm, flags=re.M)
+    assert any(rep for _, _, _, rep in ck.check_all(stripped))
+
+
+@pytest.mark.parametrize("src", ["attention.hip", "attention_hp.hip", "gemm.hip"])
+def test_other_mfma_kernels_are_clean(src, tmp_path):
+    import check_mfma_hazard as ck
+    res = ck.check_all(isa(src, tmp_path))
+    assert res and all(rep == [] for _, _, _, rep in res), [(n, r[:2]) for n, _, _, r in res if r]
+
+
+def test_synthetic_listing_known_answers():
+    import check_mfma_hazard as ck
+    head = "\t.amdhsa_kernel k\nk:\n"
+    ok = head + "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]\n" + "\ts_nop 11\n\tv_add_f32 v40, v0, v1\n\ts_endpgm\n"
+    assert ck.check(ok, "k")[3] == []
+    short = ok.replace("s_nop 11", "s_nop 10")
+    assert len(ck.check(short, "k")[3]) == 1
+    # across a loop back-edge: the MFMA at the bottom of the loop, the read at its top
+    loop = head + ".LBB0_1:\n\tv_max_f32 v40, v0, v1\n" + "\ts_nop 3\n" * 2 + "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]\n" \
+        "\ts_cbranch_scc1 .LBB0_1\n\ts_nop 15\n\ts_endpgm\n"
+    assert len(ck.check(loop, "k")[3]) == 1
+    # a dependent MFMA (SrcC chain) is the compiler's business, an LDS write of the result is not
+    chain = head + "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], 0\n\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]\n" \
+        "\ts_nop 11\n\tds_write_b32 v50, v3\n\ts_endpgm\n"
+    assert ck.check(chain, "k")[3] == []
+    assert len(ck.check(chain.replace("s_nop 11", "s_nop 2"), "k")[3]) == 1
+    # transcendental result -> VALU: one instruction in between
+    tr = head + "\tv_exp_f32_e32 v1, v2\n\tv_cvt_pk_bf16_f32 v3, v1, v4\n\ts_endpgm\n"
+    assert len(ck.check(tr, "k")[3]) == 1
+    assert ck.check(tr.replace("\tv_cvt", "\ts_nop 0\n\tv_cvt"), "k")[3] == []

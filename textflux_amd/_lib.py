@@ -169,23 +169,38 @@ def _src_hash() -> str:
 
 def is_stale() -> bool:
     """True when libtextflux_hip.so is missing or was not built from the sources now in csrc/ (content hash kept in a
-    side file next to the library; mtimes do not survive the copy to the GPU box)."""
+    side file next to the library; mtimes do not survive the copy to the GPU box).  A library that arrives WITHOUT its
+    hash file (the file is git-ignored; a hand-copied build) is taken as it is: never recompiled behind the caller's back,
+    and usable where hipcc is absent."""
     if os.environ.get("TFX_LIB"):
         return not os.path.exists(LIB_PATH)          # an explicitly chosen build is the caller's business
-    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
+    if not os.path.exists(LIB_PATH):
         return True
+    if not os.path.exists(HASH_PATH):
+        return False
     with open(HASH_PATH) as f:
         return f.read().strip() != _src_hash()
 
 
 def build(force: bool = False) -> str:
-    """Compile textflux_amd/csrc for gfx950 into libtextflux_hip.so (hipcc cross-compiles without a GPU)."""
-    if force or is_stale():
-        r = subprocess.run(["make", "-C", CSRC, "-j8"] + (["-B"] if force else []), capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("building libtextflux_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
-        with open(HASH_PATH, "w") as f:
-            f.write(_src_hash() + "\n")
+    """Compile textflux_amd/csrc for gfx950 into libtextflux_hip.so (hipcc cross-compiles without a GPU).  Serialised by a
+    file lock (N torchrun ranks importing at once build once); a hash-triggered rebuild is unconditional (`make -B`): make
+    itself compares mtimes, which say nothing after a copy, and would leave a stale library next to a fresh hash."""
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            stale = is_stale()                        # re-checked under the lock: another rank may have just built it
+            if force or stale:
+                r = subprocess.run(["make", "-C", CSRC, "-j8", "-B"], capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError("building libtextflux_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+                with open(HASH_PATH, "w") as f:
+                    f.write(_src_hash() + "\n")
+            elif not os.path.exists(HASH_PATH) and not os.environ.get("TFX_LIB"):
+                pass                                  # shipped library without a hash: left alone (see is_stale)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -1,4 +1,7 @@
-"""Batched, multi-GPU batch driver: a JSON list of {image, mask, text} items -> one generated (and cropped) image per item.
+"""Batched, multi-GPU batch driver: a list of work items -> one generated (and cropped) image per item.  Two item schemas:
+the reference's `annos.json` entries {img_name, annotations: [{text, polygon}]} (scripts/run_eval.py:76-140: polygon -> mask,
+strip height int(w * text_height_ratio), glyph strip stacked on top, `full_images/` + `cropped_images/` outputs) and the plain
+{image, mask, text} triples of run_inference.py's rule.
 
 Counterpart of the reference's scripts/run_eval.py:76-247.  The reference starts one worker process per GPU; every worker
 holds a full replica (incl. the 9.5 GB T5 encoder), pulls ONE item at a time from a multiprocessing queue, encodes its own
@@ -9,9 +12,13 @@ prompts and calls the pipeline at batch 1.  Here (one process per GPU, launched 
   (`ops.compose_canvas`), including the callers' resize to a multiple of 32 (`ops.resample_u8`: Pillow's bicubic resampler
   in its own fixed-point arithmetic, bit-identical); items are grouped by pipeline geometry into batches of up to `batch_size` -- the engine's batch-8 rate is 13 % above its batch-1
   rate, and the captured step graph is reused across batches of one geometry;
-* batches are dealt round-robin to the ranks; in each round rank 0 encodes the T5 prompts of ALL ranks' batches (the CLIP
-  prompt is the one fixed template: encoded once, broadcast once) and scatters them -- 4 MiB per prompt over xGMI against
-  >= 1 s of denoising per image -- so ranks > 0 need no text encoders at all (`encode_rank0_only`);
+* batches are dealt round-robin to the ranks.  The CLIP prompt is the one fixed template: its pooled embedding is encoded ONCE
+  on rank 0 and broadcast (RCCL over xGMI).  The T5 prompts differ per image: when every rank holds a T5 encoder (9.5 GB of
+  288 GB; the default) each rank encodes the prompts of ITS OWN batch -- 0.06 s per 8 prompts, no rank waits for another, the
+  per-round critical path is the same on every rank.  Only when some rank has no T5 (`text_encoder_2 is None`) does rank 0
+  encode for everybody and scatter, 4 MiB per prompt -- then rank 0 carries world x the encoding work on top of its own
+  denoising and is the round's straggler by that much (3 % at world 8); an encoding failure on rank 0 marks that batch
+  failed on its owner (a flag travels with the rows) instead of leaving the other ranks blocked in the collective;
 * every rank denoises its batch with per-item generators seeded like the reference's single-image call (same noise per
   image as `run_inference.py --seed`), crops and writes its own results; a per-rank summary is gathered on rank 0.
 
@@ -40,6 +47,7 @@ class Work:
     meta: Dict[str, Any]
     size: Tuple[int, int]            # (width, height) given to the pipeline
     parts: Any = None                # (glyph, scene, mask uint8 arrays, horizontal): composed on the device per batch
+    name: Optional[str] = None       # eval schema: base file name written under full_images/ and cropped_images/
 
 
 @dataclass
@@ -48,10 +56,49 @@ class Batch:
     items: List[Work] = field(default_factory=list)
 
 
-def prepare_item(index: int, item: Dict[str, Any], loader: Optional[Callable] = None, device_compose: bool = False) -> Work:
-    """Host-side preparation of one item (run_inference.py:395-467 up to the pipeline call).  With device_compose the
-    stacking is left to the device when no resize is involved."""
+def eval_item_complete(item: Dict[str, Any]) -> bool:
+    """The reference's filter (scripts/run_eval.py:229-231): first annotation with a non-empty text and polygon."""
+    ann = item.get("annotations")
+    return bool(ann) and bool(ann[0].get("text")) and bool(ann[0].get("polygon"))
+
+
+def prepare_eval_item(index: int, item: Dict[str, Any], original_images_dir: str, font, text_height_ratio: float = 0.1667,
+                      loader: Optional[Callable] = None, device_compose: bool = False) -> Work:
+    """One `annos.json` entry -> Work (scripts/run_eval.py:76-112): scene = original_images_dir / img_name; mask = the first
+    annotation's polygon filled white on black; glyph strip of height int(w * text_height_ratio) -- a fraction of the image
+    WIDTH -- with the annotation's text, stacked on top with a black mask; pipeline size ((w // 32) * 32,
+    ((h + strip) // 32) * 32); T5 prompt generate_prompt([text])."""
+    import numpy as np
     from PIL import Image
+    load = loader or (lambda p: Image.open(p))
+    ann = item["annotations"][0]
+    text = ann["text"]
+    scene = load(os.path.join(original_images_dir, item["img_name"])).convert("RGB")
+    w, h = scene.size
+    strip = int(w * text_height_ratio)
+    g = np.array(glyph.draw_glyph(font, text, w, strip))
+    m = glyph.fill_polygon(h, w, ann["polygon"])
+    meta = dict(mode="singleline", direction="vertical", strip=strip, orig_h=h)
+    size = ((w // 32) * 32, ((h + strip) // 32) * 32)
+    prompt = glyph.generate_prompt([text])
+    name = os.path.basename(item["img_name"])
+    if device_compose:
+        return Work(index, None, None, prompt, meta, size, parts=(g, np.array(scene), m, False), name=name)
+    combined = Image.fromarray(np.vstack((g, np.array(scene))))
+    cmask = Image.fromarray(np.vstack((np.zeros_like(g), m)))
+    return Work(index, combined.resize(size), cmask.resize(size), prompt, meta, size, name=name)
+
+
+def prepare_item(index: int, item: Dict[str, Any], loader: Optional[Callable] = None, device_compose: bool = False,
+                 eval_cfg: Optional[Dict[str, Any]] = None) -> Work:
+    """Host-side preparation of one item (run_inference.py:395-467 up to the pipeline call).  With device_compose the
+    stacking is left to the device when no resize is involved.  Items in the reference's `annos.json` schema (an `img_name`
+    key) go through prepare_eval_item with eval_cfg = dict(original_images_dir, font, text_height_ratio)."""
+    from PIL import Image
+    if "img_name" in item:
+        c = eval_cfg or {}
+        return prepare_eval_item(index, item, c.get("original_images_dir", "."), c.get("font") or glyph.load_font(c.get("font_path")),
+                                 c.get("text_height_ratio", 0.1667), loader, device_compose)
     load = loader or (lambda p: Image.open(p))
     scene, mask = load(item["image"]).convert("RGB"), load(item["mask"]).convert("RGB")
     words = glyph.read_words_from_text(item["text"])
@@ -117,36 +164,64 @@ def _scatter(rows: Optional[List[torch.Tensor]], shape, dtype, device) -> torch.
     return out
 
 
+def _flag_min(v: int, device) -> int:
+    """min over ranks of an int (1 rank: the value itself)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return v
+    t = torch.tensor([v], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 @torch.no_grad()
 def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], batch_size: int = 8, num_inference_steps: int = 30,
               guidance_scale: float = 30.0, seed: int = 42, device="cuda", loader: Optional[Callable] = None,
-              save: Optional[Callable] = None, max_sequence_length: int = 512) -> Dict[str, Any]:
-    """Runs the whole list; returns {"done": [indices this rank wrote], "failed": [...], "all_done": [...] on rank 0}.
-    `pipe` needs `encode_prompt(prompt, prompt_2, ...)` (rank 0 only) and the FluxFillPipeline `__call__`."""
+              save: Optional[Callable] = None, max_sequence_length: int = 512, eval_cfg: Optional[Dict[str, Any]] = None,
+              encode: str = "auto", save_full: Optional[Callable] = None) -> Dict[str, Any]:
+    """Runs the whole list; returns {"done": [indices this rank wrote], "failed": [...], "all_done": [...] on rank 0,
+    "encode": "local" | "rank0"}.  `pipe` needs `encode_prompt(prompt, prompt_2, ...)` and the FluxFillPipeline `__call__`.
+    encode: "local" = every rank encodes the T5 prompts of its own batches (needs a T5 on every rank), "rank0" = rank 0
+    encodes for all and scatters, "auto" = local when every rank has `pipe.text_encoder_2`, else rank0.
+    Outputs: eval-schema items (Work.name set) are written as out_dir/full_images/<name> and out_dir/cropped_images/<name>
+    (or handed to save_full(work, full, cropped)); other items as out_dir/<index>.png (or save(index, cropped))."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     works, failed = [], []
     for i, it in enumerate(items):
         try:
-            works.append(prepare_item(i, it, loader, device_compose=bool(getattr(pipe, "supports_device_compose", False))))
+            works.append(prepare_item(i, it, loader, device_compose=bool(getattr(pipe, "supports_device_compose", False)),
+                                      eval_cfg=eval_cfg))
         except Exception as e:       # per-item failures do not stop the run (reference :195-198)
             failed.append(i)
             if rank == 0:
                 print(f"item {i} failed in preparation: {e}")
     plan = plan_batches(works, batch_size)
     rounds = (len(plan) + world - 1) // world
-    # ---- the CLIP prompt is one fixed template: pooled embedding encoded once on rank 0, broadcast once
-    pooled1 = pe_shape = dtype = None
+    if encode == "auto":
+        has_t5 = 1 if (getattr(pipe, "text_encoder_2", None) is not None or getattr(pipe, "encodes_locally", False)) else 0
+        encode = "local" if _flag_min(has_t5, device) == 1 else "rank0"
+    if encode not in ("local", "rank0"):
+        raise ValueError("encode must be 'auto', 'local' or 'rank0'")
+    # ---- the CLIP prompt is one fixed template: pooled embedding encoded once on rank 0, broadcast once.  meta[0] < 0 is the
+    # abort flag: a failure on rank 0 reaches every rank through the same broadcast the others are waiting in
+    pooled1 = None
+    err0 = None
     if rank == 0:
-        pe1, pooled1, _ = pipe.encode_prompt(prompt=glyph.PROMPT_TEMPLATE2, prompt_2=glyph.PROMPT_TEMPLATE2, device=device,
-                                             max_sequence_length=max_sequence_length)
-        meta = [pe1.shape[1], pe1.shape[2], pooled1.shape[1], {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}[pe1.dtype]]
+        try:
+            pe1, pooled1, _ = pipe.encode_prompt(prompt=glyph.PROMPT_TEMPLATE2, prompt_2=glyph.PROMPT_TEMPLATE2, device=device,
+                                                 max_sequence_length=max_sequence_length)
+            meta = [pe1.shape[1], pe1.shape[2], pooled1.shape[1], {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}[pe1.dtype]]
+        except Exception as e:
+            err0, meta = e, [-1, 0, 0, 0]
     else:
         meta = [0, 0, 0, 0]
     if world > 1:
         mt = torch.tensor(meta, dtype=torch.int64, device=device)
         dist.broadcast(mt, src=0)
         meta = [int(v) for v in mt.tolist()]
+    if meta[0] < 0:
+        raise RuntimeError(f"rank 0 could not encode the prompt template: {err0}" if rank == 0 else
+                           "rank 0 could not encode the prompt template (see its log)")
     T, J, P, dcode = meta
     dtype = {0: torch.bfloat16, 1: torch.float32, 2: torch.float16}[dcode]
     if rank != 0:
@@ -156,28 +231,45 @@ def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], bat
     done: List[int] = []
     for r in range(rounds):
         mine = plan[r * world + rank] if r * world + rank < len(plan) else None
-        # ---- rank 0 encodes the T5 prompts of every rank's batch of this round (padded to batch_size rows) and scatters
-        rows = None
-        if rank == 0:
-            rows = []
-            for k in range(world):
-                b = plan[r * world + k] if r * world + k < len(plan) else None
-                buf = torch.zeros(batch_size, T, J, dtype=dtype, device=device)
-                if b is not None:
-                    prompts = [w.prompt for w in b.items]
-                    pe, _, _ = pipe.encode_prompt(prompt=[glyph.PROMPT_TEMPLATE2] * len(prompts), prompt_2=prompts,
-                                                  device=device, max_sequence_length=max_sequence_length)
-                    buf[:len(prompts)] = pe.to(dtype)
-                rows.append(buf)
-        pe_mine = _scatter(rows, (batch_size, T, J), dtype, device)
+        pe_mine, enc_ok = None, True
+        if encode == "rank0":
+            # ---- rank 0 encodes the T5 prompts of every rank's batch of this round (padded to batch_size rows, one more row
+            # whose first element is the ok flag) and scatters; a failed encode sends zero rows + flag 0 -- collectives stay matched
+            rows = None
+            if rank == 0:
+                rows = []
+                for k in range(world):
+                    b = plan[r * world + k] if r * world + k < len(plan) else None
+                    buf = torch.zeros(batch_size + 1, T, J, dtype=dtype, device=device)
+                    buf[batch_size, 0, 0] = 1
+                    if b is not None:
+                        try:
+                            prompts = [w.prompt for w in b.items]
+                            pe, _, _ = pipe.encode_prompt(prompt=[glyph.PROMPT_TEMPLATE2] * len(prompts), prompt_2=prompts,
+                                                          device=device, max_sequence_length=max_sequence_length)
+                            buf[:len(prompts)] = pe.to(dtype)
+                        except Exception as e:
+                            buf[batch_size, 0, 0] = 0
+                            print(f"[rank 0] encoding the prompts of batch {r * world + k} failed: {e}")
+                    rows.append(buf)
+            got = _scatter(rows, (batch_size + 1, T, J), dtype, device)
+            pe_mine, enc_ok = got[:batch_size], bool(float(got[batch_size, 0, 0]) != 0)
         if mine is None:
             continue
         n = len(mine.items)
         try:
+            if not enc_ok:
+                raise RuntimeError("rank 0 failed to encode this batch's prompts")
+            if encode == "local":   # this rank's own prompts, no collective: nobody waits for anybody
+                prompts = [w.prompt for w in mine.items]
+                pe_mine, _, _ = pipe.encode_prompt(prompt=[glyph.PROMPT_TEMPLATE2] * n, prompt_2=prompts, device=device,
+                                                   max_sequence_length=max_sequence_length)
+                pe_mine = pe_mine.to(dtype)
             gens = [torch.Generator(device=device).manual_seed(int(seed)) for _ in range(n)]   # run_inference.py:76, per image
             boxes = [glyph.crop_box(w.size, w.meta) for w in mine.items]
+            keep_full = any(w.name is not None for w in mine.items)   # eval schema: the uncropped result is an output too
             same_box = all(bx == boxes[0] for bx in boxes)      # one crop window for the whole batch: applied on the device
-            kw = dict(output_crop=boxes[0]) if same_box and getattr(pipe, "supports_output_crop", False) else {}
+            kw = dict(output_crop=boxes[0]) if same_box and not keep_full and getattr(pipe, "supports_output_crop", False) else {}
             img_in, mask_in = _batch_inputs(mine.items, device)
             images = pipe(height=mine.size[1], width=mine.size[0], image=img_in,
                           mask_image=mask_in, num_inference_steps=num_inference_steps, generator=gens,
@@ -185,7 +277,13 @@ def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], bat
                           prompt_embeds=pe_mine[:n], pooled_prompt_embeds=pooled1.expand(n, -1).contiguous(), **kw).images
             for w, img, bx in zip(mine.items, images, boxes):
                 cropped = img if kw else img.crop(bx)
-                if save is not None:
+                if w.name is not None and (save_full is not None or (save is None and out_dir is not None)):
+                    if save_full is not None:
+                        save_full(w, img, cropped)
+                    else:
+                        img.save(os.path.join(out_dir, "full_images", w.name))
+                        cropped.save(os.path.join(out_dir, "cropped_images", w.name))
+                elif save is not None:
                     save(w.index, cropped)
                 elif out_dir is not None:
                     cropped.save(os.path.join(out_dir, f"{w.index:06d}.png"))
@@ -194,7 +292,7 @@ def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], bat
             failed.extend(w.index for w in mine.items)
             print(f"[rank {rank}] batch of {n} at {mine.size} failed: {e}")
     # ---- summary on rank 0
-    res: Dict[str, Any] = {"done": done, "failed": failed, "batches": len(plan), "rounds": rounds}
+    res: Dict[str, Any] = {"done": done, "failed": failed, "batches": len(plan), "rounds": rounds, "encode": encode}
     if world > 1:
         cnt = torch.zeros(len(items) + 1, dtype=torch.int32, device=device)
         for i in done:

@@ -798,9 +798,12 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     if (prof) prof_end(1, st);
     return rc ? rc : check_launch("joint_attention");
   }
-  // option 30: whole-row 16-byte output stores; its K / V buffer descriptors cover one head's rows with a 32-bit byte count
-  const bool w4_ok = (a.ldo | a.o_bstride) % 8 == 0 && (uint64_t)(a.N - 1) * (uint64_t)a.ldk * 2 + 256 < (1ull << 32) &&
-                     (uint64_t)(a.N - 1) * (uint64_t)a.ldv * 2 + 256 < (1ull << 32);
+  // option 30: whole-row 16-byte output stores; its K / V buffer descriptors cover one head's rows with a 32-bit byte count,
+  // and its pipeline requests up to three 64-key tiles past the last one: those offsets are computed in 32 bits too and must
+  // stay beyond the descriptor's range (zero fill) instead of wrapping back into it
+  const uint64_t w4_rows = (uint64_t)((a.N + 63) / 64 + 3) * 64;
+  const bool w4_ok = (a.ldo | a.o_bstride) % 8 == 0 && w4_rows * (uint64_t)a.ldk * 2 + 256 < (1ull << 32) &&
+                     w4_rows * (uint64_t)a.ldv * 2 + 256 < (1ull << 32);
   if (g_attn_waves == 30 && w4_ok) {
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);

@@ -78,6 +78,22 @@ constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
                "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"      \
                "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 
+// The scores are read by inline-asm VALU instructions (below), which hipcc's hazard recogniser does not see as VALU: it would
+// not insert the wait states an MFMA result needs before a VALU read (8-pass MFMA: 11).  W4_TOUCH(acc) is a COMPILER-VISIBLE
+// VALU read of the accumulator tuple (v_readfirstlane_b32 of one element; the hazard is tracked per destination tuple) placed
+// in program order before the first asm read: the recogniser pads in front of IT, whatever a future compiler or a schedule
+// change does to the distance, and every later read is at least as far from the MFMA.  tools/check_mfma_hazard.py verifies
+// the emitted ISA (tests/test_isa_hazards.py; -DW4_NO_TOUCH removes the touch and shortens the distance: the self-test).
+#ifndef W4_NO_TOUCH
+#define W4_TOUCH(acc)                                                                  \
+  do {                                                                                 \
+    const int t_ = __builtin_amdgcn_readfirstlane(__float_as_int((acc)[0]));           \
+    asm volatile("" ::"s"(t_));                                                        \
+  } while (0)
+#else
+#define W4_TOUCH(acc) do { } while (0)
+#endif
+
 __device__ __forceinline__ void w4_mfma_s0(f32x16& d, const bf16x8& k, const bf16x8& q) {
   f32x16 z;
 #pragma unroll
@@ -370,6 +386,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     // VALU read, and hipcc cannot insert that wait in front of the inline-asm maxima (it does not know they are VALU).
     float mx = 0.f;
     S(IC<0>{});
+    W4_TOUCH(cur);
     if constexpr (!(W4_ABL & 8)) mx = w4_max7(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6]);
     W4_GAP();
     S(IC<1>{});
@@ -429,6 +446,9 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     P(IC<6>{}); F(IC<18>{}); F(IC<19>{}); G(IC<9>{});
     W4_GAP();
     S(IC<8>{}); F(IC<20>{}); F(IC<21>{}); G(IC<10>{});
+#ifdef W4_HAZARD_SELFTEST   // a score read from inline asm two instructions behind its chain's last MFMA: what check_mfma_hazard.py must catch
+    { const float t_ = w4_max(nxt[0], nxt[1]); asm volatile("" ::"v"(t_)); }
+#endif
     W4_GAP();
     P(IC<7>{}); F(IC<22>{}); G(IC<11>{});
     W4_GAP();

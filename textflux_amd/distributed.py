@@ -85,6 +85,16 @@ def broadcast_conditioning(prompt_embeds: Optional[torch.Tensor], pooled: Option
     return prompt_embeds, pooled
 
 
+def broadcast_tensor(t: Optional[torch.Tensor], shape, dtype, device, src: int = 0) -> torch.Tensor:
+    """One tensor from rank `src` to everybody (the others pass None)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    t = torch.empty(shape, dtype=dtype, device=device) if rank != src else t.to(device, dtype).contiguous()
+    if world > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
 def gather_to_rank0(t: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
     """Equal-shape gather of per-rank results (final latents / images) on rank `dst`."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

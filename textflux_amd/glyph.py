@@ -68,6 +68,24 @@ def draw_glyph(font, text: str, width: int, height: int, max_font_size: int = 14
     return img
 
 
+def fill_polygon(height: int, width: int, polygon) -> np.ndarray:
+    """uint8 [height, width, 3] mask: the polygon (list of [x, y] vertices, truncated to ints as np.int32 does) filled white on
+    black, boundary pixels included -- the reference's cv2.fillPoly(zeros, [polygon], (255, 255, 255)) (scripts/run_eval.py:
+    92-96).  cv2 is absent here; PIL's scan-line polygon fill plus its outline follows the same rule (interior by scan line,
+    edges drawn as lines): identical for the axis-aligned and convex cases of tests/test_host_logic.py, pixel parity on
+    arbitrary slanted edges is unpinned."""
+    pts = [(int(p[0]), int(p[1])) for p in np.asarray(polygon).reshape(-1, 2).tolist()]
+    m = Image.new("L", (width, height), 0)
+    d = ImageDraw.Draw(m)
+    if len(pts) == 1:
+        d.point(pts, fill=255)
+    elif len(pts) == 2:
+        d.line(pts, fill=255)
+    elif len(pts) > 2:
+        d.polygon(pts, fill=255, outline=255)
+    return np.repeat(np.array(m)[:, :, None], 3, axis=2)
+
+
 def render_single_line(scene: Image.Image, words: Sequence[str], font_path: Optional[str] = None):
     w, _ = scene.size
     strip_h = int(w * TEXT_HEIGHT_RATIO)
