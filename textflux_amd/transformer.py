@@ -208,32 +208,60 @@ class FluxTransformer2DModel:
     @classmethod
     def from_pretrained(cls, path: str, subfolder: Optional[str] = None, torch_dtype=BF16, device="cuda", **_):
         """Reads the HF layout: config.json + diffusion_pytorch_model.safetensors or the sharded form with
-        diffusion_pytorch_model.safetensors.index.json (D/models/modeling_utils.py:468)."""
-        from safetensors import safe_open
+        diffusion_pytorch_model.safetensors.index.json (D/models/modeling_utils.py:468), streamed straight
+        into the fused device layout (loader.ShardStreamer: mmap, pinned double-buffered staging, asynchronous H2D)."""
+        from . import loader
         if torch_dtype not in (BF16, None):
             raise ValueError("the HIP engine computes in bf16; pass torch_dtype=torch.bfloat16")
         root = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(root, cls.config_name)) as f:
             model = cls.from_config(json.load(f))
-        index = os.path.join(root, "diffusion_pytorch_model.safetensors.index.json")
-        if os.path.exists(index):
-            with open(index) as f:
-                files = sorted(set(json.load(f)["weight_map"].values()))
-        else:
-            files = ["diffusion_pytorch_model.safetensors"]
+        files = loader.shard_files(root, "diffusion_pytorch_model")
         model._alloc(device)
+        # routing table: reference key -> row slice of the fused device matrix it lands in (the concatenation IS the copy)
+        route: Dict[str, torch.Tensor] = {}
+        for key, name, off in model._fusion_map():
+            wt, bs = model.w[name + ".w"], model.w[name + ".b"]
+            rows = model._rows_of(key)
+            route[key + ".weight"], route[key + ".bias"] = wt[off:off + rows], bs[off:off + rows]
+        for key, name in model._norm_map():
+            route[key] = model.w[name]
         seen = set()
-        for fn in files:  # shard by shard: never more than one shard resident on the host
-            sd = {}
-            with safe_open(os.path.join(root, fn), framework="pt", device="cpu") as f:
-                for k in f.keys():
-                    sd[k] = f.get_tensor(k)
-            seen.update(sd)
-            model.load_state_dict(sd, strict=False, device=device)
+
+        def pick(k, shape, dt):
+            dst = route.get(k)
+            if dst is None:
+                return None
+            if tuple(dst.shape) != tuple(shape):
+                raise RuntimeError(f"{k}: checkpoint shape {tuple(shape)} != model shape {tuple(dst.shape)}")
+            seen.add(k)
+            return dst
+
+        st = loader.ShardStreamer(device)
+        for fn in files:      # shard by shard, tensor by tensor in file order, through pinned double-buffered async copies
+            st.stream_file(os.path.join(root, fn), pick)
+        st.finish()
+        model.load_stats = dict(bytes=st.bytes_moved, files=len(files))
         missing = [k for k in model.expected_keys() if k not in seen]
         if missing:
             raise RuntimeError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:3]}")
+        model._session = None
         return model
+
+    def _rows_of(self, key: str) -> int:
+        """Output rows of the reference Linear `key` (its weight is [rows, in])."""
+        D = self.inner_dim
+        if key.endswith("norm1.linear") or key.endswith("norm1_context.linear"):
+            return 6 * D
+        if key.endswith(".norm.linear"):
+            return 3 * D
+        if key == "norm_out.linear":
+            return 2 * D
+        if key.endswith((".net.0.proj", ".proj_mlp")):
+            return 4 * D
+        if key == "proj_out":
+            return self.out_channels
+        return D
 
     def to(self, device=None, dtype=None):
         if dtype is not None and dtype != BF16:
