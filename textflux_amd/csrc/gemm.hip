@@ -124,9 +124,8 @@ constexpr int GLDS_AUX = 0;        // default cache policy of the operand prefet
 constexpr int LDS_X = 0;            // X_g set s at g*32768 + s*16384   (128 rows x 128 B)
 constexpr int LDS_W = 65536;        // W   set s at 65536 + s*32768     (256 rows x 128 B)
 constexpr int LDS_DUMMY = 131072;   // 8 x 1 KiB sink for out-of-range prefetches (keeps vmcnt counts uniform)
-constexpr int EPI_ROW_BYTES = 144;                  // 128 B of output columns + 16 B pad (bank spread, 16-B aligned)
-constexpr int EPI_WAVE_BYTES = 128 * EPI_ROW_BYTES;  // epilogue staging: 18 KiB per wave, reuses the operand buffers
-constexpr int LDS_TOTAL = 8 * EPI_WAVE_BYTES;        // 147456 >= 131072 + 8192 (operand sets + sink)
+constexpr int LDS_TOTAL = LDS_DUMMY + 8192;          // one-tile kernel: operand sets + sink (its epilogue stages inside the sets)
+constexpr int STG_WAVE = 4096;      // epilogue staging per wave: 32 rows x 128 B, XOR-swizzled 16-byte chunks
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -143,6 +142,245 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* smem, uint32_t lds
     __builtin_amdgcn_s_barrier();              \
     __builtin_amdgcn_sched_barrier(0);         \
   } while (0)
+
+#define TFX_CAT(lo_, hi_) __builtin_shufflevector(__builtin_bit_cast(i32x4, lo_), __builtin_bit_cast(i32x4, hi_), 0, 1, 2, 3, 4, 5, 6, 7)
+
+// One MFMA section of a wave: the 4 x 2 block of 16 x 16 accumulators (64 token rows x 32 output columns) advanced by one 64-deep
+// K-tile.  bf16: 2 k-steps of v_mfma_f32_16x16x32_bf16 = 16 MFMAs of 4 passes (the two MFMAs of one accumulator are 8 apart:
+// no dependent pair is ever back to back); e4m3: one v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) per accumulator =
+// 8 MFMAs of 8 passes.  256 matrix-pipe cycles either way.  WF[j][s] / XF[i][s]: fragment of column block j / row block i, 16-byte
+// piece s of the lane's K-tile bytes.
+template <bool FP8, bool HALF = false, int S0 = 0>
+__device__ __forceinline__ void mfma_section(f32x4 (&acc)[8][4], const bf16x8 (&WF)[2][2], const bf16x8 (&XF)[4][2], const int MIB,
+                                             const int NJB) {
+  if constexpr (FP8) {
+#pragma unroll
+    for (int j = (HALF ? S0 : 0); j < (HALF ? S0 + 1 : 2); ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[MIB + i][NJB + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(TFX_CAT(WF[j][0], WF[j][1]), TFX_CAT(XF[i][0], XF[i][1]),
+                                                                                 acc[MIB + i][NJB + j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  } else {
+#pragma unroll
+    for (int s = (HALF ? S0 : 0); s < (HALF ? S0 + 1 : 2); ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[MIB + i][NJB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j][s], XF[i][s], acc[MIB + i][NJB + j], 0, 0, 0);
+  }
+}
+// the intrinsics are pure: nothing but this keeps hipcc from moving a section's MFMAs across the barriers around it
+#define TFX_PIN_SECTION(MIB, NJB)                                                                                        \
+  do {                                                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                    \
+        asm volatile("" : "+v"(acc[(MIB) + i_][(NJB) + j_]));                                                            \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue of one 256 x 256 tile, shared by the two MFMA kernels.  With the operands swapped (MFMA "A" = weight rows, "B" =
+// token rows) lane l of a wave holds, per (mi, nj), FOUR CONSECUTIVE OUTPUT COLUMNS of one token row:
+//     m = m0 + g*128 + mi*16 + (l & 15),    n = n0 + wc*64 + nj*16 + (l >> 4)*4 + e,   e = 0..3,  mi = 0..7, nj = 0..3.
+// bias / GELU / gate are applied in fp32 on those; the bf16 results cross a wave-private LDS tile (32 rows x 128 B per
+// 32-row block, 16-byte chunks XOR-swizzled with (row >> 1) & 7: conflict-free 8-byte writes and 16-byte reads) and leave as
+// 16-byte stores in which 8 lanes cover one full 128-byte line of a row.  Everything the epilogue needs from memory (bias,
+// gate, the first residual rows) is requested up front and waited for once; residual rows of later blocks RES_DEPTH blocks
+// ahead of their use.  FP8: the accumulators are first dequantised in place (row scale x channel scale).  QKN: tiles inside
+// the q / k column ranges get the per-head RMSNorm + RoPE (see gemm8pp_kernel).  `stg`: this wave's 4 KiB staging tile,
+// `stg_partner`: the staging tile of the wave that owns the other 64 columns of this wave's heads (QKN only).
+template <int EPI, bool FP8, bool QKN, int RES_DEPTH>
+__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmParams& p, const int m0, const int n0, const int b,
+                                              const int g, const int wc, const int lane, char* stg, const char* stg_partner) {
+  // lane-derived offsets are rebuilt from an opaque copy of the lane id: derived from `lane` they are loop invariants that
+  // hipcc keeps in ~20 VGPRs across the K loop, which is what pushes the kernel into spilling
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int q_e = lane_e >> 4, r16 = lane_e & 15;
+  const int ncol = n0 + wc * 64 + q_e * 4;
+  const bool do_gelu = (EPI == EPI_BIAS_GELU) && (n0 >= p.gelu_from);
+  const int crow = lane_e >> 3, cchunk = lane_e & 7;
+  const int nst = n0 + wc * 64 + cchunk * 8;
+  constexpr bool HAS_RES = (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES);
+  const bf16_t* resp = HAS_RES ? p.res + b * p.r_bs + min(nst, p.N - 8) : nullptr;
+  auto load_res = [&](int blk, u32x4 (&rr)[4]) {
+#pragma unroll
+    for (int itr = 0; itr < 4; ++itr) {
+      const int m = min(m0 + g * 128 + blk * 32 + itr * 8 + crow, p.M - 1);
+      rr[itr] = *reinterpret_cast<const u32x4*>(resp + (int64_t)m * p.ldr);
+    }
+  };
+  if constexpr (FP8) {
+    // dequantise in place first (row scale x channel scale): the scale registers are dead before bias / gate / residual are
+    // requested.  Costs a second memory round trip per tile, saves the spills of holding both sets.
+    float sa[8];
+    f32x4 sw[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) sa[mi] = p.a_scale[b * p.as_bs + min(m0 + g * 128 + mi * 16 + r16, p.M - 1)];
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+      const int n = ncol + nj * 16;
+      sw[nj] = *reinterpret_cast<const f32x4*>(p.w_scale + (n < p.N ? n : 0));
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mi][nj][e] = (acc[mi][nj][e] * sa[mi]) * sw[nj][e];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  u32x2 bsr[4], gtr[4];   // bias / gate stay packed (bf16 pairs) until they are used
+  u32x4 rr[RES_DEPTH][4];
+#pragma unroll
+  for (int nj = 0; nj < 4; ++nj) {
+    const int n = ncol + nj * 16;
+    const int nc = n < p.N ? n : 0;  // columns beyond N are computed but never stored
+    bsr[nj] = p.bias ? *reinterpret_cast<const u32x2*>(p.bias + nc) : u32x2{0u, 0u};
+    if (EPI == EPI_BIAS_GATE_RES) gtr[nj] = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + nc);
+  }
+  if (HAS_RES) {
+#pragma unroll
+    for (int d = 0; d < RES_DEPTH; ++d) load_res(d, rr[d]);
+  }
+  const bool in_q = QKN && n0 >= p.nq0 && n0 < p.nq1;
+  const bool norm_tile = QKN && (in_q || (n0 >= p.nk0 && n0 < p.nk1));      // block-uniform
+  // every operand request of this tile's K loop (incl. the next tile's first K-tiles) is older than the stores below;
+  // loads and stores retire out of order with respect to each other, so the counted waits of the next K loop are only
+  // meaningful once these have landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float rinv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  u32x4 nw8 = u32x4{0u, 0u, 0u, 0u};     // norm weights of the 8 columns this lane stores (norm tiles)
+  if (norm_tile) {
+    nw8 = *reinterpret_cast<const u32x4*>((in_q ? p.nq_w : p.nk_w) + (wc & 1) * 64 + cchunk * 8);
+    // Linear output in bf16 (what the reference's RMSNorm sees), in place; sum of squares of this lane's 16 columns, then of
+    // the row's 64 columns in this wave (the four lanes l, l ^ 16, l ^ 32, l ^ 48 hold one row)
+    float ss[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      ss[mi] = 0.f;
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) {
+        const u32x2 br = bsr[nj];
+        const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
+                             __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = round_bf(acc[mi][nj][e] + bs[e]);
+          acc[mi][nj][e] = x;
+          ss[mi] += x * x;
+        }
+      }
+      ss[mi] += __shfl_xor(ss[mi], 16, 64);
+      ss[mi] += __shfl_xor(ss[mi], 32, 64);
+    }
+    if (q_e == 0) {
+      *reinterpret_cast<f32x4*>(stg + r16 * 32) = f32x4{ss[0], ss[1], ss[2], ss[3]};
+      *reinterpret_cast<f32x4*>(stg + r16 * 32 + 16) = f32x4{ss[4], ss[5], ss[6], ss[7]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TFX_BARRIER();                                 // both stripes of every head have published their sums
+    const f32x4 o0 = *reinterpret_cast<const f32x4*>(stg_partner + r16 * 32);
+    const f32x4 o1 = *reinterpret_cast<const f32x4*>(stg_partner + r16 * 32 + 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TFX_BARRIER();                                 // ... and read the partner's, before the staging areas are reused below
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) rinv[mi] = rsqrtf((ss[mi] + (mi < 4 ? o0[mi & 3] : o1[mi & 3])) * (1.0f / 128.0f) + p.n_eps);
+  }
+  auto store_blocks = [&](auto NORM_T) __attribute__((always_inline)) {
+    constexpr bool NORM = decltype(NORM_T)::value;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      // (cos, sin) pairs of the four rows this lane stores from this row block, requested before the block is converted
+      // and staged (the latency hides behind that work)
+      f32x4 csr[4][2];
+      if (NORM) {
+#pragma unroll
+        for (int itr = 0; itr < 4; ++itr) {
+          const int mrow = min(m0 + g * 128 + blk * 32 + itr * 8 + crow, p.M - 1);
+          const float* cs = p.rope_cs + (int64_t)(p.rope_pos0 + mrow) * 128 + (wc & 1) * 64 + cchunk * 8;
+          csr[itr][0] = *reinterpret_cast<const f32x4*>(cs);
+          csr[itr][1] = *reinterpret_cast<const f32x4*>(cs + 4);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int mi = blk * 2 + h;
+        const int R = h * 16 + r16;                 // row inside the 32-row staging tile
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+          const u32x2 br = bsr[nj];
+          const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
+                               __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
+          float v[4];
+          if (NORM) {      // already bias-added and bf16-rounded by the pre-pass; normalised + rotated after the transpose
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][e] + bs[e];
+          }
+          if (do_gelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+          }
+          if (EPI == EPI_BIAS_GATE_RES) {
+            const u32x2 gr = gtr[nj];
+            const float gt[4] = {__uint_as_float(gr[0] << 16), __uint_as_float(gr[0] & 0xffff0000u),
+                                 __uint_as_float(gr[1] << 16), __uint_as_float(gr[1] & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gt[e] * round_bf(v[e]);
+          }
+          u32x2 o;
+          o[0] = pack_bf2(v[0], v[1]);
+          o[1] = pack_bf2(v[2], v[3]);
+          // columns nj*16 + q*4 .. +4 of row R = 8-byte half (q & 1) of 16-byte chunk nj*2 + (q >> 1), stored at chunk ^ ((R >> 1) & 7):
+          // the 16 lanes of a ds_write_b64 group (one q, rows 0..15) touch 16 different 16-byte slots of the 256-byte bank line
+          *reinterpret_cast<u32x2*>(stg + R * 128 + (((nj * 2 + (q_e >> 1)) ^ ((R >> 1) & 7)) << 4) + ((q_e & 1) << 3)) = o;
+        }
+      }
+      // wave-private region + in-order LDS pipe: no barrier between the writes above and the reads below
+      if (QKN) __builtin_amdgcn_sched_barrier(0);   // keeps the table loads of later row blocks from being hoisted over live accumulators
+#pragma unroll
+      for (int itr = 0; itr < 4; ++itr) {
+        const int row = itr * 8 + crow;
+        const int m = m0 + g * 128 + blk * 32 + row;
+        u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((cchunk ^ ((row >> 1) & 7)) << 4));
+        if (NORM) {
+          // this lane now holds 8 consecutive columns (4 rotation pairs) of row `row`: its 1/rms sits in every lane whose l & 15 is
+          // that row's index in its 16-row block, its (cos, sin) pairs are 32 contiguous bytes of the table
+          const float rr_row = __shfl(rinv[blk * 2 + (itr >> 1)], row & 15, 64);
+          const f32x4 c0 = csr[itr][0], c1 = csr[itr][1];
+          float x[8], wv[8], y[8], o8[8];
+          unpack8(val, x);
+          unpack8(nw8, wv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = round_bf(round_bf(x[e] * rr_row) * wv[e]);
+          o8[0] = y[0] * c0[0] + (-y[1]) * c0[1];  o8[1] = y[1] * c0[0] + y[0] * c0[1];
+          o8[2] = y[2] * c0[2] + (-y[3]) * c0[3];  o8[3] = y[3] * c0[2] + y[2] * c0[3];
+          o8[4] = y[4] * c1[0] + (-y[5]) * c1[1];  o8[5] = y[5] * c1[0] + y[4] * c1[1];
+          o8[6] = y[6] * c1[2] + (-y[7]) * c1[3];  o8[7] = y[7] * c1[2] + y[6] * c1[3];
+          val = pack8(o8);
+        }
+        if (HAS_RES) {
+          float fv[8], fr[8];
+          unpack8(val, fv);
+          unpack8(rr[blk % RES_DEPTH][itr], fr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+          val = pack8(fv);
+        }
+        if (m < p.M && nst < p.N) *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
+      }
+      if (HAS_RES && blk + RES_DEPTH < 4) {
+        load_res(blk + RES_DEPTH, rr[blk % RES_DEPTH]);   // in flight while the next block is converted and staged
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (QKN) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (QKN && norm_tile) store_blocks(std::true_type{});
+  else store_blocks(std::false_type{});
+}
 
 // ABL (bench-only ablations with WRONG results by construction, never dispatched by the product path; tools/
 // bench_gemm_abl.py, gemm_abl2.py, energy_probe.py): bit 0 no operand requests in the main loop, bit 1 no LDS fragment
@@ -283,25 +521,25 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
                                                  (ABL & 65536) ? 0 : kt * 128, 0, kAux);
   };
 
-  // ---- fragment read addresses (set 0); per-lane swizzle key is (lane>>1)&7 because fragment rows are
-  // 32-aligned block + (lane & 31).
-  const int hi = lane >> 5;
-  const int key = (lane >> 1) & 7;
-  uint32_t fx[4], fw[4];
+  // ---- fragment read addresses (set 0).  v_mfma_f32_16x16x32_bf16: lane l supplies row (l & 15) of a 16-row block and the 8
+  // k-values 8 * (l >> 4) .. of a 32-deep k-step, i.e. 16-byte chunk 4 s + (l >> 4) of the row's 128-byte K-tile (k-step s);
+  // rows are 16-aligned block + (l & 15), so the swizzle key (row >> 1) & 7 is (l & 15) >> 1
+  const int r16 = lane & 15, q4 = lane >> 4;
+  uint32_t fx[2], fw[2];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const uint32_t o = (lane & 31) * 128 + (((kk * 2 + hi) ^ key) << 4);
-    fx[kk] = LDS_X + g * 32768 + o;
-    fw[kk] = LDS_W + wc * 64 * 128 + o;
+  for (int s = 0; s < 2; ++s) {
+    const uint32_t o = r16 * 128 + (((4 * s + q4) ^ (r16 >> 1)) << 4);
+    fx[s] = LDS_X + g * 32768 + o;
+    fw[s] = LDS_W + wc * 64 * 128 + o;
   }
 
-  f32x16 acc[4][2];
+  f32x4 acc[8][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
   // ---- prologue: all of tile 0, plus the part of tile 1 that the steady state would have issued
   // during "tile -1" (the (u+2)-type items).
@@ -313,41 +551,43 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   TFX_BARRIER();
   if (g == 1) TFX_BARRIER();  // stagger: G1 runs one barrier behind G0
 
-  bf16x8 xf[2][4], wlo[4], whi[4];
+  bf16x8 xf[4][2], wlo[2][2], whi[2][2];
 
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
-  // One MFMA section: two 4-long same-accumulator chains (D -> C forwarding of an accumulate chain costs no wait states,
-  // an interleaved second accumulator exposes the write-back latency of the first on every other issue) with the
-  // section's operand request (MID) between them; sched_barriers keep hipcc from re-interleaving the chains.
-#define MFMA8(WF, ROWBASE, NJ, MID)                                                                           \
-  do {                                                                                                        \
-    if (ABL & 16) { /* bench-only: no MFMAs, fragment reads kept live */                                      \
-      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(WF[kk]), "v"(xf[0][kk]), "v"(xf[1][kk])); \
-      break;                                                                                                  \
-    }                                                                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                                            \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
-      acc[ROWBASE][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[0][kk], acc[ROWBASE][NJ], 0, 0, 0);         \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    MID;                                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
-      acc[ROWBASE + 1][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], xf[1][kk], acc[ROWBASE + 1][NJ], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    __builtin_amdgcn_s_setprio(0);                                                                            \
+  // One MFMA section = 16 MFMAs (k-step 0 of all eight accumulators, then k-step 1) with the section's operand request (MID)
+  // between the two k-steps; sched_barriers keep hipcc from re-interleaving them.
+#define MFMA16(WF, MIB, NJB, MID)                                                                                         \
+  do {                                                                                                                    \
+    if (ABL & 16) { /* bench-only: no MFMAs, fragment reads kept live */                                                  \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) asm volatile("" ::"v"(xf[i_][s_]));                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) asm volatile("" ::"v"(WF[j_][s_]));                              \
+      }                                                                                                                   \
+      break;                                                                                                              \
+    }                                                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                                        \
+    mfma_section<false, true, 0>(acc, WF, xf, MIB, NJB);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    MID;                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    mfma_section<false, true, 1>(acc, WF, xf, MIB, NJB);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    __builtin_amdgcn_s_setprio(0);                                                                                        \
   } while (0)
   // waits sit in the loads section: the 4 newest sections (8 requests) may still be in flight
 #define WAIT_PREFETCH() do { if (ABL & 32768) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } while (0)
-  // The request of a phase is issued BETWEEN the two accumulate chains of the wave's own MFMA section: +3 % over issuing
-  // it in the loads section of the same phase.  (The persistent kernel below moves all requests into the two light loads
-  // sections instead, which is better still.)
+  // The request of a phase is issued in the middle of the wave's own MFMA section: +3 % over issuing it in the loads
+  // section of the same phase.  (The persistent kernel below moves all requests into the two light loads sections
+  // instead, which is better still.)
 #define MID_STAGE(q, t) do { if (!(ABL & 1)) stage(q, t); } while (0)
 #define BODY_BARRIER() do { if (!(ABL & 4)) TFX_BARRIER(); } while (0)
   if (ABL & 2) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      xf[0][kk] = LDS_FRAG(fx[kk]); xf[1][kk] = LDS_FRAG(fx[kk] + 4096);
-      wlo[kk] = LDS_FRAG(fw[kk]); whi[kk] = LDS_FRAG(fw[kk] + 4096);
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[i][s] = LDS_FRAG(fx[s] + i * 2048);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { wlo[j][s] = LDS_FRAG(fw[s] + j * 2048); whi[j][s] = LDS_FRAG(fw[s] + 4096 + j * 2048); }
     }
   }
   auto tile_body = [&](int u, const uint32_t xs, const uint32_t ws) {
@@ -355,41 +595,43 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
     // ---- q0: X_lo (rows 0..63 of the group's half), W_lo (cols 0..31 of the stripe)
     if (!(ABL & 2)) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        xf[0][kk] = LDS_FRAG(fx[kk] + xs);
-        xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);
-        wlo[kk] = LDS_FRAG(fw[kk] + ws);
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i][s] = LDS_FRAG(fx[s] + xs + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wlo[j][s] = LDS_FRAG(fw[s] + ws + j * 2048);
       }
     }
     WAIT_PREFETCH();
     BODY_BARRIER();
-    MFMA8(wlo, 0, 0, MID_STAGE(0, u + 1));
+    MFMA16(wlo, 0, 0, MID_STAGE(0, u + 1));
     BODY_BARRIER();
     // ---- q1: W_hi (cols 32..63)
     if (!(ABL & 2)) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) whi[j][s] = LDS_FRAG(fw[s] + ws + 4096 + j * 2048);
     }
     WAIT_PREFETCH();
     BODY_BARRIER();
-    MFMA8(whi, 0, 1, MID_STAGE(1, u + 2));
+    MFMA16(whi, 0, 2, MID_STAGE(1, u + 2));
     BODY_BARRIER();
     // ---- q2: X_hi (rows 64..127)
     if (!(ABL & 2)) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        xf[0][kk] = LDS_FRAG(fx[kk] + xs + 8192);
-        xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);
-      }
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i][s] = LDS_FRAG(fx[s] + xs + 8192 + i * 2048);
     }
     WAIT_PREFETCH();
     BODY_BARRIER();
-    MFMA8(whi, 2, 1, MID_STAGE(2, u + 2));
+    MFMA16(whi, 4, 2, MID_STAGE(2, u + 2));
     BODY_BARRIER();
     // ---- q3: no reads
     WAIT_PREFETCH();
     BODY_BARRIER();
-    MFMA8(wlo, 2, 0, MID_STAGE(3, u + 2));
+    MFMA16(wlo, 4, 0, MID_STAGE(3, u + 2));
     BODY_BARRIER();
   };
 
@@ -399,79 +641,15 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   }
   if (g == 0) TFX_BARRIER();  // re-align the two groups
 #undef LDS_FRAG
-#undef MFMA8
+#undef MFMA16
 #undef WAIT_PREFETCH
 #undef MID_STAGE
 #undef BODY_BARRIER
 
-  // ---- epilogue.  Lane holds, per (mi, nj, quad), 4 consecutive columns of one row:
-  //   m = m0 + g*128 + mi*32 + (lane & 31),  n = n0 + wc*64 + nj*32 + quad*8 + hi*4 + (r & 3).
-  // bias / GELU / gate are applied here in fp32, the bf16 results are transposed through a wave-private LDS
-  // region (128 rows x 144 B, rows padded by 16 B) and leave as 16-byte stores in which 8 lanes cover one full
-  // 128-byte line of a row (16 store instructions per lane instead of 32 row-strided 8-byte ones).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // out-of-range prefetches may still target the sink region
-  char* stg = smem + wave * EPI_WAVE_BYTES;
-  const int ncol = n0 + wc * 64 + hi * 4;
-  const bool do_gelu = (EPI == EPI_BIAS_GELU) && (n0 >= p.gelu_from);
-#pragma unroll
-  for (int nj = 0; nj < 2; ++nj) {
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int n = ncol + nj * 32 + qd * 8;
-      const int nc = n < p.N ? n : 0;  // columns beyond N are computed but never stored
-      float bs[4] = {0.f, 0.f, 0.f, 0.f}, gt[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
-        const u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + nc);
-        bs[0] = __uint_as_float(raw[0] << 16); bs[1] = __uint_as_float(raw[0] & 0xffff0000u);
-        bs[2] = __uint_as_float(raw[1] << 16); bs[3] = __uint_as_float(raw[1] & 0xffff0000u);
-      }
-      if (EPI == EPI_BIAS_GATE_RES) {
-        const u32x2 raw = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + nc);
-        gt[0] = __uint_as_float(raw[0] << 16); gt[1] = __uint_as_float(raw[0] & 0xffff0000u);
-        gt[2] = __uint_as_float(raw[1] << 16); gt[3] = __uint_as_float(raw[1] & 0xffff0000u);
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][qd * 4 + e] + bs[e];
-        if (do_gelu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-        }
-        if (EPI == EPI_BIAS_GATE_RES) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gt[e] * round_bf(v[e]);
-        }
-        u32x2 o;
-        o[0] = pack_bf2(v[0], v[1]);
-        o[1] = pack_bf2(v[2], v[3]);
-        *reinterpret_cast<u32x2*>(stg + (mi * 32 + (lane & 31)) * EPI_ROW_BYTES + (nj * 32 + qd * 8 + hi * 4) * 2) = o;
-      }
-    }
-  }
-  // wave-private region + in-order LDS pipe: no barrier needed between the writes above and the reads below
-  const int crow = lane >> 3, cchunk = lane & 7;
-  const int nst = n0 + wc * 64 + cchunk * 8;
-  if (nst < p.N) {
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 8 + crow;
-      const int m = m0 + g * 128 + row;
-      if (m >= p.M) continue;
-      u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * EPI_ROW_BYTES + cchunk * 16);
-      if (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES) {
-        const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + nst);
-        float fv[8], fr[8];
-        unpack8(val, fv);
-        unpack8(rr, fr);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) fv[e] += fr[e];
-        val = pack8(fv);
-      }
-      *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
-    }
-  }
+  // ---- epilogue (tile_epilogue): the operand sets are free now -- every wave's last fragment read lies before the barrier
+  // above -- so each wave stages through 4 KiB of them; out-of-range prefetches may still target the sink region and are
+  // drained by the epilogue's own vmcnt(0)
+  tile_epilogue<EPI, false, false, 2>(acc, p, m0, n0, b, g, wc, lane, smem + wave * STG_WAVE, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -480,7 +658,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 // as above; what changes:
 //   * requests are issued from the LOADS sections.  An LDS-DMA instruction costs its wave ~60 issue cycles; issued
 //     between the MFMAs of a section (above) that is a hole in the matrix pipe, issued while the partner group owns
-//     the pipe it is free as long as the loads section stays under the 256 cycles of the partner's 8 MFMAs.  Each
+//     the pipe it is free as long as the loads section stays under the 256 cycles of the partner's 16 MFMAs.  Each
 //     group stages its own X half and the W stripes {2g, 2g+1}, everything for K-tile u+2 (same buffer set as u):
 //         item 0  X_lo  reads done after L0            item 1  W_lo  after L0 (+1 slot: the partner's read)
 //         item 2  W_hi  after L1 (+1)                  item 3  X_hi  after L2
@@ -496,14 +674,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
 // Operands are addressed through ONE buffer descriptor per matrix, the tile origin folded into the scalar offset
 // (32 bits, checked by persist_ok); rows beyond M / N are clamped on the way in and never stored.
 constexpr int PP_STG = 131072;
-constexpr int PP_STG_WAVE = 4096;
+constexpr int PP_STG_WAVE = STG_WAVE;
 constexpr int PP_LDS_TOTAL = PP_STG + 8 * PP_STG_WAVE;  // 163840 = all of the CU's LDS
 
 // FP8: A and W hold e4m3 bytes.  The byte geometry is the bf16 kernel's -- a K-tile is 128 bytes per row, now 128 k --
-// so staging, swizzle, buffer sets, slots and waits are unchanged; a 32x32 block takes two
-// v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; 64 matrix cycles each) instead of four 32x32x16 bf16 (32 each),
+// so staging, swizzle, buffer sets, slots and waits are unchanged; a 16x16 accumulator takes one
+// v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; 8 passes) per K-tile instead of two 16x16x32 bf16 (4 passes each),
 // i.e. the same 256 cycles per section for twice the k, and the epilogue applies the per-row / per-channel scales.
-// Lane l supplies row (l & 31), k bytes (l >> 5) * 32 .. +32 of a 64-k step (checked by tools/ubench/mfma_fp8_layout.hip).
+// Lane l supplies row (l & 15), k bytes (l >> 4) * 32 .. +32 of the 128-k step = 16-byte chunks 2 (l >> 4), 2 (l >> 4) + 1.
 // SPLIT: the work unit is (tile, K slice): p.sk slices of nt / p.sk K-tiles each, units ordered slice-major; the epilogue
 // stores the raw fp32 accumulators to p.ws [slice][batch][M][N] and splitk_reduce_kernel<EPI> finishes (sum over the
 // slices in order, bias, activation, gate, residual).  Used when a GEMM has fewer tiles than the chip has CUs.
@@ -596,16 +774,16 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
                                                0, GLDS_AUX);
   };
 
-  const int hi = lane >> 5;
-  const int key = (lane >> 1) & 7;
-  uint32_t fx[4], fw[4];
+  // fragment read addresses (see gemm8p_kernel): bf16 chunk 4 s + (l >> 4) = k-step s; e4m3 chunks 2 (l >> 4) + s = the two
+  // halves of the lane's 32 k bytes
+  const int r16 = lane & 15, q4 = lane >> 4;
+  uint32_t fx[2], fw[2];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    // bf16: chunk 2*kk + hi = k-step kk's 8 elements of this lane half; fp8: chunks 4*ks + 2*hi + {0, 1} (kk = 2*ks + h)
-    const int chunk = FP8 ? (kk >> 1) * 4 + hi * 2 + (kk & 1) : kk * 2 + hi;
-    const uint32_t o = (lane & 31) * 128 + ((chunk ^ key) << 4);
-    fx[kk] = LDS_X + g * 32768 + o;
-    fw[kk] = LDS_W + wc * 64 * 128 + o;
+  for (int s = 0; s < 2; ++s) {
+    const int chunk = FP8 ? 2 * q4 + s : 4 * s + q4;
+    const uint32_t o = r16 * 128 + ((chunk ^ (r16 >> 1)) << 4);
+    fx[s] = LDS_X + g * 32768 + o;
+    fw[s] = LDS_W + wc * 64 * 128 + o;
   }
 
   Tile cur = coords(xstart + it);
@@ -620,32 +798,15 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   TFX_BARRIER();
   if (g == 1) TFX_BARRIER();  // stagger: G1 runs one barrier behind G0, for the whole life of the block
 
-  f32x16 acc[4][2];
-  bf16x8 xf[2][4], wlo[4], whi[4];
+  f32x4 acc[8][4];
+  bf16x8 xf[4][2], wlo[2][2], whi[2][2];
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-  // same-accumulator MFMAs back to back (D -> C forwarding costs no wait states); the empty asm statements pin each
-  // chain inside its section -- the intrinsics are pure, nothing else stops hipcc from moving them across a barrier
-#define PP_CAT(lo_, hi_) __builtin_shufflevector(__builtin_bit_cast(i32x4, lo_), __builtin_bit_cast(i32x4, hi_), 0, 1, 2, 3, 4, 5, 6, 7)
-#define PP_CHAIN(ACC, WF, XF)                                                                                \
-  do {                                                                                                       \
-    if (FP8) {                                                                                               \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
-        ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(PP_CAT(WF[2 * ks], WF[2 * ks + 1]),            \
-                                                              PP_CAT(XF[2 * ks], XF[2 * ks + 1]), ACC, 0, 0, 0,  \
-                                                              0x7f7f7f7f, 0, 0x7f7f7f7f);                    \
-    } else {                                                                                                 \
-      _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                       \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[kk], XF[kk], ACC, 0, 0, 0);                         \
-    }                                                                                                        \
-    asm volatile("" : "+v"(ACC));                                                                            \
-  } while (0)
-#define PP_MFMA8(WF, ROWBASE, NJ)                                                                            \
+#define PP_MFMA16(WF, MIB, NJB)                                                                              \
   do {                                                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
-    PP_CHAIN(acc[ROWBASE][NJ], WF, xf[0]);                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    PP_CHAIN(acc[ROWBASE + 1][NJ], WF, xf[1]);                                                               \
+    mfma_section<FP8>(acc, WF, xf, MIB, NJB);                                                                \
+    TFX_PIN_SECTION(MIB, NJB);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
@@ -653,34 +814,32 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #define PP_TILE_W(SET, GO, XO, WO, KT, W0, W1, W3)                                                           \
   do {                                                                                                       \
     constexpr uint32_t xs = (SET) * 16384u, ws = (SET) * 32768u;                                             \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {            /* L0: X_lo, W_lo */                       \
-      xf[0][kk] = LDS_FRAG(fx[kk] + xs);                                                                     \
-      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 4096);                                                              \
-      wlo[kk] = LDS_FRAG(fw[kk] + ws);                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {               /* L0: X_lo, W_lo */                       \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) xf[i][s] = LDS_FRAG(fx[s] + xs + i * 2048);              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) wlo[j][s] = LDS_FRAG(fw[s] + ws + j * 2048);             \
     }                                                                                                        \
     if (W0) PP_VMCNT(10);                                                                                    \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA8(wlo, 0, 0);                                                                                     \
+    PP_MFMA16(wlo, 0, 0);                                                                                    \
     TFX_BARRIER();                                                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) whi[kk] = LDS_FRAG(fw[kk] + ws + 4096);  /* L1: W_hi */ \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                 /* L1: W_hi */                             \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) whi[j][s] = LDS_FRAG(fw[s] + ws + 4096 + j * 2048);      \
     stage(0, GO, XO, WO, KT, SET);                                                                           \
     if (PLACE == 1) { stage(1, GO, XO, WO, KT, SET); if (W1) PP_VMCNT(12); } else { if (W1) PP_VMCNT(10); }  \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA8(whi, 0, 1);                                                                                     \
+    PP_MFMA16(whi, 0, 2);                                                                                    \
     TFX_BARRIER();                                                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {            /* L2: X_hi */                             \
-      xf[0][kk] = LDS_FRAG(fx[kk] + xs + 8192);                                                              \
-      xf[1][kk] = LDS_FRAG(fx[kk] + xs + 12288);                                                             \
-    }                                                                                                        \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                 /* L2: X_hi */                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) xf[i][s] = LDS_FRAG(fx[s] + xs + 8192 + i * 2048);       \
     if (PLACE != 1) stage(1, GO, XO, WO, KT, SET);                                                           \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA8(whi, 2, 1);                                                                                     \
+    PP_MFMA16(whi, 4, 2);                                                                                    \
     TFX_BARRIER();                                                                                           \
     stage(2, GO, XO, WO, KT, SET);                                /* L3: no reads */                         \
     stage(3, GO, XO, WO, KT, SET);                                                                           \
     if (W3) PP_VMCNT(12);                                                                                    \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA8(wlo, 2, 0);                                                                                     \
+    PP_MFMA16(wlo, 4, 0);                                                                                    \
     TFX_BARRIER();                                                                                           \
   } while (0)
 #define PP_TILE(SET, GO, XO, WO, KT) PP_TILE_W(SET, GO, XO, WO, KT, 1, 1, 1)
@@ -695,17 +854,17 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     offsets(nxt, gon);
     const uint32_t cx = cur.xoff, cw = cur.woff, nx = nxt.xoff, nw = nxt.woff;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     // Everything K-tiles 0 and 1 read was waited for before this tile started (prologue / the epilogue's vmcnt(0)), and
     // the first requests of THIS tile have their deadline at L3 of K-tile 1: the earlier counted waits could only stall
     // on the previous epilogue's stores, which retire in issue order with the requests.
     int u0 = 0;
-    // (not in the fp8 gated-residual instantiation: there the two extra loop bodies tip hipcc's allocation into 80+ spills)
+    // (not in the fp8 gated-residual instantiation: there the two extra loop bodies tip hipcc's allocation into spills)
     if (nt >= 4 && !(FP8 && EPI == EPI_BIAS_GATE_RES)) {
       PP_TILE_W(0, goc, cx, cw, 2, 0, 0, 0);
       PP_TILE_W(1, goc, cx, cw, 3, 0, 0, 1);
@@ -718,237 +877,32 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     PP_TILE(0, gon, nx, nw, 0);  // K-tiles nt-2, nt-1: their requests are the next tile's K-tiles 0 and 1
     PP_TILE(1, gon, nx, nw, 1);
 
-    // ---- epilogue (see gemm8p_kernel for the lane -> element map), one 32-row accumulator block at a time.
-    // Every vector the epilogue needs (bias, gate, the first block's residual rows) is requested up front and waited
-    // for ONCE; the residual rows of block mi+1 are requested as soon as block mi has consumed its own.  (Loaded at their
-    // first use they cost one memory round trip each: 16-28 of them per tile, 26 us of a 95 us tile at K = 3072.)
+    // ---- epilogue (tile_epilogue), one 32-row block of the accumulators at a time
     if (SPLIT) {
-      // raw fp32 partials: lane = row r32 of each 32-row block, 4 consecutive columns per (nj, quad) -> 16-byte stores
+      // raw fp32 partials: lane = row (l & 15) of each 16-row block, 4 consecutive columns per nj -> 16-byte stores
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       int le = lane;
       asm volatile("" : "+v"(le));
       float* wsp = p.ws + (int64_t)(cur.slice * p.batch + cur.b) * p.ws_bs;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int m = cur.m0 + g * 128 + mi * 32 + (le & 31);
+      for (int mi = 0; mi < 8; ++mi) {
+        const int m = cur.m0 + g * 128 + mi * 16 + (le & 15);
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
+        for (int nj = 0; nj < 4; ++nj) {
+          const int n = cur.n0 + wc * 64 + nj * 16 + (le >> 4) * 4;
+          if (m < p.M && n + 3 < p.N) {
+            *reinterpret_cast<f32x4*>(wsp + (int64_t)m * p.ws_ld + n) = acc[mi][nj];
+          } else if (m < p.M) {   // ragged right edge (fp32-output mode only: the split path has N % 8 == 0)
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const int n = cur.n0 + wc * 64 + nj * 32 + qd * 8 + (le >> 5) * 4;
-            if (m < p.M && n + 3 < p.N) {
-              *reinterpret_cast<f32x4*>(wsp + (int64_t)m * p.ws_ld + n) =
-                  f32x4{acc[mi][nj][qd * 4], acc[mi][nj][qd * 4 + 1], acc[mi][nj][qd * 4 + 2], acc[mi][nj][qd * 4 + 3]};
-            } else if (m < p.M) {   // ragged right edge (fp32-output mode only: the split path has N % 8 == 0)
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n + e < p.N) wsp[(int64_t)m * p.ws_ld + n + e] = acc[mi][nj][qd * 4 + e];
-            }
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) wsp[(int64_t)m * p.ws_ld + n + e] = acc[mi][nj][e];
           }
+        }
       }
-      if (!has_next) break;
-      cur = nxt;
-      it = nit;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) goc[q][j] = gon[q][j];
-      continue;
+    } else {
+      tile_epilogue<EPI, FP8, QKN, (FP8 ? 1 : 2)>(acc, p, cur.m0, cur.n0, cur.b, g, wc, lane, stg,
+                                                  smem + PP_STG + (wave ^ 1) * PP_STG_WAVE);
     }
-    const int m0 = cur.m0, n0 = cur.n0, b = cur.b;
-    // lane-derived offsets are rebuilt from an opaque copy of the lane id: derived from `lane` they are loop invariants
-    // that hipcc keeps in ~20 VGPRs across the K loop, which is what pushed this kernel into spilling
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int hi_e = lane_e >> 5;
-    const int ncol = n0 + wc * 64 + hi_e * 4;
-    const bool do_gelu = (EPI == EPI_BIAS_GELU) && (n0 >= p.gelu_from);
-    const int r32 = lane_e & 31;
-    const int crow = lane_e >> 3, cchunk = lane_e & 7;
-    const int nst = n0 + wc * 64 + cchunk * 8;
-    constexpr bool HAS_RES = (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES);
-    const bf16_t* resp = HAS_RES ? p.res + b * p.r_bs + min(nst, p.N - 8) : nullptr;
-    auto load_res = [&](int mi, u32x4 (&rr)[4]) {
-#pragma unroll
-      for (int itr = 0; itr < 4; ++itr) {
-        const int m = min(m0 + g * 128 + mi * 32 + itr * 8 + crow, p.M - 1);
-        rr[itr] = *reinterpret_cast<const u32x4*>(resp + (int64_t)m * p.ldr);
-      }
-    };
-    if (FP8) {
-      // dequantise in place first (row scale x channel scale): the 36 scale registers are dead before bias / gate /
-      // residual are requested.  Costs a second memory round trip per tile, saves the spills of holding both sets.
-      float sa[4];
-      f32x4 sw[2][4];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) sa[mi] = p.a_scale[b * p.as_bs + min(m0 + g * 128 + mi * 32 + r32, p.M - 1)];
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int n = ncol + nj * 32 + qd * 8;
-          sw[nj][qd] = *reinterpret_cast<const f32x4*>(p.w_scale + (n < p.N ? n : 0));
-        }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[mi][nj][qd * 4 + e] = (acc[mi][nj][qd * 4 + e] * sa[mi]) * sw[nj][qd][e];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    u32x2 bsr[2][4], gtr[2][4];   // bias / gate stay packed (bf16 pairs) until they are used
-    constexpr int RES_DEPTH = FP8 ? 1 : 2;   // residual row blocks requested ahead of their use
-    u32x4 rr[RES_DEPTH][4];
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int n = ncol + nj * 32 + qd * 8;
-        const int nc = n < p.N ? n : 0;  // columns beyond N are computed but never stored
-        bsr[nj][qd] = p.bias ? *reinterpret_cast<const u32x2*>(p.bias + nc) : u32x2{0u, 0u};
-        if (EPI == EPI_BIAS_GATE_RES) gtr[nj][qd] = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + nc);
-      }
-    if (HAS_RES) {
-#pragma unroll
-      for (int d = 0; d < RES_DEPTH; ++d) load_res(d, rr[d]);
-    }
-    const bool in_q = QKN && n0 >= p.nq0 && n0 < p.nq1;
-    const bool norm_tile = QKN && (in_q || (n0 >= p.nk0 && n0 < p.nk1));      // block-uniform
-    // every request of this tile's K loop (incl. the next tile's first K-tiles) is older than the stores below;
-    // loads and stores retire out of order with respect to each other, so the counted waits of the next K loop are
-    // only meaningful once these have landed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float rinv[4] = {0.f, 0.f, 0.f, 0.f};
-    u32x4 nw8 = u32x4{0u, 0u, 0u, 0u};     // norm weights of the 8 columns this lane stores (norm tiles)
-    if (norm_tile) {
-      nw8 = *reinterpret_cast<const u32x4*>((in_q ? p.nq_w : p.nk_w) + (wc & 1) * 64 + cchunk * 8);
-      // Linear output in bf16 (what the reference's RMSNorm sees), in place; sum of squares of this lane's 32 columns
-      float ss[4];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        ss[mi] = 0.f;
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const u32x2 br = bsr[nj][qd];
-            const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
-                                 __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x = round_bf(acc[mi][nj][qd * 4 + e] + bs[e]);
-              acc[mi][nj][qd * 4 + e] = x;
-              ss[mi] += x * x;
-            }
-          }
-        ss[mi] += __shfl_xor(ss[mi], 32, 64);       // the other 32 columns of this wave's stripe
-      }
-      if (hi_e == 0) *reinterpret_cast<f32x4*>(stg + r32 * 16) = f32x4{ss[0], ss[1], ss[2], ss[3]};
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      TFX_BARRIER();                                 // both stripes of every head have published their sums
-      const f32x4 other = *reinterpret_cast<const f32x4*>(smem + PP_STG + (wave ^ 1) * PP_STG_WAVE + r32 * 16);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      TFX_BARRIER();                                 // ... and read the partner's, before the staging areas are reused below
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) rinv[mi] = rsqrtf((ss[mi] + other[mi]) * (1.0f / 128.0f) + p.n_eps);
-    }
-    auto store_blocks = [&](auto NORM_T) __attribute__((always_inline)) {
-      constexpr bool NORM = decltype(NORM_T)::value;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        // (cos, sin) pairs of the four rows this lane stores from this row block, requested before the block is converted
-        // and staged (the latency hides behind that work)
-        f32x4 csr[4][2];
-        if (NORM) {
-#pragma unroll
-          for (int itr = 0; itr < 4; ++itr) {
-            const int mrow = min(m0 + g * 128 + mi * 32 + itr * 8 + crow, p.M - 1);
-            const float* cs = p.rope_cs + (int64_t)(p.rope_pos0 + mrow) * 128 + (wc & 1) * 64 + cchunk * 8;
-            csr[itr][0] = *reinterpret_cast<const f32x4*>(cs);
-            csr[itr][1] = *reinterpret_cast<const f32x4*>(cs + 4);
-          }
-        }
-  #pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-  #pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const u32x2 br = bsr[nj][qd];
-            const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
-                                 __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
-            float v[4];
-            if (NORM) {      // already bias-added and bf16-rounded by the pre-pass; normalised + rotated after the transpose
-  #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][qd * 4 + e];
-            } else {
-  #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][qd * 4 + e] + bs[e];
-            }
-            if (do_gelu) {
-  #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-            }
-            if (EPI == EPI_BIAS_GATE_RES) {
-              const u32x2 gr = gtr[nj][qd];
-              const float gt[4] = {__uint_as_float(gr[0] << 16), __uint_as_float(gr[0] & 0xffff0000u),
-                                   __uint_as_float(gr[1] << 16), __uint_as_float(gr[1] & 0xffff0000u)};
-  #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gt[e] * round_bf(v[e]);
-            }
-            u32x2 o;
-            o[0] = pack_bf2(v[0], v[1]);
-            o[1] = pack_bf2(v[2], v[3]);
-            // row r32, 16-byte chunk c = nj*4 + qd stored at chunk c ^ (r32 & 7); the 8-byte half is flipped for rows
-            // 8..15 / 24..31 so the 16 lanes of a ds_write_b64 group touch 16 different bank pairs
-            const int c = nj * 4 + qd;
-            *reinterpret_cast<u32x2*>(stg + r32 * 128 + ((c ^ (r32 & 7)) << 4) + ((hi_e ^ ((r32 >> 3) & 1)) << 3)) = o;
-          }
-        }
-        // wave-private region + in-order LDS pipe: no barrier between the writes above and the reads below
-        if (QKN) __builtin_amdgcn_sched_barrier(0);   // keeps the table loads of later row blocks from being hoisted over live accumulators
-  #pragma unroll
-        for (int itr = 0; itr < 4; ++itr) {
-          const int row = itr * 8 + crow;
-          const int m = m0 + g * 128 + mi * 32 + row;
-          u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((cchunk ^ (row & 7)) << 4));
-          if (itr & 1) { const uint32_t t0 = val[0], t1 = val[1]; val[0] = val[2]; val[1] = val[3]; val[2] = t0; val[3] = t1; }
-          if (NORM) {
-            // this lane now holds 8 consecutive columns (4 rotation pairs) of row `row`: its 1/rms sits in the lane whose r32 is
-            // that row, its (cos, sin) pairs are 32 contiguous bytes of the table (the 8 lanes of a row read 256 contiguous bytes)
-            const float rr_row = __shfl(rinv[mi], row, 64);
-            const f32x4 c0 = csr[itr][0], c1 = csr[itr][1];
-            float x[8], wv[8], y[8], o8[8];
-            unpack8(val, x);
-            unpack8(nw8, wv);
-  #pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = round_bf(round_bf(x[e] * rr_row) * wv[e]);
-            o8[0] = y[0] * c0[0] + (-y[1]) * c0[1];  o8[1] = y[1] * c0[0] + y[0] * c0[1];
-            o8[2] = y[2] * c0[2] + (-y[3]) * c0[3];  o8[3] = y[3] * c0[2] + y[2] * c0[3];
-            o8[4] = y[4] * c1[0] + (-y[5]) * c1[1];  o8[5] = y[5] * c1[0] + y[4] * c1[1];
-            o8[6] = y[6] * c1[2] + (-y[7]) * c1[3];  o8[7] = y[7] * c1[2] + y[6] * c1[3];
-            val = pack8(o8);
-          }
-          if (HAS_RES) {
-            float fv[8], fr[8];
-            unpack8(val, fv);
-            unpack8(rr[mi % RES_DEPTH][itr], fr);
-  #pragma unroll
-            for (int e = 0; e < 8; ++e) fv[e] += fr[e];
-            val = pack8(fv);
-          }
-          if (m < p.M && nst < p.N) *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
-        }
-        if (HAS_RES && mi + RES_DEPTH < 4) {
-          load_res(mi + RES_DEPTH, rr[mi % RES_DEPTH]);   // in flight while the next block is converted and staged
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (QKN) __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    if (QKN && norm_tile) store_blocks(std::true_type{});
-    else store_blocks(std::false_type{});
     if (!has_next) break;
     cur = nxt;
     it = nit;
@@ -961,9 +915,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the closing requests must not land in a successor's LDS
 #undef LDS_FRAG
 #undef PP_VMCNT
-#undef PP_MFMA8
-#undef PP_CHAIN
-#undef PP_CAT
+#undef PP_MFMA16
 #undef PP_TILE
 #undef PP_TILE_W
 }
