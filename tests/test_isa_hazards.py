@@ -20,7 +20,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipc
 
 def isa(src, tmp_path, *flags):
     out = tmp_path / (os.path.basename(src) + "".join(f.replace("-", "_") for f in flags) + ".s")
-    extra = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if src.endswith("attention_w4.hip") else []     # as the Makefile builds it
+    extra = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if src.endswith(("attention_w4.hip", "attention_w16.hip")) else []   # as the Makefile builds them
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only", "-S", *extra, *flags,
                         "-o", str(out), os.path.join(CSRC, src)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -33,6 +33,17 @@ def test_default_attention_kernel_has_no_mfma_result_hazard(tmp_path):
     (name, n, n_mfma, rep), = ck.check_all(asm)
     assert "attn_w4_kernel" in name and n_mfma > 250 and n > 3000      # the kernel was really parsed
     assert asm.count("v_readfirstlane_b32") >= 16                       # the compiler-visible touches are in the stream
+    assert rep == [], rep[:5]
+
+
+def test_attention_w16_kernel_has_no_mfma_or_transcendental_result_hazard(tmp_path):
+    """The 16 x 16 x 32 attention kernel: MFMA results (scores) and v_exp_f32 results are both read from inline asm.  (Its first
+    version ordered the exponentials / packs so that hipcc could put a pack right behind the v_exp_f32 it reads: this check found
+    it before the GPU did.)"""
+    import check_mfma_hazard as ck
+    asm = isa("attention_w16.hip", tmp_path)
+    (name, n, n_mfma, rep), = ck.check_all(asm)
+    assert "attn_w16_kernel" in name and n_mfma >= 4 * 136
     assert rep == [], rep[:5]
 
 

@@ -219,7 +219,7 @@ def test_attention(ops, B, H, N):
     close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
-@pytest.mark.parametrize("nw", [8, 10, 20])
+@pytest.mark.parametrize("nw", [8, 10, 20, 30, 40])
 def test_attention_waves_variants(ops, nw):
     """The other kernels of the product library (8: exact online maximum, 10: matrix-pipe softmax with 8 waves x 32 rows, 20:
     half-tile software-pipelined) compute the same thing as the default (30: one wave per SIMD, 64 rows per wave).  The
@@ -232,7 +232,23 @@ def test_attention_waves_variants(ops, nw):
     try:
         got = ops.attention(q.cuda(), k.cuda(), v.cuda())
     finally:
-        ops.set_option("attention_waves", 30)
+        ops.set_option("attention_waves", ops.DEFAULT_ATTENTION)
+    close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+
+
+@pytest.mark.parametrize("nw", [30, 40])
+@pytest.mark.parametrize("B,H,N", [(1, 1, 1), (2, 3, 8), (1, 2, 33), (1, 1, 64), (1, 1, 65), (2, 2, 96), (1, 3, 300), (2, 2, 1664), (1, 24, 520)])
+def test_attention_one_wave_per_simd_kernels_shape_sweep(ops, nw, B, H, N):
+    """Both one-wave-per-SIMD kernels (30: 32 x 32 x 16 MFMA, 40: 16 x 16 x 32 MFMA) over the ragged / tiny-N sweep, whichever
+    of them is the default."""
+    q, k, v = (rnd((B, N, H * 128), s).to(BF) for s in (20, 21, 22))
+    qh, kh, vh = (t.float().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, N, H * 128)
+    ops.set_option("attention_waves", nw)
+    try:
+        got = ops.attention(q.cuda(), k.cuda(), v.cuda())
+    finally:
+        ops.set_option("attention_waves", ops.DEFAULT_ATTENTION)
     close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
@@ -270,7 +286,7 @@ def test_attention_unaligned_output_rows_take_the_fallback_kernel(ops):
     assert (buf[:, :, H * 128:] == 0).all()
 
 
-@pytest.mark.parametrize("nw", [8, 10, 20, 30])
+@pytest.mark.parametrize("nw", [8, 10, 20, 30, 40])
 def test_attention_reference_maximum_paths_vs_fp64(ops, nw):
     """Inputs that drive every path of the (lazy) reference-maximum logic, against an fp64 softmax: scores that are all
     very negative (first tile must pin the reference to the true maximum: no underflow of the row sum), a maximum that
@@ -302,7 +318,7 @@ def test_attention_reference_maximum_paths_vs_fp64(ops, nw):
             assert err.max().item() <= 2e-2 * ref.abs().max().item() + 1e-3, (name, err.max().item())
             assert err.mean().item() <= 6e-3 * ref.abs().mean().item() + 1e-5, (name, err.mean().item(), ref.abs().mean().item())
     finally:
-        ops.set_option("attention_waves", 30)
+        ops.set_option("attention_waves", ops.DEFAULT_ATTENTION)
 
 
 def test_attention_online_softmax_rescale_branch(ops):

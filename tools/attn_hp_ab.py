@@ -23,4 +23,4 @@ for (B, N) in [(8, 4608), (1, 1664), (2, 8704), (1, 4608 - 37)]:
         print(json.dumps(dict(B=B, N=N, option=nw, ms=round(t * 1e3, 4), tflops=round(4.0 * B * 24 * N * N * 128 / t / 1e12, 1), max_err_vs_fp32=err)), flush=True)
     d = (outs[10].float() - outs[20].float()).abs()
     print("   max |mx - hp| =", d.max().item(), " mean", d.mean().item(), flush=True)
-ops.set_option("attention_waves", 30)
+ops.set_option("attention_waves", 0)

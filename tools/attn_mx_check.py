@@ -40,4 +40,4 @@ for (B, N) in [(8, 4608), (1, 4608), (8, 8704), (1, 1664)]:
         o = torch.empty(B, N, D, dtype=BF, device="cuda")
         t = timeit(lambda: ops.attention(q, k, v, out=o), iters=10)
         print(json.dumps(dict(B=B, N=N, waves=nw, ms=round(t * 1e3, 4), tflops=round(4.0 * B * 24 * N * N * 128 / t / 1e12, 1))), flush=True)
-ops.set_option("attention_waves", 30)
+ops.set_option("attention_waves", 0)

@@ -12,4 +12,4 @@ for data in ("random", "zero"):
     for nw in opts:
         ops.set_option("attention_waves", nw)
         probe(f"attention option {nw}, {data} data", lambda: ops.attention(y[:, :, 2 * D:], y[:, :, :D], y[:, :, D:2 * D], out=o), secs=3.0)
-ops.set_option("attention_waves", 30)
+ops.set_option("attention_waves", 0)

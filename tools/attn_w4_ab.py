@@ -37,4 +37,4 @@ for (B, N) in [(8, 4608), (1, 1664), (2, 8704)]:
         print(json.dumps(dict(B=B, N=N, option=nw, ms=round(t * 1e3, 4), tflops=round(4.0 * B * 24 * N * N * 128 / t / 1e12, 1))), flush=True)
     d = (outs[opts[0]].float() - outs[opts[-1]].float()).abs()
     print("   max |a - b| =", d.max().item(), " mean", d.mean().item(), flush=True)
-ops.set_option("attention_waves", 30)
+ops.set_option("attention_waves", 0)

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from textflux_amd import ops
 BF = torch.bfloat16
 torch.manual_seed(0)
-ops.set_option("attention_waves", 30)
+ops.set_option("attention_waves", 0)
 tot = 0
 for name, qs, N, H in [("normal", 1.0, 256, 1), ("tinyq", 0.01, 256, 1), ("normal", 1.0, 128, 1), ("normal", 1.0, 192, 1), ("bigq", 3.0, 256, 1), ("normal", 1.0, 512, 1),
                        ("normal", 1.0, 1000, 4), ("bigq", 4.0, 4608, 24), ("normal", 1.0, 33, 2), ("normal", 1.0, 8704, 6)]:

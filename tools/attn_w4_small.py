@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from textflux_amd import ops
 BF = torch.bfloat16
 torch.manual_seed(0)
-ops.set_option("attention_waves", 30)
+ops.set_option("attention_waves", 0)
 for N in (8, 33, 64, 128, 192, 256):
     H, B, Dh = 1, 1, 128
     y = torch.randn(B, N, 3 * Dh, device="cuda").to(BF)

@@ -24,10 +24,17 @@ VARIANTS = [
     ("16x16x32 wave128x64  Astat   accV 4w", 16, 8, 4, "astat", "v", 4),
     ("16x16x32 wave128x64  Astat   accA 4w", 16, 8, 4, "astat", "a", 4),
     ("16x16x32 wave128x128 Astat   accA 4w", 16, 8, 8, "astat", "a", 4),
+    # the same 128-MFMA K-tile with the memory instructions a one-wave-per-SIMD 256x256x64 GEMM main loop would carry beside it
+    # (per wave and K-tile: 32 fragment reads, 16 LDS-DMA requests of 1 KiB, one barrier): does the matrix pipe stay fed?
+    ("16x16x32 wave128x128 + 32 ds_read_b128 / K-tile", 16, 8, 8, "astat", "a", 4, 32, 0, 0),
+    ("16x16x32 wave128x128 + 16 LDS-DMA / K-tile", 16, 8, 8, "astat", "a", 4, 0, 16, 0),
+    ("16x16x32 wave128x128 + 32 ds_read + 16 LDS-DMA + barrier / K-tile", 16, 8, 8, "astat", "a", 4, 32, 16, 1),
+    ("16x16x32 wave128x128 + 32 ds_read + 16 LDS-DMA (all in 2nd half) + barrier", 16, 8, 8, "astat", "a", 4, 32, 16, 2),
+    ("16x16x32 wave128x128 + 32 ds_read + 16 buffer_load->VGPR + 16 ds_write_b128 + barrier", 16, 8, 8, "astat", "a", 4, 32, 16, 3),
 ]
 
 
-def kernel(idx, shape, MI, NJ, order, accf, waves):
+def kernel(idx, shape, MI, NJ, order, accf, waves, n_ds=0, n_dma=0, mode=0):
     KS = 4 if shape == 32 else 2                 # k-steps per 64-deep K-tile
     accw = 16 if shape == 32 else 4
     mn = "v_mfma_f32_32x32x16_bf16" if shape == 32 else "v_mfma_f32_16x16x32_bf16"
@@ -47,6 +54,13 @@ def kernel(idx, shape, MI, NJ, order, accf, waves):
     for f in range(nfrag):
         L.append(f"global_load_dwordx4 v[{a0 + 4 * f}:{a0 + 4 * f + 3}], %0, off offset:{16 * f}")
     L.append("s_waitcnt vmcnt(0)")
+    if n_ds or n_dma:
+        L.append("v_mov_b32 v2, %2")             # per-lane LDS byte address (lane * 16)
+        L.append("v_mov_b32 v4, %3")             # global source of the DMA / staging loads (this wave's operand block)
+        L.append("v_mov_b32 v5, %4")
+        for k in range(8):
+            L.append(f"s_add_u32 s{22 + k}, %5, {k * 2048}")    # M0 values: 8 x 2 KiB slots of this wave's LDS slice
+        L.append("s_nop 4")
     L.append("s_mov_b32 s20, %1")                # tiles
     L.append("1:")
     for r in range(nacc):
@@ -77,9 +91,38 @@ def kernel(idx, shape, MI, NJ, order, accf, waves):
             for i in range(MI):
                 for j in range(NJ):
                     seq.append((i, j, kk))
-    for (i, j, kk) in seq:
+    # fillers: ds_read_b128 into scratch VGPRs v[240:255] (rotating), LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction
+    # into this wave's 16 KiB LDS slice, source = the wave's operand block, L2-resident), spread evenly over the MFMAs
+    nm = len(seq)
+    fill = {}
+    if n_ds or n_dma:
+        assert op_end <= 224
+        ds_at = [int((k + 0.5) * nm / n_ds) for k in range(n_ds)] if n_ds else []
+        if mode == 2:
+            dma_at = [nm // 2 + int((k + 0.5) * (nm // 2) / n_dma) for k in range(n_dma)] if n_dma else []
+        else:
+            dma_at = [int((k + 0.25) * nm / n_dma) for k in range(n_dma)] if n_dma else []
+        for k, pos in enumerate(ds_at):
+            fill.setdefault(pos, []).append(f"ds_read_b128 v[{240 + 4 * (k % 4)}:{243 + 4 * (k % 4)}], v2 offset:{(k % 16) * 1024}")
+        for k, pos in enumerate(dma_at):
+            if mode == 3:     # register staging: load to VGPRs now, write the piece loaded 8 requests ago to LDS
+                r = 224 + 4 * (k % 4)
+                fill.setdefault(pos, []).append(f"ds_write_b128 v2, v[{r}:{r + 3}] offset:{16384 + (k % 16) * 1024}")
+                fill.setdefault(pos, []).append(f"global_load_dwordx4 v[{r}:{r + 3}], v[4:5], off offset:{(k % 4) * 1024}")
+            else:
+                fill.setdefault(pos, []).append(f"s_mov_b32 m0, s{22 + (k % 8)}")
+                fill.setdefault(pos, []).append(f"global_load_lds_dwordx4 v[4:5], off offset:{(k % 4) * 1024}")
+    for n_, (i, j, kk) in enumerate(seq):
+        if mode in (1, 2, 3) and n_ == nm // 2:
+            L.append("s_waitcnt vmcnt(%d)" % (4 if mode == 3 else 0))
+            L.append("s_waitcnt lgkmcnt(0)")
+            L.append("s_barrier")
+        for f in fill.get(n_, []):
+            L.append(f)
         c = rng(accf, C(i, j), accw)
         L.append(f"{mn} {c}, {rng('v', A(j, kk), 4)}, {rng('v', B(i, kk), 4)}, {c}")
+    if n_ds or n_dma:
+        L.append("s_waitcnt lgkmcnt(0)")
     L.append("s_sub_u32 s21, s21, 1")
     L.append("s_cmp_lg_u32 s21, 0")
     L.append("s_cbranch_scc1 2b")
@@ -89,10 +132,27 @@ def kernel(idx, shape, MI, NJ, order, accf, waves):
     L.append("s_cmp_lg_u32 s20, 0")
     L.append("s_cbranch_scc1 1b")
     clob = [f"v{r}" for r in range(a0, op_end)] + [f"{accf}{acc0 + r}" for r in range(nacc)] + ["s20", "s21", "scc"]
+    mix = bool(n_ds or n_dma)
+    if mix:
+        clob += ["v2", "v4", "v5", "m0"] + [f"v{r}" for r in range(224, 256)] + [f"s{22 + k}" for k in range(8)]
     body = "\\n\\t".join(L)
     clobs = ", ".join(f'"{c}"' for c in clob)
     flops_per_ktile = len(seq) * (32 * 32 * 16 * 2 if shape == 32 else 16 * 16 * 32 * 2)
-    src = f"""
+    if mix:
+        src = f"""
+__global__ __launch_bounds__({64 * waves}) void k{idx}(const char* src, int tiles) {{
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const char* p = src + (size_t)(blockIdx.x * {64 * waves} + threadIdx.x) * {16 * nfrag};
+  const unsigned lane16 = (threadIdx.x & 63) * 16;
+  // the DMA / staging source: 1 KiB contiguous per wave instruction (lane * 16 B), as a real operand stream (8 lanes per 128-B line)
+  const unsigned long long gp = (unsigned long long)(src + (size_t)(blockIdx.x * {waves} + (threadIdx.x >> 6)) * 8192 + lane16);
+  const unsigned lo = (unsigned)gp, hi = (unsigned)(gp >> 32);
+  const unsigned wbase = __builtin_amdgcn_readfirstlane(32768u + (threadIdx.x >> 6) * 16384u + (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+  asm volatile("{body}" :: "v"(p), "s"(tiles), "v"(lane16), "v"(lo), "v"(hi), "s"(wbase) : {clobs}, "memory");
+}}
+"""
+    else:
+        src = f"""
 __global__ __launch_bounds__({64 * waves}) void k{idx}(const char* src, int tiles) {{
   const char* p = src + (size_t)(blockIdx.x * {64 * waves} + threadIdx.x) * {16 * nfrag};
   asm volatile("{body}" :: "v"(p), "s"(tiles) : {clobs}, "memory");
@@ -106,12 +166,13 @@ def main():
            '#include <hip/hip_runtime.h>', '#include <chrono>', '#include <cstdio>', '#include <cstdlib>', '#include <cstring>',
            '#include <random>', '#include <vector>']
     table = []
-    for idx, (name, shape, MI, NJ, order, accf, waves) in enumerate(VARIANTS):
-        src, fl, nfrag = kernel(idx, shape, MI, NJ, order, accf, waves)
+    for idx, var in enumerate(VARIANTS):
+        name, shape, MI, NJ, order, accf, waves = var[:7]
+        src, fl, nfrag = kernel(idx, shape, MI, NJ, order, accf, waves, *var[7:])
         out.append(src)
-        table.append((name, idx, fl, nfrag, waves))
-    out.append("struct V { const char* name; void (*fn)(const char*, int); double flops_ktile; int nfrag, waves; };")
-    out.append("static const V vs[] = {" + ", ".join(f'{{"{n}", k{i}, {fl}.0, {nf}, {w}}}' for n, i, fl, nf, w in table) + "};")
+        table.append((name, idx, fl, nfrag, waves, 131072 if len(var) > 7 else 0))
+    out.append("struct V { const char* name; void (*fn)(const char*, int); double flops_ktile; int nfrag, waves, lds; };")
+    out.append("static const V vs[] = {" + ", ".join(f'{{"{n}", k{i}, {fl}.0, {nf}, {w}, {l}}}' for n, i, fl, nf, w, l in table) + "};")
     out.append(r'''
 int main(int argc, char** argv) {
   const int nv = sizeof(vs) / sizeof(vs[0]);
@@ -134,10 +195,11 @@ int main(int argc, char** argv) {
     h[i] = (uint16_t)(u >> 16);
   }
   char* d;
-  (void)hipMalloc(&d, n * 2);
+  (void)hipMalloc(&d, n * 2 + 65536);     // the DMA / staging fillers read up to 4 KiB past a lane's operand block
   (void)hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice);
   const int tiles = 100;
-  vs[v].fn<<<cus, 64 * vs[v].waves>>>(d, 2);
+  if (vs[v].lds) (void)hipFuncSetAttribute((const void*)vs[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, vs[v].lds);
+  vs[v].fn<<<cus, 64 * vs[v].waves, vs[v].lds>>>(d, 2);
   if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 2; }
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -145,7 +207,7 @@ int main(int argc, char** argv) {
   const auto t0 = std::chrono::steady_clock::now();
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
     (void)hipEventRecord(e0);
-    for (int r = 0; r < 4; ++r) vs[v].fn<<<cus, 64 * vs[v].waves>>>(d, tiles);
+    for (int r = 0; r < 4; ++r) vs[v].fn<<<cus, 64 * vs[v].waves, vs[v].lds>>>(d, tiles);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
