@@ -177,6 +177,13 @@ typedef struct tfx_dit_desc {
    * has CUs apply the per-head RMSNorm + RoPE in their GEMM epilogue (bf16 mode); the others -- and every projection when
    * this is NULL -- are followed by tfx_rmsnorm_rope as a separate pass.  Same rounding points either way. */
   const float* rope_cs;
+  /* optional: the flow-matching Euler update fused into proj_out's epilogue (scheduling_flow_match_euler_discrete.py:319-330:
+   * x' = x + (sigma_next - sigma) * v).  euler_gate: bf16 [B][out_channels] rows (row stride euler_gate_bstride elements), every
+   * element = the step's bf16-rounded dsigma.  When set, the final projection runs with the gated-residual epilogue --
+   * xin[:, :, :out_channels] <- xin[:, :, :out_channels] + bf16(dsigma * bf16(proj_out(...))), the reference's rounding points,
+   * bit-identical to tfx_euler_step on the stored model output -- i.e. the latent state lives IN the x_embedder input, `out` is
+   * not written, and there is neither a scheduler launch nor a copy of the new latents into the next step's input. */
+  const void* euler_gate; int64_t euler_gate_bstride;
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
 
@@ -205,7 +212,11 @@ typedef struct tfx_step_desc {
   int32_t* step_ptr;
   void* latents;
   const float* coef; const float* noise;
-  int32_t sampler;                                                 /* 0 Euler, 1 AMO */
+  int32_t sampler;                                                 /* 0 Euler, 1 AMO, 2 Euler fused into proj_out's epilogue:
+                                                                      dit.euler_gate must point into mod_cur (the step's dsigma row
+                                                                      travels with its modulation rows: mod_step_elems covers it), the
+                                                                      latents live in dit.xin[:, :, :out_channels]; `latents` / `coef` are
+                                                                      not used -- copy the result out with tfx_copy_rows after the loop */
 } tfx_step_desc;
 typedef void* tfx_graph;
 int tfx_dit_step_run(const tfx_step_desc* step, tfx_stream stream);

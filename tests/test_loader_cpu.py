@@ -58,3 +58,25 @@ def test_scheduler_config_round_trip(ckpt):
     with open(os.path.join(root, "scheduler", "scheduler_config.json")) as f:
         sch = FlowMatchEulerDiscreteScheduler.from_config(json.load(f))
     assert sch.config.use_dynamic_shifting and sch.config.max_shift == 1.15 and sch.config.shift == 3.0
+
+
+def test_streamer_chunking_matches_safetensors_reader(tmp_path):
+    """loader.ShardStreamer with chunk sizes from 64 B to 1 MiB (tensors cut across chunks, several tensors per chunk, dtype
+    conversion on the way) against the tensors safetensors itself wrote."""
+    from safetensors.torch import save_file
+    from textflux_amd import loader
+    g = torch.Generator().manual_seed(0)
+    specs = [((3,), torch.float32), ((1000, 7), torch.bfloat16), ((5,), torch.bfloat16), ((4097, 33), torch.float32),
+             ((1,), torch.float16), ((70000,), torch.bfloat16), ((16, 16), torch.float32)]
+    sd = {f"t{i}": torch.randn(*shape, generator=g).to(dt) for i, (shape, dt) in enumerate(specs)}
+    fn = str(tmp_path / "x.safetensors")
+    save_file(sd, fn)
+    for chunk in (64, 1000, 4096, 100000, 1 << 20):
+        st = loader.ShardStreamer("cpu")
+        st.chunk, st.bufs, st.events = chunk, [torch.empty(chunk, dtype=torch.uint8)], [None]
+        out = {k: torch.empty(v.shape, dtype=torch.bfloat16) for k, v in sd.items()}
+        seen = st.stream_file(fn, lambda k, shape, dt: out[k] if k != "t2" else None)      # t2 is skipped by the router
+        assert set(seen) == set(sd) and st.bytes_moved > 0
+        for k in sd:
+            if k != "t2":
+                assert torch.equal(out[k], sd[k].to(torch.bfloat16)), (chunk, k)

@@ -196,6 +196,33 @@ def test_hip_graph_replay_is_bit_identical_to_eager_loop(golden, sname):
     assert mae(graphed, g[f"{sname}.bf16.final"]) < 1e-3
 
 
+def test_euler_update_in_proj_out_epilogue_is_bit_identical_to_the_scheduler_kernel(golden):
+    """north_star's "flow-matching Euler step fused into the residual add": the final projection's gated-residual epilogue
+    applies x' = x + bf16(dsigma * bf16(v)) in place on the latent columns of the x_embedder input (tfx_dit_desc.euler_gate;
+    no scheduler launch, no copy of the new latents into the next step's input).  Same rounding points as
+    FlowMatchEulerDiscreteScheduler.step (scheduling_flow_match_euler_discrete.py:319-330) applied to the stored model output:
+    every step of the trajectory is bit-identical, eagerly and as a replayed step graph."""
+    g = golden("g5_pipeline")
+    kw = dict(prompt_embeds=g["prompt_embeds"].to(BF).cuda(), pooled_prompt_embeds=g["pooled"].to(BF).cuda(),
+              latents=g["latents"].to(BF).cuda(), masked_image_latents=g["masked_image_latents"].to(BF).cuda(),
+              height=128, width=128, guidance_scale=30.0, output_type="latent")
+    pipe = make_pipe("euler")
+    outs = {}
+    for n in (1, 2, 4):
+        for fuse in (False, True):
+            pipe.fuse_euler_step = fuse
+            pipe.enable_hip_graph(False)
+            outs[(n, fuse, "eager")] = pipe(num_inference_steps=n, **kw).images
+            pipe.enable_hip_graph(True)
+            outs[(n, fuse, "graph")] = pipe(num_inference_steps=n, **kw).images
+        ref = outs[(n, False, "eager")]
+        for k, v in outs.items():
+            if k[0] == n:
+                assert torch.equal(v, ref), k
+    assert mae(outs[(4, True, "graph")], g["euler.bf16.final"]) < 1e-3
+    assert pipe.transformer._session.desc.euler_gate is not None        # the last call really ran fused
+
+
 def test_hip_graph_amo_internal_noise_runs():
     pipe = make_pipe("amo").enable_hip_graph(True)
     gi = torch.Generator().manual_seed(1)

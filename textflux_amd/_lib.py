@@ -72,6 +72,7 @@ class DitDesc(C.Structure):
         ("q8", c_void_p), ("q8_scale", c_void_p),
         ("gemm_workspace", c_void_p), ("gemm_workspace_bytes", c_int64),
         ("rope_cs", c_void_p),
+        ("euler_gate", c_void_p), ("euler_gate_bstride", c_int64),
     ]
 
 

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
 
 #endif  // TFX_BENCH
 
-static int g_attn_waves = 40;  // 40 (default) one wave per SIMD on the 16x16x32 MFMA (attention_w16.hip; grids smaller than the chip take 30); 30 one wave per SIMD, 64 rows per wave, 32x32x16 MFMA (attention_w4.hip); 10 matrix-pipe softmax, 8 waves x 32 rows; 8 exact-online-max lock-step kernel; 4 / 12 = 4-wave workgroups of 8 / 10; 9 = 128 keys per barrier; 16 = ping-pong
+static int g_attn_waves = 30;  // 30 (default) one wave per SIMD, 64 rows per wave, 32x32x16 MFMA (attention_w4.hip); 10 matrix-pipe softmax, 8 waves x 32 rows; 8 exact-online-max lock-step kernel; 4 / 12 = 4-wave workgroups of 8 / 10; 9 = 128 keys per barrier; 16 = ping-pong
 static int g_attn_force = 0;   // set by an explicit tfx_set_option("attention_waves", .): no size heuristic, the named kernel runs
 static unsigned long long* g_attn_dbg = nullptr;  // bench-only phase timing buffer
 void set_attention_debug(void* p) {
@@ -780,7 +780,7 @@ void set_attention_debug(void* p) {
 static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
 void set_attention_waves(int nw) {
-  if (nw == 0) { g_attn_force = 0; g_attn_waves = 40; return; }
+  if (nw == 0) { g_attn_force = 0; g_attn_waves = 30; return; }
   g_attn_force = 1; g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || nw == 30 || nw == 40) ? nw : 16;
 }
 
@@ -808,17 +808,11 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
   const uint64_t w4_rows = (uint64_t)((a.N + 63) / 64 + 3) * 64;
   const bool w4_ok = (a.ldo | a.o_bstride) % 8 == 0 && w4_rows * (uint64_t)a.ldk * 2 + 256 < (1ull << 32) &&
                      w4_rows * (uint64_t)a.ldv * 2 + 256 < (1ull << 32);
-  // 40 = the 16 x 16 x 32 kernel: 10 % fewer matrix cycles and joules per tile, ~30 % more instructions -- it wins where the chip is
-  // full and the power limit binds (+4 .. 10 % at batch 8), and loses ~6 % where a launch has fewer workgroups than CUs and
-  // only latency counts (batch 1 at 576 x 512: 168 workgroups), so those launches take 30
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-  }
-  const bool full_chip = (int64_t)a.B * a.H * ((a.N + 255) / 256) >= cus;
-  if (g_attn_waves == 40 && w4_ok && (full_chip || g_attn_force)) {     // same output-store and descriptor constraints as 30
+  // 40 = the 16 x 16 x 32 kernel (attention_w16.hip): fewer matrix cycles and, alone on the chip, 4 % faster than 30 (it sustains
+  // 2.23 GHz where 30 sustains 1.95) -- but ~9 % more wave cycles per tile (474 instructions against 358), and inside the DiT step
+  // the clock is set by the power-capped GEMMs around it (~1.7 GHz): there cycles decide and 40 measures 2 % SLOWER per forward
+  // (tools/dit_ab.py attention_waves=30,40: 481.5 vs 471.1 ms).  Kept selectable, not the default.
+  if (g_attn_waves == 40 && w4_ok) {     // same output-store and descriptor constraints as 30
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
     const int rc = joint_attention_w16(a, st);

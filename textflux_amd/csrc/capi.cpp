@@ -199,8 +199,17 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
     // norm_out (AdaLayerNormContinuous: chunk order scale, shift) + proj_out on the image rows (:1200-1203)
     const uint16_t* mo = mod + (int64_t)d.n_double * 12 * D + (int64_t)d.n_single * 3 * D;
     TRY(ln_modulate(hid_img, xn_img, mo + D, mo, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
-    TRY(Gemm(xn_img, D, hid_bs, d.proj_out, D, d.out, d.out_channels, (int64_t)Sn * d.out_channels, Sn, d.out_channels,
-             D, B).run(st));
+    if (d.euler_gate) {
+      // flow-matching Euler step in the epilogue: x' = x + bf16(dsigma * bf16(v)), in place on the latent columns of xin
+      // (gate = the step's dsigma in every column, residual = output = xin[:, :, :out_channels])
+      void* lat = const_cast<void*>(d.xin);
+      const int64_t xbs = (int64_t)Sn * d.in_channels;
+      TRY(Gemm(xn_img, D, hid_bs, d.proj_out, D, lat, d.in_channels, xbs, Sn, d.out_channels, D, B)
+              .gate_res(d.euler_gate, d.euler_gate_bstride, lat, d.in_channels, xbs).run(st));
+    } else {
+      TRY(Gemm(xn_img, D, hid_bs, d.proj_out, D, d.out, d.out_channels, (int64_t)Sn * d.out_channels, Sn, d.out_channels,
+               D, B).run(st));
+    }
   }
   return 0;
 }
@@ -474,6 +483,7 @@ int tfx_set_option(const char* name, int value) {
     return 0;
   }
   if (!std::strcmp(name, "gemm_group_m")) { set_gemm_group_m(value); return 0; }
+  if (!std::strcmp(name, "gemm_nt_store")) { set_gemm_nt_store(value); return 0; }
   if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
   if (!std::strcmp(name, "gemm_splitk")) { set_gemm_splitk(value); return 0; }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only
@@ -515,9 +525,17 @@ struct StepGraph { hipGraph_t graph; hipGraphExec_t exec; };
 
 int step_check(const tfx_step_desc* s) {
   if (!s) return fail("tfx_dit_step: null descriptor");
-  if (!s->mod_table || !s->mod_cur || !s->step_ptr || !s->latents || !s->coef) return fail("tfx_dit_step: null pointer in descriptor");
+  if (!s->mod_table || !s->mod_cur || !s->step_ptr) return fail("tfx_dit_step: null pointer in descriptor");
   if (s->dit.mod != s->mod_cur) return fail("tfx_dit_step: dit.mod must point at mod_cur (the rows the step selects)");
-  if (s->sampler != 0 && s->sampler != 1) return fail("tfx_dit_step: sampler must be 0 (Euler) or 1 (AMO)");
+  if (s->sampler < 0 || s->sampler > 2) return fail("tfx_dit_step: sampler must be 0 (Euler), 1 (AMO) or 2 (Euler fused into proj_out)");
+  if (s->sampler == 2) {
+    const char* g = (const char*)s->dit.euler_gate;
+    if (!g || g < (const char*)s->mod_cur || g >= (const char*)s->mod_cur + s->mod_step_elems * 2)
+      return fail("tfx_dit_step: sampler 2 needs dit.euler_gate inside mod_cur (the step's dsigma row is selected with its modulation rows)");
+    return 0;
+  }
+  if (s->dit.euler_gate) return fail("tfx_dit_step: dit.euler_gate is set but sampler is not 2");
+  if (!s->latents || !s->coef) return fail("tfx_dit_step: null pointer in descriptor");
   if (s->sampler == 1 && !s->noise) return fail("tfx_dit_step: the AMO sampler needs a noise buffer");
   if (!s->dit.out) return fail("tfx_dit_step: dit.out is null");
   return 0;
@@ -526,6 +544,7 @@ int step_check(const tfx_step_desc* s) {
 int step_enqueue(const tfx_step_desc& s, hipStream_t st) {
   TRY(select_step(s.mod_table, s.mod_cur, s.mod_step_elems, s.step_ptr, st));
   TRY(tfx_dit_forward(&s.dit, (tfx_stream)st));
+  if (s.sampler == 2) return advance_step(s.step_ptr, st);     // the update happened in proj_out's epilogue
   const int64_t rows = (int64_t)s.dit.B * s.dit.S;
   TRY(sched_step(s.sampler == 1, s.dit.out, s.latents, const_cast<void*>(s.dit.xin), s.dit.in_channels, s.dit.out_channels, rows,
                  s.coef, s.step_ptr, 0, s.noise, st));

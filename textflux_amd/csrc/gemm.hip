@@ -40,6 +40,7 @@ struct GemmParams {
   bf16_t* C; int64_t ldc, c_bs;
   int M, N, K, batch, tm, tn, gm;
   int gelu_from;
+  int nt_store;                                     // bench knob: C stores with the non-temporal policy (tfx_set_option gemm_nt_store)
   const bf16_t* gate; int64_t gate_bs;
   const bf16_t* res; int64_t ldr, r_bs;
   int cin, inH, inW, oH, oW, cstride, cup, cpad;   // implicit 3x3 convolution (cin > 0), see GemmArgs
@@ -369,7 +370,11 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
           for (int e = 0; e < 8; ++e) fv[e] += fr[e];
           val = pack8(fv);
         }
-        if (m < p.M && nst < p.N) *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst) = val;
+        if (m < p.M && nst < p.N) {
+          u32x4* dst = reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst);
+          if (p.nt_store) __builtin_nontemporal_store(val, dst);
+          else *dst = val;
+        }
       }
       if (HAS_RES && blk + RES_DEPTH < 4) {
         load_res(blk + RES_DEPTH, rr[blk % RES_DEPTH]);   // in flight while the next block is converted and staged
@@ -983,6 +988,8 @@ static int g_gemm_splitk = 1;     // 0 disables the split-K path (A/B knob)
 void set_gemm_splitk(int v) { g_gemm_splitk = v; }
 static int g_gemm_place = 2;      // request placement of the persistent kernel (bench knob, see gemm8pp_kernel)
 void set_gemm_place(int v) { g_gemm_place = v; }
+static int g_gemm_nt_store = 0;  // bench knob (see GemmParams::nt_store)
+void set_gemm_nt_store(int v) { g_gemm_nt_store = v; }
 static int g_gemm_group_m = 4;  // row tiles per group of the tile order (L2 locality knob)
 void set_gemm_group_m(int gm) { g_gemm_group_m = gm < 1 ? 1 : gm; }
 
@@ -995,6 +1002,7 @@ static GemmParams make_params(const GemmArgs& a) {
   p.M = a.M; p.N = a.N; p.K = a.K; p.batch = a.batch;
   p.tm = (a.M + 255) / 256; p.tn = (a.N + 255) / 256; p.gm = g_gemm_group_m;
   p.gelu_from = a.gelu_from_col;
+  p.nt_store = g_gemm_nt_store;
   p.gate = (const bf16_t*)a.gate; p.gate_bs = a.gate_bstride;
   p.res = (const bf16_t*)a.res; p.ldr = a.ldr; p.r_bs = a.r_bstride;
   p.cin = a.conv_cin; p.inH = a.conv_inH; p.inW = a.conv_inW; p.oH = a.conv_H; p.oW = a.conv_W;

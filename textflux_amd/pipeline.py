@@ -115,6 +115,7 @@ class FluxFillPipeline:
         self._device = transformer.device if transformer is not None else torch.device("cpu")
         self._guidance_scale, self._joint_attention_kwargs, self._num_timesteps, self._interrupt = None, None, 0, False
         self._use_hip_graph = False
+        self.fuse_euler_step = True     # Euler update in proj_out's GEMM epilogue (tfx_dit_desc.euler_gate); False = separate scheduler kernel
 
     # ------------------------------------------------------------------ loading / placement
     @classmethod
@@ -474,8 +475,27 @@ class FluxFillPipeline:
         is_amo = isinstance(sch, StochasticRFOvershotDiscreteScheduler)
         coef = sch.coef_table(dev, BF16)
         sch._step_index = 0 if sch.begin_index is None else sch.begin_index
+        # Euler update in proj_out's epilogue (north_star: "flow-matching Euler step fused into the residual add"): the step's
+        # bf16 dsigma travels as EULER_PAD extra columns of its modulation rows and gates the final projection; the latents
+        # live in xin[:, :, :C].  Not with a step callback (it wants the latents as a tensor every step) and not for AMO.
+        from .transformer import EULER_PAD
+        fuse = (self.fuse_euler_step and not is_amo and callback_on_step_end is None and sch._step_index == 0 and C == EULER_PAD
+                and tr.out_channels == C)
+        if fuse:
+            modx = torch.empty(n, B, tr.mod_len + EULER_PAD, dtype=BF16, device=dev)
+            modx[:, :, :tr.mod_len] = mod
+            modx[:, :, tr.mod_len:] = coef[:n].to(BF16).view(n, 1, 1)      # coef is already bf16-exact (coef_table)
+            mod = modx
         if self._use_hip_graph and callback_on_step_end is None and n > 1 and sch._step_index == 0:
-            return self._graph_loop(ses, mod, latents, coef, is_amo, amo_noise, n, progress_bar)
+            return self._graph_loop(ses, mod, latents, coef, is_amo, amo_noise, n, progress_bar, fuse)
+        if fuse:
+            for i, t in enumerate(timesteps):
+                if self._interrupt:
+                    continue
+                ses.run(mod[i], euler=True)
+                sch._step_index += 1
+                progress_bar.update()
+            return ops.copy_rows_(ses.xin[:, :, :C], torch.empty_like(latents))
         for i, t in enumerate(timesteps):
             if self._interrupt:
                 continue
@@ -507,7 +527,7 @@ class FluxFillPipeline:
         self._use_hip_graph = bool(on)
         return self
 
-    def _graph_loop(self, ses, mod, latents, coef, is_amo, amo_noise, n, progress_bar):
+    def _graph_loop(self, ses, mod, latents, coef, is_amo, amo_noise, n, progress_bar, fuse=False):
         """The loop as ONE captured step graph replayed n - 1 times (C ABI: tfx_dit_step_run / _capture / _replay; the
         hipGraph API is driven by the library, not by torch).  Capture needs a non-NULL stream: the loop runs on the
         session's side stream, fenced against the caller's current stream on both sides."""
@@ -515,12 +535,12 @@ class FluxFillPipeline:
         from . import _lib as L
         dev = latents.device
         gb = ses.graph_buffers(n, coef.numel(), latents.shape)
-        gb["mod_table"][:n].copy_(mod)
+        gb["mod_table"][:n, :, :mod.shape[2]].copy_(mod)
         gb["coef"][:coef.numel()].copy_(coef.reshape(-1))
         gb["lat"].copy_(latents)
         gb["step"].zero_()
         internal_noise = is_amo and amo_noise is None
-        sd = ses.step_desc(gb, is_amo)
+        sd = ses.step_desc(gb, is_amo, fuse)
         ses._mod_keepalive = gb["mod_cur"]
         lib = L.lib()
         cur = torch.cuda.current_stream(dev)
@@ -538,11 +558,11 @@ class FluxFillPipeline:
             feed_noise(0)
             L.check(lib.tfx_dit_step_run(C.byref(sd), st), "dit_step_run")     # eager step 0: also warms every kernel
             progress_bar.update()
-            key = (is_amo,)
+            key = (is_amo, fuse)
             g = ses.graphs.get(key)
             if g is None:
                 side.synchronize()
-                saved = [gb[k].clone() for k in ("lat", "step")] + [ses.xin.clone()]
+                saved = [gb[k].clone() for k in ("lat", "step")] + [ses.xin.clone()]     # (xin also holds the latents when fused)
                 h = C.c_void_p()
                 rc = lib.tfx_dit_step_capture(C.byref(sd), st, C.byref(h))
                 if rc != 0:     # capture refused (driver / runtime state): same kernels, launched eagerly
@@ -561,7 +581,7 @@ class FluxFillPipeline:
                 else:
                     L.check(lib.tfx_dit_step_replay(g, st), "dit_step_replay")
                 progress_bar.update()
-            out = gb["lat"].clone()
+            out = ops.copy_rows_(ses.xin[:, :, :latents.shape[2]], torch.empty_like(latents)) if fuse else gb["lat"].clone()
         out.record_stream(cur)
         cur.wait_stream(side)
         self.scheduler._step_index = n

@@ -29,6 +29,7 @@ from . import _lib as L
 from . import ops
 
 BF16 = torch.bfloat16
+EULER_PAD = 64     # columns appended to a step's modulation rows when the Euler update rides on proj_out's epilogue (= out_channels)
 
 
 def rope_tables(ids: torch.Tensor, axes_dim=(16, 56, 56), theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -451,16 +452,19 @@ class DitSession:
             self._gstream = torch.cuda.Stream(device=self.model.device)
         return self._gstream
 
-    def step_desc(self, gb, is_amo: bool) -> "L.StepDesc":
-        """tfx_step_desc of one denoising step over the persistent graph buffers `gb` (graph_buffers())."""
+    def step_desc(self, gb, is_amo: bool, fuse_euler: bool = False) -> "L.StepDesc":
+        """tfx_step_desc of one denoising step over the persistent graph buffers `gb` (graph_buffers()).  fuse_euler: sampler 2 --
+        the step's dsigma row (the EULER_PAD columns behind each modulation row) gates proj_out's epilogue, the latents live in xin."""
         d = self.desc
         d.mod, d.mod_bstride = gb["mod_cur"].data_ptr(), gb["mod_cur"].stride(0)
         d.first_block, d.last_block, d.flags = 0, -1, (4 if self.fp8 else 0)
+        d.euler_gate, d.euler_gate_bstride = (gb["mod_cur"].data_ptr() + 2 * self.model.mod_len, gb["mod_cur"].stride(0)) if fuse_euler else (None, 0)
         sd = L.StepDesc()
         sd.dit = d
         sd.mod_table, sd.mod_cur, sd.mod_step_elems = gb["mod_table"].data_ptr(), gb["mod_cur"].data_ptr(), gb["mod_cur"].numel()
         sd.step_ptr, sd.latents = gb["step"].data_ptr(), gb["lat"].data_ptr()
-        sd.coef, sd.noise, sd.sampler = gb["coef"].data_ptr(), gb["noise"].data_ptr() if is_amo else None, 1 if is_amo else 0
+        sd.coef, sd.noise = gb["coef"].data_ptr(), gb["noise"].data_ptr() if is_amo else None
+        sd.sampler = 1 if is_amo else 2 if fuse_euler else 0
         return sd
 
     def set_conditioning(self, prompt_embeds: torch.Tensor, txt_ids: torch.Tensor, img_ids: torch.Tensor) -> None:
@@ -487,22 +491,27 @@ class DitSession:
                 if g:
                     L.lib().tfx_graph_destroy(g)
             self.graphs = {}
+            W = self.model.mod_len + EULER_PAD     # every row carries the step's dsigma behind its modulation values
             gb = self._gb = dict(
-                mod_table=torch.empty(n_steps, self.B, self.model.mod_len, dtype=BF16, device=dev),
-                mod_cur=torch.empty(self.B, self.model.mod_len, dtype=BF16, device=dev),
+                mod_table=torch.empty(n_steps, self.B, W, dtype=BF16, device=dev),
+                mod_cur=torch.empty(self.B, W, dtype=BF16, device=dev),
                 coef=torch.zeros(max(n_coef, 3 * n_steps), dtype=torch.float32, device=dev),
                 lat=torch.empty(lat_shape, dtype=BF16, device=dev),
                 noise=torch.zeros(lat_shape, dtype=torch.float32, device=dev),
                 step=torch.zeros(1, dtype=torch.int32, device=dev))
         return gb
 
-    def run(self, mod: torch.Tensor, first_block: int = 0, last_block: int = -1, flags: int = 0) -> torch.Tensor:
+    def run(self, mod: torch.Tensor, first_block: int = 0, last_block: int = -1, flags: int = 0, euler: bool = False) -> torch.Tensor:
         """One transformer forward with modulation rows `mod` [B, mod_len] (a view into a table is fine).
-        first_block/last_block/flags: partial runs for block-level tests (see tfx_dit_desc)."""
-        assert mod.shape == (self.B, self.model.mod_len) and mod.stride(1) == 1 and self._ids_key is not None
+        first_block/last_block/flags: partial runs for block-level tests (see tfx_dit_desc).  euler: `mod` rows are mod_len +
+        EULER_PAD wide, the extra columns hold the step's bf16 dsigma: proj_out's epilogue applies the Euler update in place on
+        xin[:, :, :out_channels] (tfx_dit_desc.euler_gate) and `out` is not written."""
+        W = self.model.mod_len + (EULER_PAD if euler else 0)
+        assert mod.shape == (self.B, W) and mod.stride(1) == 1 and self._ids_key is not None
         self._mod_keepalive = mod
         d = self.desc
         d.mod, d.mod_bstride = mod.data_ptr(), mod.stride(0)
+        d.euler_gate, d.euler_gate_bstride = (mod.data_ptr() + 2 * self.model.mod_len, mod.stride(0)) if euler else (None, 0)
         d.first_block, d.last_block, d.flags = first_block, last_block, flags | (4 if self.fp8 else 0)
         L.check(L.lib().tfx_dit_forward(C.byref(d), ops._stream()), "dit_forward")
         return self.out

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--dir", default="/dev/shm/tfx_ckpt")
     ap.add_argument("--layers", type=int, nargs=2, default=[19, 38])
     ap.add_argument("--out", default="gpurun_out/r03_loader.json")
+    ap.add_argument("--sweep", action="store_true", help="also time threads x chunk x buffers combinations of the streamer")
     a = ap.parse_args()
     cfg = dict(in_channels=384, out_channels=64, num_layers=a.layers[0], num_single_layers=a.layers[1], attention_head_dim=128,
                num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True,
@@ -106,6 +107,19 @@ def main():
             assert all(torch.equal(ref[k], m.w[k]) for k in ref), "the two loaders disagree"
         del m
         torch.cuda.empty_cache()
+    if a.sweep:
+        rec["sweep"] = []
+        for cfg_s in ("8,256,2", "16,128,3", "32,128,3", "16,64,4", "32,64,4", "24,256,2"):
+            os.environ["TFX_LOADER"] = cfg_s
+            t0 = time.time()
+            m = FluxTransformer2DModel.from_pretrained(a.dir)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            rec["sweep"].append(dict(threads_chunkMiB_buffers=cfg_s, seconds=round(dt, 2), gb_per_s=round(total / dt / 1e9, 2)))
+            print(rec["sweep"][-1], flush=True)
+            del m
+            torch.cuda.empty_cache()
+        os.environ.pop("TFX_LOADER", None)
     shutil.rmtree(a.dir, ignore_errors=True)
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, "w") as f:

@@ -31,6 +31,9 @@ VARIANTS = [
     ("16x16x32 wave128x128 + 32 ds_read + 16 LDS-DMA + barrier / K-tile", 16, 8, 8, "astat", "a", 4, 32, 16, 1),
     ("16x16x32 wave128x128 + 32 ds_read + 16 LDS-DMA (all in 2nd half) + barrier", 16, 8, 8, "astat", "a", 4, 32, 16, 2),
     ("16x16x32 wave128x128 + 32 ds_read + 16 buffer_load->VGPR + 16 ds_write_b128 + barrier", 16, 8, 8, "astat", "a", 4, 32, 16, 3),
+    # the shipped structure (gemm8pp): 8 waves = 2 row groups ping-ponging one barrier apart, wave tile 128x64; per wave and K-tile 4 x
+    # (loads section: 6 fragment reads + 2 LDS-DMA requests | barrier | 16 MFMAs | barrier)
+    ("16x16x32 wave128x64 8w ping-pong: 4 x (6 ds_read + 2 LDS-DMA | barrier | 16 MFMA | barrier)", 16, 8, 4, "astat", "v", 8, 24, 8, 4),
 ]
 
 
@@ -61,6 +64,11 @@ def kernel(idx, shape, MI, NJ, order, accf, waves, n_ds=0, n_dma=0, mode=0):
         for k in range(8):
             L.append(f"s_add_u32 s{22 + k}, %5, {k * 2048}")    # M0 values: 8 x 2 KiB slots of this wave's LDS slice
         L.append("s_nop 4")
+    if mode == 4:
+        L.append("s_cmp_lt_u32 %6, 4")           # waves 4..7: the second row group starts one barrier late
+        L.append("s_cbranch_scc1 9f")
+        L.append("s_barrier")
+        L.append("9:")
     L.append("s_mov_b32 s20, %1")                # tiles
     L.append("1:")
     for r in range(nacc):
@@ -96,7 +104,7 @@ def kernel(idx, shape, MI, NJ, order, accf, waves, n_ds=0, n_dma=0, mode=0):
     nm = len(seq)
     fill = {}
     if n_ds or n_dma:
-        assert op_end <= 224
+        assert op_end <= 224 and (mode != 4 or acc0 + nacc <= 232)
         ds_at = [int((k + 0.5) * nm / n_ds) for k in range(n_ds)] if n_ds else []
         if mode == 2:
             dma_at = [nm // 2 + int((k + 0.5) * (nm // 2) / n_dma) for k in range(n_dma)] if n_dma else []
@@ -112,7 +120,28 @@ def kernel(idx, shape, MI, NJ, order, accf, waves, n_ds=0, n_dma=0, mode=0):
             else:
                 fill.setdefault(pos, []).append(f"s_mov_b32 m0, s{22 + (k % 8)}")
                 fill.setdefault(pos, []).append(f"global_load_lds_dwordx4 v[4:5], off offset:{(k % 4) * 1024}")
-    for n_, (i, j, kk) in enumerate(seq):
+    if mode == 4:
+        # group 1 (waves 4..7) runs one barrier behind group 0: it executes one extra barrier before the loop (s30 = wave >> 2)
+        sec = nm // 4
+        for q in range(4):
+            for k in range(n_ds // 4):
+                L.append(f"ds_read_b128 v[{232 + 4 * (k % 4)}:{235 + 4 * (k % 4)}], v2 offset:{((q * 6 + k) % 16) * 1024}")
+            for k in range(n_dma // 4):
+                L.append(f"s_mov_b32 m0, s{22 + ((q * 2 + k) % 8)}")
+                L.append(f"global_load_lds_dwordx4 v[4:5], off offset:{((q * 2 + k) % 4) * 1024}")
+            L.append("s_waitcnt vmcnt(6)")
+            L.append("s_barrier")
+            L.append("s_setprio 1")
+            L.append("s_waitcnt lgkmcnt(0)")
+            for (i, j, kk) in seq[q * sec:(q + 1) * sec]:
+                c = rng(accf, C(i, j), accw)
+                L.append(f"{mn} {c}, {rng('v', A(j, kk), 4)}, {rng('v', B(i, kk), 4)}, {c}")
+            L.append("s_setprio 0")
+            L.append("s_barrier")
+        seq_emit = []
+    else:
+        seq_emit = seq
+    for n_, (i, j, kk) in enumerate(seq_emit):
         if mode in (1, 2, 3) and n_ == nm // 2:
             L.append("s_waitcnt vmcnt(%d)" % (4 if mode == 3 else 0))
             L.append("s_waitcnt lgkmcnt(0)")
@@ -131,10 +160,15 @@ def kernel(idx, shape, MI, NJ, order, accf, waves, n_ds=0, n_dma=0, mode=0):
     L.append("s_sub_u32 s20, s20, 1")
     L.append("s_cmp_lg_u32 s20, 0")
     L.append("s_cbranch_scc1 1b")
+    if mode == 4:
+        L.append("s_cmp_lt_u32 %6, 4")
+        L.append("s_cbranch_scc0 8f")
+        L.append("s_barrier")
+        L.append("8:")
     clob = [f"v{r}" for r in range(a0, op_end)] + [f"{accf}{acc0 + r}" for r in range(nacc)] + ["s20", "s21", "scc"]
     mix = bool(n_ds or n_dma)
     if mix:
-        clob += ["v2", "v4", "v5", "m0"] + [f"v{r}" for r in range(224, 256)] + [f"s{22 + k}" for k in range(8)]
+        clob += ["v2", "v4", "v5"] + [f"v{r}" for r in (range(232, 248) if mode == 4 else range(224, 256))] + [f"s{22 + k}" for k in range(8)]
     body = "\\n\\t".join(L)
     clobs = ", ".join(f'"{c}"' for c in clob)
     flops_per_ktile = len(seq) * (32 * 32 * 16 * 2 if shape == 32 else 16 * 16 * 32 * 2)
@@ -148,7 +182,8 @@ __global__ __launch_bounds__({64 * waves}) void k{idx}(const char* src, int tile
   const unsigned long long gp = (unsigned long long)(src + (size_t)(blockIdx.x * {waves} + (threadIdx.x >> 6)) * 8192 + lane16);
   const unsigned lo = (unsigned)gp, hi = (unsigned)(gp >> 32);
   const unsigned wbase = __builtin_amdgcn_readfirstlane(32768u + (threadIdx.x >> 6) * 16384u + (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
-  asm volatile("{body}" :: "v"(p), "s"(tiles), "v"(lane16), "v"(lo), "v"(hi), "s"(wbase) : {clobs}, "memory");
+  const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  asm volatile("{body}" :: "v"(p), "s"(tiles), "v"(lane16), "v"(lo), "v"(hi), "s"(wbase), "s"(wv) : {clobs}, "memory");
 }}
 """
     else:
