@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r03; mkdir -p $out
 # 1. kernel-trace summary of the default bench run (eager, so that every launch is in the trace) + its bench line
 rocprofv3 --kernel-trace --stats -d $out/trace -o r03 --output-format csv -- python bench.py --no-cpu-baseline --no-graph --steps 1 --warmup 1 > $out/bench_under_rocprof.log 2>&1
-tail -1 $out/bench_under_rocprof.log > $out/r03_bench_under_rocprof.json
+grep "^{\"metric\"" $out/bench_under_rocprof.log > $out/r03_bench_under_rocprof.json
 cp $out/trace/*kernel_stats.csv $out/r03_bench_kernel_stats.csv 2>/dev/null
 # 2. matrix-pipe busy over a 2-step bench
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/mfma -o r03 --output-format csv -- python bench.py --no-cpu-baseline --no-graph --steps 1 --warmup 0 --denoise-steps 2 > $out/mfma.log 2>&1
