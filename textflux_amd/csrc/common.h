@@ -47,9 +47,10 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 // Evaluated as x * sigmoid(2u) = x / (1 + 2^(-2u log2 e)) with the hardware v_exp_f32 / v_rcp_f32 (1 ulp each, far
 // below the bf16 output rounding); ocml tanhf costs ~4x more VALU in the GEMM epilogue.
 __device__ __forceinline__ float gelu_tanh(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float u = k0 * (x + k1 * x * x * x);
-  const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * u);  // exp(-2u)
+  // -2 u log2(e) = x * (c0 + c1 x^2): 3 multiply-adds in front of the two transcendental ops (each costs two VALU slots, tools/ubench/valu_rate)
+  const float c0 = -2.3022081981443252f, c1 = -0.10294323958002349f;
+  const float z = x * __builtin_fmaf(x * x, c1, c0);
+  const float e = __builtin_amdgcn_exp2f(z);  // exp(-2u)
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }

@@ -48,7 +48,9 @@ struct GemmParams {
   bf16_t* C; int64_t ldc, c_bs;
   int M, N, K, batch, tm, tn, gm;
   int gelu_from;
-  int nt_store;                                     // bench knob: C stores with the non-temporal policy (tfx_set_option gemm_nt_store)
+#ifdef TFX_BENCH
+  unsigned long long* timers;                       // bench only: s_memtime sums of wave 0 / wave 4 {K loop, epilogue wait, epilogue, tiles}
+#endif
   const bf16_t* gate; int64_t gate_bs;
   const bf16_t* res; int64_t ldr, r_bs;
   int cin, inH, inW, oH, oW, cstride, cup, cpad;   // implicit 3x3 convolution (cin > 0), see GemmArgs
@@ -159,16 +161,19 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* smem, uint32_t lds
 // no dependent pair is ever back to back); e4m3: one v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) per accumulator =
 // 8 MFMAs of 8 passes.  256 matrix-pipe cycles either way.  WF[j][s] / XF[i][s]: fragment of column block j / row block i, 16-byte
 // piece s of the lane's K-tile bytes.
-template <bool FP8, bool HALF = false, int S0 = 0>
+template <bool FP8, bool HALF = false, int S0 = 0, bool ZERO = false>
 __device__ __forceinline__ void mfma_section(f32x4 (&acc)[8][4], const bf16x8 (&WF)[2][2], const bf16x8 (&XF)[4][2], const int MIB,
                                              const int NJB) {
+  // ZERO: the section's first MFMA into each accumulator takes a zero C operand (the first K-tile of a tile: no 128 v_mov per tile)
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   if constexpr (FP8) {
 #pragma unroll
     for (int j = (HALF ? S0 : 0); j < (HALF ? S0 + 1 : 2); ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         acc[MIB + i][NJB + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(TFX_CAT(WF[j][0], WF[j][1]), TFX_CAT(XF[i][0], XF[i][1]),
-                                                                                 acc[MIB + i][NJB + j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                                                                                 ZERO ? z : acc[MIB + i][NJB + j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                                 0x7f7f7f7f);
   } else {
 #pragma unroll
     for (int s = (HALF ? S0 : 0); s < (HALF ? S0 + 1 : 2); ++s)
@@ -176,7 +181,8 @@ __device__ __forceinline__ void mfma_section(f32x4 (&acc)[8][4], const bf16x8 (&
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[MIB + i][NJB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j][s], XF[i][s], acc[MIB + i][NJB + j], 0, 0, 0);
+          acc[MIB + i][NJB + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[j][s], XF[i][s], (ZERO && s == 0) ? z : acc[MIB + i][NJB + j], 0, 0, 0);
   }
 }
 // the intrinsics are pure: nothing but this keeps hipcc from moving a section's MFMAs across the barriers around it
@@ -186,6 +192,12 @@ __device__ __forceinline__ void mfma_section(f32x4 (&acc)[8][4], const bf16x8 (&
         asm volatile("" : "+v"(acc[(MIB) + i_][(NJB) + j_]));                                                            \
   } while (0)
 
+// bench-only phase timers of the persistent kernel (tools/gemm_phase_timers.py): s_memtime stamps in SGPRs
+#ifdef TFX_BENCH
+#define TFX_STAMP(i) (tfx_stamp[i] = __builtin_amdgcn_s_memtime())
+#else
+#define TFX_STAMP(i) ((void)0)
+#endif
 // ------------------------------------------------------------------------------------------------
 // Epilogue of one 256 x 256 tile, shared by the two MFMA kernels.  With the operands swapped (MFMA "A" = weight rows, "B" =
 // token rows) lane l of a wave holds, per (mi, nj), FOUR CONSECUTIVE OUTPUT COLUMNS of one token row:
@@ -199,7 +211,8 @@ __device__ __forceinline__ void mfma_section(f32x4 (&acc)[8][4], const bf16x8 (&
 // `stg_partner`: the staging tile of the wave that owns the other 64 columns of this wave's heads (QKN only).
 template <int EPI, bool FP8, bool QKN, int RES_DEPTH>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmParams& p, const int m0, const int n0, const int b,
-                                              const int g, const int wc, const int lane, char* stg, const char* stg_partner) {
+                                              const int g, const int wc, const int lane, char* stg, const char* stg_partner,
+                                              unsigned long long* tfx_stamp = nullptr) {
   // lane-derived offsets are rebuilt from an opaque copy of the lane id: derived from `lane` they are loop invariants that
   // hipcc keeps in ~20 VGPRs across the K loop, which is what pushes the kernel into spilling
   int lane_e = lane;
@@ -210,13 +223,26 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
   const int crow = lane_e >> 3, cchunk = lane_e & 7;
   const int nst = n0 + wc * 64 + cchunk * 8;
   constexpr bool HAS_RES = (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES);
-  const bf16_t* resp = HAS_RES ? p.res + b * p.r_bs + min(nst, p.N - 8) : nullptr;
+  // C, the residual, bias and gate are addressed through buffer descriptors whose range check does the edge handling: a lane
+  // whose row is beyond M or whose 8 columns start beyond N carries an out-of-range offset, its loads return zero and its stores
+  // are dropped -- no branch around any access, so hipcc batches a block's LDS reads and stores instead of serialising
+  // {branch, ds_read, wait, store} per row.  Descriptors start at this wave's first row (wave-uniform 64-bit address).
+  const int rows_ok = min(max(p.M - m0 - g * 128, 0), 128);               // valid rows of this wave's 128
+  constexpr uint32_t OOR = 0x80000000u;                                     // >= every num_records below
+  auto uniform_rsrc = [](const void* base, int bytes) {   // scalar (SGPR) descriptor: otherwise every access sits in a waterfall loop
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |   // (the builtin returns a signed int)
+                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  const auto rsrcC = uniform_rsrc(p.C + b * p.c_bs + (int64_t)(m0 + g * 128) * p.ldc, rows_ok ? (int)(((int64_t)(rows_ok - 1) * p.ldc + p.N) * 2) : 0);
+  const auto rsrcR = uniform_rsrc(HAS_RES ? p.res + b * p.r_bs + (int64_t)(m0 + g * 128) * p.ldr : p.C,
+                                  HAS_RES && rows_ok ? (int)(((int64_t)(rows_ok - 1) * p.ldr + p.N) * 2) : 0);
+  const uint32_t col_off = nst < p.N ? (uint32_t)nst * 2u : OOR;          // N % 8 == 0: a lane's 8 columns are all in or all out
   auto load_res = [&](int blk, u32x4 (&rr)[4]) {
 #pragma unroll
-    for (int itr = 0; itr < 4; ++itr) {
-      const int m = min(m0 + g * 128 + blk * 32 + itr * 8 + crow, p.M - 1);
-      rr[itr] = *reinterpret_cast<const u32x4*>(resp + (int64_t)m * p.ldr);
-    }
+    for (int itr = 0; itr < 4; ++itr)
+      rr[itr] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)((uint32_t)(blk * 32 + itr * 8 + crow) * (uint32_t)(p.ldr * 2) + col_off), 0, 0);
   };
   if constexpr (FP8) {
     // dequantise in place first (row scale x channel scale): the scale registers are dead before bias / gate / residual are
@@ -240,12 +266,12 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
   }
   u32x2 bsr[4], gtr[4];   // bias / gate stay packed (bf16 pairs) until they are used
   u32x4 rr[RES_DEPTH][4];
+  const auto rsrcB = uniform_rsrc(p.bias ? p.bias : p.C, p.bias ? p.N * 2 : 0);
+  const auto rsrcG = uniform_rsrc(EPI == EPI_BIAS_GATE_RES ? p.gate + b * p.gate_bs : p.C, EPI == EPI_BIAS_GATE_RES ? p.N * 2 : 0);
 #pragma unroll
-  for (int nj = 0; nj < 4; ++nj) {
-    const int n = ncol + nj * 16;
-    const int nc = n < p.N ? n : 0;  // columns beyond N are computed but never stored
-    bsr[nj] = p.bias ? *reinterpret_cast<const u32x2*>(p.bias + nc) : u32x2{0u, 0u};
-    if (EPI == EPI_BIAS_GATE_RES) gtr[nj] = *reinterpret_cast<const u32x2*>(p.gate + b * p.gate_bs + nc);
+  for (int nj = 0; nj < 4; ++nj) {   // no bias / columns beyond N: zeros (computed, never stored)
+    bsr[nj] = __builtin_amdgcn_raw_buffer_load_b64(rsrcB, (ncol + nj * 16) * 2, 0, 0);
+    if (EPI == EPI_BIAS_GATE_RES) gtr[nj] = __builtin_amdgcn_raw_buffer_load_b64(rsrcG, (ncol + nj * 16) * 2, 0, 0);
   }
   if (HAS_RES) {
 #pragma unroll
@@ -257,6 +283,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
   // loads and stores retire out of order with respect to each other, so the counted waits of the next K loop are only
   // meaningful once these have landed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TFX_STAMP(1);
   float rinv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   u32x4 nw8 = u32x4{0u, 0u, 0u, 0u};     // norm weights of the 8 columns this lane stores (norm tiles)
   if (norm_tile) {
@@ -295,8 +322,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) rinv[mi] = rsqrtf((ss[mi] + (mi < 4 ? o0[mi & 3] : o1[mi & 3])) * (1.0f / 128.0f) + p.n_eps);
   }
-  auto store_blocks = [&](auto NORM_T) __attribute__((always_inline)) {
+  // NORM / GELU are per-tile (block-uniform) properties: one straight-line instantiation each instead of a branch per element group
+  auto store_blocks = [&](auto NORM_T, auto GELU_T) __attribute__((always_inline)) {
     constexpr bool NORM = decltype(NORM_T)::value;
+    constexpr bool GELU = decltype(GELU_T)::value;
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
       // (cos, sin) pairs of the four rows this lane stores from this row block, requested before the block is converted
@@ -328,7 +357,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][e] + bs[e];
           }
-          if (do_gelu) {
+          if (GELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
           }
@@ -352,7 +381,6 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
 #pragma unroll
       for (int itr = 0; itr < 4; ++itr) {
         const int row = itr * 8 + crow;
-        const int m = m0 + g * 128 + blk * 32 + row;
         u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((cchunk ^ ((row >> 1) & 7)) << 4));
         if (NORM) {
           // this lane now holds 8 consecutive columns (4 rotation pairs) of row `row`: its 1/rms sits in every lane whose l & 15 is
@@ -378,11 +406,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
           for (int e = 0; e < 8; ++e) fv[e] += fr[e];
           val = pack8(fv);
         }
-        if (m < p.M && nst < p.N) {
-          u32x4* dst = reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + nst);
-          if (p.nt_store) __builtin_nontemporal_store(val, dst);
-          else *dst = val;
-        }
+        __builtin_amdgcn_raw_buffer_store_b128(val, rsrcC, (int)((uint32_t)(blk * 32 + row) * (uint32_t)(p.ldc * 2) + col_off), 0, 0);
       }
       if (HAS_RES && blk + RES_DEPTH < 4) {
         load_res(blk + RES_DEPTH, rr[blk % RES_DEPTH]);   // in flight while the next block is converted and staged
@@ -391,8 +415,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
       if (QKN) __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (QKN && norm_tile) store_blocks(std::true_type{});
-  else store_blocks(std::false_type{});
+  if (QKN && norm_tile) store_blocks(std::true_type{}, std::false_type{});   // q / k columns lie in front of gelu_from
+  else if (EPI == EPI_BIAS_GELU && do_gelu) store_blocks(std::false_type{}, std::true_type{});
+  else store_blocks(std::false_type{}, std::false_type{});
 }
 
 // ABL (bench-only ablations with WRONG results by construction, never dispatched by the product path; tools/
@@ -815,16 +840,16 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   bf16x8 xf[4][2], wlo[2][2], whi[2][2];
 #define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-#define PP_MFMA16(WF, MIB, NJB)                                                                              \
+#define PP_MFMA16(WF, MIB, NJB, Z)                                                                           \
   do {                                                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
-    mfma_section<FP8>(acc, WF, xf, MIB, NJB);                                                                \
+    mfma_section<FP8, false, 0, Z>(acc, WF, xf, MIB, NJB);                                                   \
     TFX_PIN_SECTION(MIB, NJB);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
   // one K-tile out of buffer set SET; (GO, XO, WO, KT) = the operands requested meanwhile (two K-tiles ahead)
-#define PP_TILE_W(SET, GO, XO, WO, KT, W0, W1, W3)                                                           \
+#define PP_TILE_W(SET, GO, XO, WO, KT, W0, W1, W3, Z)                                                        \
   do {                                                                                                       \
     constexpr uint32_t xs = (SET) * 16384u, ws = (SET) * 32768u;                                             \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) {               /* L0: X_lo, W_lo */                       \
@@ -833,32 +858,38 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     }                                                                                                        \
     if (W0) PP_VMCNT(10);                                                                                    \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA16(wlo, 0, 0);                                                                                    \
+    PP_MFMA16(wlo, 0, 0, Z);                                                                                 \
     TFX_BARRIER();                                                                                           \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                 /* L1: W_hi */                             \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) whi[j][s] = LDS_FRAG(fw[s] + ws + 4096 + j * 2048);      \
     stage(0, GO, XO, WO, KT, SET);                                                                           \
     if (PLACE == 1) { stage(1, GO, XO, WO, KT, SET); if (W1) PP_VMCNT(12); } else { if (W1) PP_VMCNT(10); }  \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA16(whi, 0, 2);                                                                                    \
+    PP_MFMA16(whi, 0, 2, Z);                                                                                 \
     TFX_BARRIER();                                                                                           \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                 /* L2: X_hi */                             \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) xf[i][s] = LDS_FRAG(fx[s] + xs + 8192 + i * 2048);       \
     if (PLACE != 1) stage(1, GO, XO, WO, KT, SET);                                                           \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA16(whi, 4, 2);                                                                                    \
+    PP_MFMA16(whi, 4, 2, Z);                                                                                 \
     TFX_BARRIER();                                                                                           \
     stage(2, GO, XO, WO, KT, SET);                                /* L3: no reads */                         \
     stage(3, GO, XO, WO, KT, SET);                                                                           \
     if (W3) PP_VMCNT(12);                                                                                    \
     TFX_BARRIER();                                                                                           \
-    PP_MFMA16(wlo, 4, 0);                                                                                    \
+    PP_MFMA16(wlo, 4, 0, Z);                                                                                 \
     TFX_BARRIER();                                                                                           \
   } while (0)
-#define PP_TILE(SET, GO, XO, WO, KT) PP_TILE_W(SET, GO, XO, WO, KT, 1, 1, 1)
+#define PP_TILE(SET, GO, XO, WO, KT) PP_TILE_W(SET, GO, XO, WO, KT, 1, 1, 1, false)
 
   char* stg = smem + PP_STG + wave * PP_STG_WAVE;
+#ifdef TFX_BENCH
+  unsigned long long tfx_stamp[4] = {0, 0, 0, 0}, tfx_sum[4] = {0, 0, 0, 0};
+#else
+  unsigned long long* tfx_stamp = nullptr;
+#endif
   for (;;) {
+    TFX_STAMP(3);
     const int nit = it + per_xcd;
     const bool has_next = nit < xcnt;
     // the last tile of the block re-requests its own first K-tiles: harmless (nobody reads them) and keeps the
@@ -866,22 +897,23 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     const Tile nxt = coords(xstart + (has_next ? nit : it));
     offsets(nxt, gon);
     const uint32_t cx = cur.xoff, cw = cur.woff, nx = nxt.xoff, nw = nxt.woff;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
     // Everything K-tiles 0 and 1 read was waited for before this tile started (prologue / the epilogue's vmcnt(0)), and
     // the first requests of THIS tile have their deadline at L3 of K-tile 1: the earlier counted waits could only stall
-    // on the previous epilogue's stores, which retire in issue order with the requests.
+    // on the previous epilogue's stores, which retire in issue order with the requests.  The first K-tile's MFMAs start from
+    // a zero C operand instead of zeroed accumulators.
     int u0 = 0;
     // (not in the fp8 gated-residual instantiation: there the two extra loop bodies tip hipcc's allocation into spills)
     if (nt >= 4 && !(FP8 && EPI == EPI_BIAS_GATE_RES)) {
-      PP_TILE_W(0, goc, cx, cw, 2, 0, 0, 0);
-      PP_TILE_W(1, goc, cx, cw, 3, 0, 0, 1);
+      PP_TILE_W(0, goc, cx, cw, 2, 0, 0, 0, true);
+      PP_TILE_W(1, goc, cx, cw, 3, 0, 0, 1, false);
       u0 = 2;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
     }
     for (int u = u0; u < nt - 2; u += 2) {
       PP_TILE(0, goc, cx, cw, u + 2);
@@ -889,6 +921,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     }
     PP_TILE(0, gon, nx, nw, 0);  // K-tiles nt-2, nt-1: their requests are the next tile's K-tiles 0 and 1
     PP_TILE(1, gon, nx, nw, 1);
+    TFX_STAMP(0);
 
     // ---- epilogue (tile_epilogue), one 32-row block of the accumulators at a time
     if (SPLIT) {
@@ -914,8 +947,15 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
       }
     } else {
       tile_epilogue<EPI, FP8, QKN, (FP8 ? 1 : 2)>(acc, p, cur.m0, cur.n0, cur.b, g, wc, lane, stg,
-                                                  smem + PP_STG + (wave ^ 1) * PP_STG_WAVE);
+                                                  smem + PP_STG + (wave ^ 1) * PP_STG_WAVE, tfx_stamp);
     }
+#ifdef TFX_BENCH
+    TFX_STAMP(2);
+    tfx_sum[0] += tfx_stamp[0] - tfx_stamp[3];   // K loop (incl. next-tile bookkeeping)
+    tfx_sum[1] += tfx_stamp[1] - tfx_stamp[0];   // epilogue: operand / bias requests drained
+    tfx_sum[2] += tfx_stamp[2] - tfx_stamp[1];   // epilogue: convert, stage, store issue
+    tfx_sum[3] += 1;
+#endif
     if (!has_next) break;
     cur = nxt;
     it = nit;
@@ -926,6 +966,10 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   }
   if (g == 0) TFX_BARRIER();  // pairs with G1's extra barrier of the prologue
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the closing requests must not land in a successor's LDS
+#ifdef TFX_BENCH
+  if (p.timers && wc == 0 && lane == 0)
+    for (int i = 0; i < 4; ++i) atomicAdd(p.timers + g * 4 + i, tfx_sum[i]);
+#endif
 #undef LDS_FRAG
 #undef PP_VMCNT
 #undef PP_MFMA16
@@ -996,8 +1040,10 @@ static int g_gemm_splitk = 1;     // 0 disables the split-K path (A/B knob)
 void set_gemm_splitk(int v) { g_gemm_splitk = v; }
 static int g_gemm_place = 2;      // request placement of the persistent kernel (bench knob, see gemm8pp_kernel)
 void set_gemm_place(int v) { g_gemm_place = v; }
-static int g_gemm_nt_store = 0;  // bench knob (see GemmParams::nt_store)
-void set_gemm_nt_store(int v) { g_gemm_nt_store = v; }
+#ifdef TFX_BENCH
+static unsigned long long* g_gemm_timers = nullptr;   // device buffer of 8 counters (tools/gemm_phase_timers.py)
+extern "C" void tfx_bench_gemm_timers(unsigned long long* dev) { g_gemm_timers = dev; }
+#endif
 static int g_gemm_group_m = 4;  // row tiles per group of the tile order (L2 locality knob)
 void set_gemm_group_m(int gm) { g_gemm_group_m = gm < 1 ? 1 : gm; }
 
@@ -1010,7 +1056,9 @@ static GemmParams make_params(const GemmArgs& a) {
   p.M = a.M; p.N = a.N; p.K = a.K; p.batch = a.batch;
   p.tm = (a.M + 255) / 256; p.tn = (a.N + 255) / 256; p.gm = g_gemm_group_m;
   p.gelu_from = a.gelu_from_col;
-  p.nt_store = g_gemm_nt_store;
+#ifdef TFX_BENCH
+  p.timers = g_gemm_timers;
+#endif
   p.gate = (const bf16_t*)a.gate; p.gate_bs = a.gate_bstride;
   p.res = (const bf16_t*)a.res; p.ldr = a.ldr; p.r_bs = a.r_bstride;
   p.cin = a.conv_cin; p.inH = a.conv_inH; p.inW = a.conv_inW; p.oH = a.conv_H; p.oW = a.conv_W;
@@ -1209,6 +1257,8 @@ bool gemm_qkn_ok(const GemmArgs& a) {
   const GemmParams p = make_params(a);
   if (!persist_ok(p)) return false;
   if ((a.qkn_q0 | a.qkn_q1 | a.qkn_k0 | a.qkn_k1) % 256) return false;
+  // the normalised columns carry no activation (the epilogue instantiates norm and GELU tiles separately)
+  if (a.epilogue == EPI_BIAS_GELU && a.gelu_from_col < (a.qkn_q1 > a.qkn_k1 ? a.qkn_q1 : a.qkn_k1)) return false;
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;

@@ -58,7 +58,6 @@ struct GemmArgs {
   void* workspace = nullptr; int64_t workspace_bytes = 0;
 };
 void set_gemm_group_m(int gm);
-void set_gemm_nt_store(int v);
 void set_gemm_place(int v);
 void set_gemm_splitk(int v);
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback

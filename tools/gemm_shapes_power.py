@@ -25,7 +25,13 @@ def main():
     ap.add_argument("--secs", type=float, default=2.5)
     ap.add_argument("--out", default="gpurun_out/r03_gemm_shapes.jsonl")
     ap.add_argument("--hipblaslt", action="store_true")
+    ap.add_argument("--place", type=int, default=0, help="tfx_set_option gemm_place (bench knob)")
+    ap.add_argument("--opt", action="append", default=[], help="name=value for tfx_set_option (bench knobs)")
     a = ap.parse_args()
+    for kv in a.opt:
+        ops.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    if a.place:
+        ops.set_option("gemm_place", a.place)
     M = 36864          # 8 x 4608 token rows
     # (name, rows, N, K, epilogue, FLOP share of a P1024 forward in units of D^2 per token)
     shapes = [("double qkv (img)", 32768, 3 * D, D, ops.EPI_BIAS, 19 * 3), ("double ff1 (img)", 32768, 4 * D, D, ops.EPI_BIAS_GELU, 19 * 4),
