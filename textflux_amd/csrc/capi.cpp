@@ -233,6 +233,13 @@ int tfx_query_arch(char* buf, int buflen) {
   return 0;
 }
 
+#ifdef TFX_BENCH
+// bench library only (tools/gemm_phase_timers.py, gemm_shapes_power.py): the next tfx_gemm_bf16 calls carry the DiT's fused q / k
+// RMSNorm + RoPE epilogue on the [k | v | q | ...] column layout, as tfx_dit_forward attaches it internally
+static struct { const void* wq; const void* wk; const float* cs; int D; } g_bench_qkn = {nullptr, nullptr, nullptr, 0};
+extern "C" void tfx_bench_gemm_qkn(const void* wq, const void* wk, const float* cs, int D) { g_bench_qkn = {wq, wk, cs, D}; }
+#endif
+
 int tfx_gemm_bf16(const tfx_gemm_args* g, int variant, tfx_stream stream) {
   if (!g) return fail("tfx_gemm_bf16: null args");
   GemmArgs a;
@@ -245,6 +252,14 @@ int tfx_gemm_bf16(const tfx_gemm_args* g, int variant, tfx_stream stream) {
   a.res = g->res; a.ldr = g->ldr; a.r_bstride = g->r_bstride;
   a.workspace = g->workspace; a.workspace_bytes = g->workspace_bytes;
   if (!a.A || !a.W || !a.C) return fail("tfx_gemm_bf16: null matrix pointer");
+#ifdef TFX_BENCH
+  if (g_bench_qkn.cs) {
+    const int D = g_bench_qkn.D;
+    a.qkn_wq = g_bench_qkn.wq; a.qkn_wk = g_bench_qkn.wk; a.qkn_rope_cs = g_bench_qkn.cs; a.qkn_pos0 = 0;
+    a.qkn_k0 = 0; a.qkn_k1 = D; a.qkn_q0 = 2 * D; a.qkn_q1 = 3 * D; a.qkn_eps = 1e-6f;
+    if (!gemm_qkn_ok(a)) return fail("tfx_bench_gemm_qkn: shape cannot carry the fused epilogue");
+  }
+#endif
   return variant < 0 ? gemm_bf16(a, S(stream)) : gemm_bf16_variant(a, variant, S(stream));
 }
 

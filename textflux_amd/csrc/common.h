@@ -25,8 +25,17 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+// round two values to bf16 precision: one conversion + two unpacks (round_bf twice: two conversions + two shifts)
+__device__ __forceinline__ void round_bf2(float& a, float& b);
+// two values -> one v_cvt_pk_bf16_f32 (the scalar form above costs a conversion per value plus an OR to combine them)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
+}
+__device__ __forceinline__ void round_bf2(float& a, float& b) {
+  const uint32_t p = pack_bf2(a, b);
+  a = __uint_as_float(p << 16);
+  b = __uint_as_float(p & 0xffff0000u);
 }
 __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
 #pragma unroll

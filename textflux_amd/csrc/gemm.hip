@@ -282,7 +282,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
   // every operand request of this tile's K loop (incl. the next tile's first K-tiles) is older than the stores below;
   // loads and stores retire out of order with respect to each other, so the counted waits of the next K loop are only
   // meaningful once these have landed
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (the builtin, not inline asm: hipcc's own wait-count pass must see that the bias / gate / residual registers have landed, or
+  // it re-waits for them -- vmcnt(0) -- at their next redefinition, which is the first fragment read of the K loop)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+  __builtin_amdgcn_sched_barrier(0);
   TFX_STAMP(1);
   float rinv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   u32x4 nw8 = u32x4{0u, 0u, 0u, 0u};     // norm weights of the 8 columns this lane stores (norm tiles)
@@ -300,10 +303,13 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
         const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
                              __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = round_bf(acc[mi][nj][e] + bs[e]);
-          acc[mi][nj][e] = x;
-          ss[mi] += x * x;
+        for (int e = 0; e < 4; e += 2) {
+          float x0 = acc[mi][nj][e] + bs[e], x1 = acc[mi][nj][e + 1] + bs[e + 1];
+          round_bf2(x0, x1);
+          acc[mi][nj][e] = x0;
+          acc[mi][nj][e + 1] = x1;
+          ss[mi] += x0 * x0;
+          ss[mi] += x1 * x1;
         }
       }
       ss[mi] += __shfl_xor(ss[mi], 16, 64);
@@ -326,20 +332,22 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
   auto store_blocks = [&](auto NORM_T, auto GELU_T) __attribute__((always_inline)) {
     constexpr bool NORM = decltype(NORM_T)::value;
     constexpr bool GELU = decltype(GELU_T)::value;
+    // (cos, sin) pairs of the four rows this lane stores from a row block.  The requests of block k + 1 are issued BEFORE the
+    // stores of block k: vmcnt retires in issue order, so a table load behind a store would only return after that store's
+    // acknowledgement from L2 (~1 us), four times per tile.
+    f32x4 csr[4][2];
+    auto load_cs = [&](int blk) {
+#pragma unroll
+      for (int itr = 0; itr < 4; ++itr) {
+        const int mrow = min(m0 + g * 128 + blk * 32 + itr * 8 + crow, p.M - 1);
+        const float* cs = p.rope_cs + (int64_t)(p.rope_pos0 + mrow) * 128 + (wc & 1) * 64 + cchunk * 8;
+        csr[itr][0] = *reinterpret_cast<const f32x4*>(cs);
+        csr[itr][1] = *reinterpret_cast<const f32x4*>(cs + 4);
+      }
+    };
+    if (NORM) load_cs(0);
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
-      // (cos, sin) pairs of the four rows this lane stores from this row block, requested before the block is converted
-      // and staged (the latency hides behind that work)
-      f32x4 csr[4][2];
-      if (NORM) {
-#pragma unroll
-        for (int itr = 0; itr < 4; ++itr) {
-          const int mrow = min(m0 + g * 128 + blk * 32 + itr * 8 + crow, p.M - 1);
-          const float* cs = p.rope_cs + (int64_t)(p.rope_pos0 + mrow) * 128 + (wc & 1) * 64 + cchunk * 8;
-          csr[itr][0] = *reinterpret_cast<const f32x4*>(cs);
-          csr[itr][1] = *reinterpret_cast<const f32x4*>(cs + 4);
-        }
-      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int mi = blk * 2 + h;
@@ -365,8 +373,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
             const u32x2 gr = gtr[nj];
             const float gt[4] = {__uint_as_float(gr[0] << 16), __uint_as_float(gr[0] & 0xffff0000u),
                                  __uint_as_float(gr[1] << 16), __uint_as_float(gr[1] & 0xffff0000u)};
+            round_bf2(v[0], v[1]);
+            round_bf2(v[2], v[3]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gt[e] * round_bf(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gt[e] * v[e];
           }
           u32x2 o;
           o[0] = pack_bf2(v[0], v[1]);
@@ -378,6 +388,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
       }
       // wave-private region + in-order LDS pipe: no barrier between the writes above and the reads below
       if (QKN) __builtin_amdgcn_sched_barrier(0);   // keeps the table loads of later row blocks from being hoisted over live accumulators
+      u32x4 vals[4];
 #pragma unroll
       for (int itr = 0; itr < 4; ++itr) {
         const int row = itr * 8 + crow;
@@ -391,7 +402,15 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
           unpack8(val, x);
           unpack8(nw8, wv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) y[e] = round_bf(round_bf(x[e] * rr_row) * wv[e]);
+          for (int e = 0; e < 8; e += 2) {
+            float a0 = x[e] * rr_row, a1 = x[e + 1] * rr_row;
+            round_bf2(a0, a1);
+            a0 *= wv[e];
+            a1 *= wv[e + 1];
+            round_bf2(a0, a1);
+            y[e] = a0;
+            y[e + 1] = a1;
+          }
           o8[0] = y[0] * c0[0] + (-y[1]) * c0[1];  o8[1] = y[1] * c0[0] + y[0] * c0[1];
           o8[2] = y[2] * c0[2] + (-y[3]) * c0[3];  o8[3] = y[3] * c0[2] + y[2] * c0[3];
           o8[4] = y[4] * c1[0] + (-y[5]) * c1[1];  o8[5] = y[5] * c1[0] + y[4] * c1[1];
@@ -406,12 +425,19 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
           for (int e = 0; e < 8; ++e) fv[e] += fr[e];
           val = pack8(fv);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(val, rsrcC, (int)((uint32_t)(blk * 32 + row) * (uint32_t)(p.ldc * 2) + col_off), 0, 0);
+        vals[itr] = val;
       }
-      if (HAS_RES && blk + RES_DEPTH < 4) {
-        load_res(blk + RES_DEPTH, rr[blk % RES_DEPTH]);   // in flight while the next block is converted and staged
+      // requests first, stores second (see load_cs)
+      if ((NORM && blk + 1 < 4) || (HAS_RES && blk + RES_DEPTH < 4)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (NORM && blk + 1 < 4) load_cs(blk + 1);
+        if (HAS_RES && blk + RES_DEPTH < 4) load_res(blk + RES_DEPTH, rr[blk % RES_DEPTH]);   // in flight while the next blocks are converted and staged
         __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int itr = 0; itr < 4; ++itr)
+        __builtin_amdgcn_raw_buffer_store_b128(vals[itr], rsrcC,
+                                               (int)((uint32_t)(blk * 32 + itr * 8 + crow) * (uint32_t)(p.ldc * 2) + col_off), 0, 0);
       if (QKN) __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -781,35 +807,41 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
       if (q == 0 || q == 3) ldst[q][j] = LDS_X + g * 32768 + ((q == 3 ? 64 : 0) + pc * 8) * 128;
       else ldst[q][j] = LDS_W + (g * 128 + (pc >> 2) * 64 + (q == 2 ? 32 : 0) + (pc & 3) * 8) * 128;
     }
-  // per-lane byte offsets from the tile origin (edge tiles: rows beyond M / N re-read the last valid row)
-  auto offsets = [&](const Tile& t, int (&go)[4][2]) {
+  // A request's byte offset = per-lane part + per-piece scalar part + tile origin + K-tile.  The lane part -- row (lane >> 3) of the
+  // piece, swizzled chunk -- does not depend on the tile and, because every piece starts on a multiple of 8 rows whose (row / 8)
+  // parity is j, only on j:  (row >> 1) & 7 = 4 j + (lr >> 1).  Four VGPRs for the life of the block; the piece's first row
+  // travels in the scalar offset.  Edge tiles rely on the descriptors' range check (num_records = the operand's extent: rows beyond
+  // M of the last batch / beyond N read as zeros into LDS and are never stored; rows beyond M of an inner batch read the next batch).
+  int vx[2], vw[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+  for (int j = 0; j < 2; ++j) {
+    const int clog = cphys ^ ((j << 2) | (lr >> 1));
+    vx[j] = lr * (int)p.lda * ESZ + clog * 16;
+    vw[j] = lr * (int)p.ldw * ESZ + clog * 16;
+  }
+  uint32_t srow[4][2];   // scalar byte offset of the piece's first row
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int pc = wc * 2 + j;
-        const bool x_item = (q == 0 || q == 3);
-        const int row0 = x_item ? (q == 3 ? 64 : 0) + pc * 8 : g * 128 + (pc >> 2) * 64 + (q == 2 ? 32 : 0) + (pc & 3) * 8;
-        const int row = row0 + lr;
-        const int clog = cphys ^ ((row >> 1) & 7);
-        if (x_item) go[q][j] = min(g * 128 + row, p.M - 1 - t.m0) * (int)p.lda * ESZ + clog * 16;
-        else go[q][j] = min(row, p.N - 1 - t.n0) * (int)p.ldw * ESZ + clog * 16;
-      }
-  };
-  // num_records = 2^32 - 1: the whole 32-bit offset range persist_ok admits is in bounds (with 2^31 - 1 every byte of an
-  // operand beyond 2 GiB read as zero: samples 6, 7 of the [8, 8704, 7 D] projection buffer at 2048 x 1024, batch 8)
-  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)0xffffffffu, 0x00020000);
-  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)0xffffffffu, 0x00020000);
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pc = wc * 2 + j;
+      if (q == 0 || q == 3) srow[q][j] = (uint32_t)(g * 128 + (q == 3 ? 64 : 0) + pc * 8) * (uint32_t)(p.lda * ESZ);
+      else srow[q][j] = (uint32_t)(g * 128 + (pc >> 2) * 64 + (q == 2 ? 32 : 0) + (pc & 3) * 8) * (uint32_t)(p.ldw * ESZ);
+    }
+  // num_records: the operand's extent in bytes (< 2^32, persist_ok)
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.A, 0, (int)(uint32_t)((((int64_t)(p.batch - 1) * p.a_bs + (int64_t)(p.M - 1) * p.lda + p.K) * ESZ)), 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(uint32_t)((((int64_t)(p.N - 1) * p.ldw + p.K) * ESZ)), 0x00020000);
 
-  // request item q of K-tile kt of the tile with origins (xo, wo) and lane offsets go into buffer set `set`
-  auto stage = [&](int q, const int (&go)[4][2], uint32_t xo, uint32_t wo, int kt, int set) {
+  // request item q of K-tile kt of the tile with origins (xo, wo) into buffer set `set`
+  auto stage = [&](int q, uint32_t xo, uint32_t wo, int kt, int set) {
     const bool x_item = (q == 0 || q == 3);
     const uint32_t so = (x_item ? xo : wo) + (uint32_t)kt * 128u;
     const uint32_t setoff = set * (x_item ? 16384u : 32768u);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_item ? rsrcX : rsrcW, (lds_void*)(smem + ldst[q][j] + setoff), 16, go[q][j], so,
-                                               0, GLDS_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_item ? rsrcX : rsrcW, (lds_void*)(smem + ldst[q][j] + setoff), 16, x_item ? vx[j] : vw[j],
+                                               so + srow[q][j], 0, GLDS_AUX);
   };
 
   // fragment read addresses (see gemm8p_kernel): bf16 chunk 4 s + (l >> 4) = k-step s; e4m3 chunks 2 (l >> 4) + s = the two
@@ -825,13 +857,11 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   }
 
   Tile cur = coords(xstart + it);
-  int goc[4][2], gon[4][2];
-  offsets(cur, goc);
   // ---- prologue (first tile of the block only): K-tiles 0 and 1 complete
 #pragma unroll
-  for (int q = 0; q < 4; ++q) stage(q, goc, cur.xoff, cur.woff, 0, 0);
+  for (int q = 0; q < 4; ++q) stage(q, cur.xoff, cur.woff, 0, 0);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) stage(q, goc, cur.xoff, cur.woff, 1, 1);
+  for (int q = 0; q < 4; ++q) stage(q, cur.xoff, cur.woff, 1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TFX_BARRIER();
   if (g == 1) TFX_BARRIER();  // stagger: G1 runs one barrier behind G0, for the whole life of the block
@@ -848,8 +878,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   } while (0)
-  // one K-tile out of buffer set SET; (GO, XO, WO, KT) = the operands requested meanwhile (two K-tiles ahead)
-#define PP_TILE_W(SET, GO, XO, WO, KT, W0, W1, W3, Z)                                                        \
+  // one K-tile out of buffer set SET; (XO, WO, KT) = origins / K-tile of the operands requested meanwhile (two K-tiles ahead)
+#define PP_TILE_W(SET, XO, WO, KT, W0, W1, W3, Z)                                                            \
   do {                                                                                                       \
     constexpr uint32_t xs = (SET) * 16384u, ws = (SET) * 32768u;                                             \
     _Pragma("unroll") for (int s = 0; s < 2; ++s) {               /* L0: X_lo, W_lo */                       \
@@ -862,25 +892,25 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     TFX_BARRIER();                                                                                           \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                 /* L1: W_hi */                             \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) whi[j][s] = LDS_FRAG(fw[s] + ws + 4096 + j * 2048);      \
-    stage(0, GO, XO, WO, KT, SET);                                                                           \
-    if (PLACE == 1) { stage(1, GO, XO, WO, KT, SET); if (W1) PP_VMCNT(12); } else { if (W1) PP_VMCNT(10); }  \
+    stage(0, XO, WO, KT, SET);                                                                               \
+    if (PLACE == 1) { stage(1, XO, WO, KT, SET);     if (W1) PP_VMCNT(12); } else { if (W1) PP_VMCNT(10); }  \
     TFX_BARRIER();                                                                                           \
     PP_MFMA16(whi, 0, 2, Z);                                                                                 \
     TFX_BARRIER();                                                                                           \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                 /* L2: X_hi */                             \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) xf[i][s] = LDS_FRAG(fx[s] + xs + 8192 + i * 2048);       \
-    if (PLACE != 1) stage(1, GO, XO, WO, KT, SET);                                                           \
+    if (PLACE != 1) stage(1, XO, WO, KT, SET);                                                               \
     TFX_BARRIER();                                                                                           \
     PP_MFMA16(whi, 4, 2, Z);                                                                                 \
     TFX_BARRIER();                                                                                           \
-    stage(2, GO, XO, WO, KT, SET);                                /* L3: no reads */                         \
-    stage(3, GO, XO, WO, KT, SET);                                                                           \
+    stage(2, XO, WO, KT, SET);                                    /* L3: no reads */                         \
+    stage(3, XO, WO, KT, SET);                                                                               \
     if (W3) PP_VMCNT(12);                                                                                    \
     TFX_BARRIER();                                                                                           \
     PP_MFMA16(wlo, 4, 0, Z);                                                                                 \
     TFX_BARRIER();                                                                                           \
   } while (0)
-#define PP_TILE(SET, GO, XO, WO, KT) PP_TILE_W(SET, GO, XO, WO, KT, 1, 1, 1, false)
+#define PP_TILE(SET, XO, WO, KT) PP_TILE_W(SET, XO, WO, KT, 1, 1, 1, false)
 
   char* stg = smem + PP_STG + wave * PP_STG_WAVE;
 #ifdef TFX_BENCH
@@ -895,7 +925,6 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     // the last tile of the block re-requests its own first K-tiles: harmless (nobody reads them) and keeps the
     // load counts of the waits uniform
     const Tile nxt = coords(xstart + (has_next ? nit : it));
-    offsets(nxt, gon);
     const uint32_t cx = cur.xoff, cw = cur.woff, nx = nxt.xoff, nw = nxt.woff;
     // Everything K-tiles 0 and 1 read was waited for before this tile started (prologue / the epilogue's vmcnt(0)), and
     // the first requests of THIS tile have their deadline at L3 of K-tile 1: the earlier counted waits could only stall
@@ -904,8 +933,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     int u0 = 0;
     // (not in the fp8 gated-residual instantiation: there the two extra loop bodies tip hipcc's allocation into spills)
     if (nt >= 4 && !(FP8 && EPI == EPI_BIAS_GATE_RES)) {
-      PP_TILE_W(0, goc, cx, cw, 2, 0, 0, 0, true);
-      PP_TILE_W(1, goc, cx, cw, 3, 0, 0, 1, false);
+      PP_TILE_W(0, cx, cw, 2, 0, 0, 0, true);
+      PP_TILE_W(1, cx, cw, 3, 0, 0, 1, false);
       u0 = 2;
     } else {
 #pragma unroll
@@ -916,11 +945,11 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
           for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
     }
     for (int u = u0; u < nt - 2; u += 2) {
-      PP_TILE(0, goc, cx, cw, u + 2);
-      PP_TILE(1, goc, cx, cw, u + 3);
+      PP_TILE(0, cx, cw, u + 2);
+      PP_TILE(1, cx, cw, u + 3);
     }
-    PP_TILE(0, gon, nx, nw, 0);  // K-tiles nt-2, nt-1: their requests are the next tile's K-tiles 0 and 1
-    PP_TILE(1, gon, nx, nw, 1);
+    PP_TILE(0, nx, nw, 0);  // K-tiles nt-2, nt-1: their requests are the next tile's K-tiles 0 and 1
+    PP_TILE(1, nx, nw, 1);
     TFX_STAMP(0);
 
     // ---- epilogue (tile_epilogue), one 32-row block of the accumulators at a time
@@ -959,10 +988,6 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     if (!has_next) break;
     cur = nxt;
     it = nit;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) goc[q][j] = gon[q][j];
   }
   if (g == 0) TFX_BARRIER();  // pairs with G1's extra barrier of the prologue
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the closing requests must not land in a successor's LDS

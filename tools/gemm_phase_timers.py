@@ -37,14 +37,24 @@ def main():
     M = 32768
     cases = [("K3072 N9216 bias", M, 3 * D, D, ops.EPI_BIAS), ("K3072 N12288 bias", M, 4 * D, D, ops.EPI_BIAS),
              ("K3072 N12288 gelu", M, 4 * D, D, ops.EPI_BIAS_GELU), ("K3072 N3072 gate_res", M, D, D, ops.EPI_BIAS_GATE_RES),
-             ("K12288 N3072 gate_res", M, D, 4 * D, ops.EPI_BIAS_GATE_RES), ("K12288 N3072 bias", M, D, 4 * D, ops.EPI_BIAS)]
+             ("K12288 N3072 gate_res", M, D, 4 * D, ops.EPI_BIAS_GATE_RES), ("K12288 N3072 bias", M, D, 4 * D, ops.EPI_BIAS),
+             ("K3072 N9216 qkn [k|v|q]", M, 3 * D, D, "qkn"), ("K3072 N21504 qkn+gelu [k|v|q|mlp]", 36864, 7 * D, D, "qkn_gelu")]
+    qfn = lib.tfx_bench_gemm_qkn
+    qfn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    qfn.restype = None
+    nw = torch.ones(128, dtype=BF, device="cuda")
+    cs = torch.randn(36864, 64, 2, device="cuda")
     rows = []
     for name, m, N, K, epi in cases:
         x = torch.randn(m, K, device="cuda").to(BF)
         w = (torch.randn(N, K, device="cuda") * 0.02).to(BF)
         b = torch.randn(N, device="cuda").to(BF)
         out = torch.empty(m, N, dtype=BF, device="cuda")
-        kw = dict(epilogue=epi)
+        qkn = isinstance(epi, str)
+        kw = dict(epilogue=(ops.EPI_BIAS_GELU if qkn else epi))
+        if qkn:
+            kw["gelu_from_col"] = 3 * D if epi == "qkn_gelu" else N
+            qfn(nw.data_ptr(), nw.data_ptr(), cs.data_ptr(), D)
         if epi == ops.EPI_BIAS_GATE_RES:
             kw.update(gate=torch.randn(1, N, device="cuda").to(BF), res=torch.randn(m, N, device="cuda").to(BF))
         fn(None)
@@ -60,6 +70,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         fn(None)
+        qfn(None, None, None, 0)
         t = tim.tolist()
         ms = e0.elapsed_time(e1) / a.reps
         r = dict(case=name, ms=round(ms, 4), tflops=round(2.0 * m * N * K / ms / 1e9, 1))
