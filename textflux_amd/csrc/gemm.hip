@@ -810,7 +810,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   // A request's byte offset = per-lane part + per-piece scalar part + tile origin + K-tile.  The lane part -- row (lane >> 3) of the
   // piece, swizzled chunk -- does not depend on the tile and, because every piece starts on a multiple of 8 rows whose (row / 8)
   // parity is j, only on j:  (row >> 1) & 7 = 4 j + (lr >> 1).  Four VGPRs for the life of the block; the piece's first row
-  // travels in the scalar offset.  Edge tiles rely on the descriptors' range check (num_records = the operand's extent: rows beyond
+  // is a scalar added per request.  Edge tiles rely on the descriptors' range check (num_records = the operand's extent: rows beyond
   // M of the last batch / beyond N read as zeros into LDS and are never stored; rows beyond M of an inner batch read the next batch).
   int vx[2], vw[2];
 #pragma unroll
@@ -840,8 +840,10 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     const uint32_t setoff = set * (x_item ? 16384u : 32768u);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_item ? rsrcX : rsrcW, (lds_void*)(smem + ldst[q][j] + setoff), 16, x_item ? vx[j] : vw[j],
-                                               so + srow[q][j], 0, GLDS_AUX);
+      // (the piece's row offset is added to the LANE offset, one v_add per request: carried in the scalar offset instead, the
+      // K = 12288 shapes -- a 24 KiB row pitch -- lose 10 %, 1.33 against 1.48 PFLOP/s; every other pitch is indifferent)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_item ? rsrcX : rsrcW, (lds_void*)(smem + ldst[q][j] + setoff), 16,
+                                               (x_item ? vx[j] : vw[j]) + (int)srow[q][j], so, 0, GLDS_AUX);
   };
 
   // fragment read addresses (see gemm8p_kernel): bf16 chunk 4 s + (l >> 4) = k-step s; e4m3 chunks 2 (l >> 4) + s = the two
