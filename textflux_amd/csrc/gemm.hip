@@ -194,7 +194,7 @@ __device__ __forceinline__ void mfma_section(f32x4 (&acc)[8][4], const bf16x8 (&
 
 // bench-only phase timers of the persistent kernel (tools/gemm_phase_timers.py): s_memtime stamps in SGPRs
 #ifdef TFX_BENCH
-#define TFX_STAMP(i) (tfx_stamp[i] = __builtin_amdgcn_s_memtime())
+#define TFX_STAMP(i) do { if (tfx_stamp) tfx_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TFX_STAMP(i) ((void)0)
 #endif

@@ -26,6 +26,10 @@ make -C textflux_amd/csrc bench -j8 > $out/make_bench.log 2>&1
 TFX_LIB=$PWD/textflux_amd/libtextflux_hip_bench.so python tools/power_profile.py --out $out/r03_power.json > $out/power.log 2>&1
 python tools/mfma_power.py --secs 2.5 --out $out/r03_mfma_power.json > $out/mfma_power.log 2>&1
 python tools/gemm_shapes_power.py --tag mfma16x16x32 --hipblaslt --out $out/r03_gemm_shapes.jsonl > $out/gemm_shapes.log 2>&1
+# 5b. where a tile's time goes (s_memtime phase timers of the bench library), the q/k-norm epilogue shapes, VALU issue rates
+TFX_LIB=$PWD/textflux_amd/libtextflux_hip_bench.so python tools/gemm_phase_timers.py --out $out/r03_gemm_phase_timers.json > $out/phase.log 2>&1
+TFX_LIB=$PWD/textflux_amd/libtextflux_hip_bench.so python tools/qkn_ab.py > $out/r03_gemm_qkn_shapes.txt 2>&1
+tools/ubench/valu_rate > $out/r03_valu_rate.jsonl 2>&1
 # 6. cold start of the DiT (23.8 GB synthetic sharded checkpoint)
 python tools/loader_bench.py --out $out/r03_loader.json > $out/loader.log 2>&1
 # 7. BASELINE config 1 on the host cores (oracle, fp32, full 57-block model)
