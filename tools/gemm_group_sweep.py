@@ -33,4 +33,4 @@ for name, M, N, K, epi in SHAPES:
         dt = (time.time() - t0) / n
         row[gm] = round(2.0 * M * N * K / dt / 1e12, 1)
     print(json.dumps({"shape": name, "M": M, "N": N, "K": K, "tflops_by_group_m": row}), flush=True)
-ops.set_option("gemm_group_m", 4)
+ops.set_option("gemm_group_m", 0)   # back to the by-shape default
