@@ -22,7 +22,10 @@
 // waits on the operand requests are counted (s_waitcnt vmcnt(n)), never drained, inside the main loop.
 // (tools/ubench/mfma_power variants 13 / 16 replay this main loop's instruction mix on registers only, next to the
 // one-wave-per-SIMD 128 x 128-per-wave alternative VERDICT round 2 asked for: 1.81 vs 1.80 PFLOP/s -- the structures tie, so the
-// ping-pong stayed; hipBLASLt's 4-wave assembly kernel of the same tile measures 3-5 % ahead on the same shapes.)
+// ping-pong stayed.  hipBLASLt's 4-wave assembly kernel of the same tile was 3-5 % ahead on bias-only shapes until the epilogue /
+// request-path work of round 3's second half -- branch-free buffer-descriptor accesses, tile-independent request offsets (no
+// spills), the epilogue's drain as a builtin -- after which the 36864 x 9216 x 3072 bias shape measures 1491 vs 1467 TFLOP/s,
+// 1.93 vs 1.97 J per launch, profiles/r03_power.json; DESIGN.md "Where a tile's time goes".)
 //
 // One-tile kernel schedule (slots = half phases; tile t, phase q in 0..3; group g runs loads(p) at slot 2p-1+g and
 // MFMA(p) at slot 2p+g, p = 4t+q).  Each wave keeps X fragments for 64 rows and both 32-column W fragments in registers:
