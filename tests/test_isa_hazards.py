@@ -30,7 +30,7 @@ def isa(src, tmp_path, *flags):
 def test_default_attention_kernel_has_no_mfma_result_hazard(tmp_path):
     import check_mfma_hazard as ck
     asm = isa("attention_w4.hip", tmp_path)
-    (name, n, n_mfma, rep), = ck.check_all(asm)
+    (name, n, n_mfma, rep), = [k for k in ck.check_all(asm) if "attn_w4_kernel" in k[0]]      # (the file also holds the tail-split merge kernel)
     assert "attn_w4_kernel" in name and n_mfma > 250 and n > 3000      # the kernel was really parsed
     assert asm.count("v_readfirstlane_b32") >= 16                       # the compiler-visible touches are in the stream
     assert rep == [], rep[:5]
@@ -51,11 +51,11 @@ def test_checker_catches_a_shortened_distance(tmp_path):
     """The self-test variant reads a score from inline asm right behind its chain's last MFMA, with the touch removed."""
     import check_mfma_hazard as ck
     asm = isa("attention_w4.hip", tmp_path, "-DW4_NO_TOUCH", "-DW4_HAZARD_SELFTEST")
-    (_, _, _, rep), = ck.check_all(asm)
+    (_, _, _, rep), = [k for k in ck.check_all(asm) if "attn_w4_kernel" in k[0]]
     assert len(rep) >= 4 and all("mfma write" in r for r in rep), rep[:3]
     # ... and the touch alone is what makes the compiler pad: same shortened read, touch in place right behind the MFMA
     padded = isa("attention_w4.hip", tmp_path, "-DW4_HAZARD_SELFTEST")
-    (_, _, _, rep2), = ck.check_all(padded)
+    (_, _, _, rep2), = [k for k in ck.check_all(padded) if "attn_w4_kernel" in k[0]]
     assert len(rep2) == len(rep)          # the unprotected asm read is still flagged (the touch sits in front of the REAL reads only)
 
 

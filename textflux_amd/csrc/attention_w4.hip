@@ -58,6 +58,7 @@ constexpr int W4_KROW = 272;                   // K row pitch
 constexpr int W4_KT = W4_KV * W4_KROW;         // K tile bytes
 constexpr int W4_NBUF = 3;
 constexpr int W4_KBASE = W4_NBUF * W4_VT;      // V tiles first, then K tiles
+constexpr int W4_PROW = 132;                   // floats per row of a tail-split partial: 128 d + row sum + reference maximum + pad
 constexpr float W4_THR = 4.0f;                 // lazy-reference threshold (log2 units), as attn_mx_kernel
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -136,24 +137,62 @@ __device__ __forceinline__ uint32_t w4_cvt_pk(float lo, float hi) {
 __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
                                                          const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq, int64_t ldk,
                                                          int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
-                                                         int64_t o_bs, int H, int N, int nqb, float scale_log2e) {
+                                                         int64_t o_bs, int H, int N, int nqb, float scale_log2e, int nfull,
+                                                         int nparts, int nsplit, int xsplit, float* part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   int bid = blockIdx.x;
-  {
+  // Tail split (nsplit > 1, joint_attention_w4): the LAST xsplit (head, q-tile) pairs of every batch sample are each cut into
+  // nsplit KEY ranges and dispatched after the nfull ordinary workgroups -- nfull a whole number of rounds of the chip, so the last
+  // round is made of short workgroups instead of being partly empty; such a workgroup leaves its un-normalised O, row sums and
+  // reference maxima in `part`, attn_w4_merge_kernel finishes.  Which tiles are split depends on (head, q-tile) only, never on
+  // the batch index: identical samples of a batch still produce identical bits; and the parts of one (batch, head) are neighbours
+  // in the dispatch order, so its K / V stay L2-resident among them.  (Measured alternatives: the last q-tile of EVERY head --
+  // re-streams all K / V from HBM at the end, no gain; whole heads -- nfull is no longer a multiple of the CU count, some CUs run
+  // three halves in a row, 1.4 % slower than no split.)
+  int kpart = -1, ptile = 0, qblk, h, b;
+  if (nsplit > 1) {
+    const int fpad = (nfull + 7) & ~7, pf = H * nqb - xsplit;      // pf: unsplit pairs per sample
+    int pair;
+    if (bid < fpad) {
+      const int q = nfull >> 3, r = nfull & 7, xcd = bid & 7, k = bid >> 3;
+      if (k >= q + (xcd < r ? 1 : 0)) return;
+      const int fid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+      b = fid / pf;
+      pair = fid % pf;
+    } else {
+      const int pi = bid - fpad;
+      if (pi >= nparts) return;
+      kpart = pi % nsplit;
+      ptile = pi / nsplit;
+      b = ptile / xsplit;
+      pair = pf + ptile % xsplit;
+    }
+    h = pair / nqb;
+    qblk = pair % nqb;
+  } else {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    qblk = bid % nqb;
+    bid /= nqb;
+    h = bid % H;
+    b = bid / H;
   }
-  const int qblk = bid % nqb;
-  bid /= nqb;
-  const int h = bid % H;
-  const int b = bid / H;
   const bf16_t* Qb = Q + b * q_bs + h * W4_HD;
-  const bf16_t* Kb = Kp + b * k_bs + h * W4_HD;
+  const bf16_t* Kb = Kp + b * k_bs + h * W4_HD;   // (advanced to the first key of a split range below)
   const bf16_t* Vb = Vp + b * v_bs + h * W4_HD;
   bf16_t* Ob = O + b * o_bs + h * W4_HD;
+  // keys of this workgroup: all N, or (tail split) the 64-key tiles [kpart, kpart + 1) * nkv / nsplit
+  int Nk = N;
+  if (kpart >= 0) {
+    const int nkv_all = (N + W4_KV - 1) / W4_KV;
+    const int t0 = kpart * nkv_all / nsplit, t1 = (kpart + 1) * nkv_all / nsplit;
+    Nk = min(N, t1 * W4_KV) - t0 * W4_KV;
+    Kb += (int64_t)t0 * W4_KV * ldk;
+    Vb += (int64_t)t0 * W4_KV * ldv;
+  }
 
   // ---- Q fragments of the wave's two q-blocks, pre-scaled into the exp2 domain (one extra bf16 rounding of q).  All sixteen
   // requests go out before the first conversion: with one wave per SIMD a request-wait-convert loop would pay sixteen memory
@@ -179,15 +218,15 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       }
   };
 
-  const int nkv = (N + W4_KV - 1) / W4_KV;
+  const int nkv = (Nk + W4_KV - 1) / W4_KV;
   // ---- staging: thread t moves the 16-byte chunks (row t / 16 + 16 i, chunk t % 16), i = 0..3, of a tile's K and V
   u32x4 kreg[4], vreg[4];
   // buffer descriptors sized to this head's N valid rows: a request past them (the rows of a ragged last tile, whole tiles
   // requested past the end of the sequence) returns zeros and moves nothing -- the scores of such keys are masked anyway,
   // and their zero V rows meet zero weights.  (The range check covers VGPR + SGPR offset: tools/ubench/buffer_range.hip.)
   const int ldk2 = (int)ldk * 2, ldv2 = (int)ldv * 2;
-  const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)((uint32_t)(N - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
-  const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((uint32_t)(N - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
+  const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)((uint32_t)(Nk - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
+  const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((uint32_t)(Nk - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
   // piece i (rows t / 16 + 16 i) of tile j: global -> registers.  Rows are clamped to the last valid key (a no-op on full
   // tiles), tiles to the last tile (the pipeline requests up to two tiles past the end; nobody reads those buffers)
   // tile j: global -> registers, piece i = rows t / 16 + 16 i.  Full tiles: one per-lane offset (rebuilt per burst: as a loop
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       asm volatile("" : "+v"(kbase));     // keep the index arithmetic inside the (last-tile-only) branch
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (kbase + (r & 3) + 8 * (r >> 2) >= N) cur[r] = -INFINITY;
+        if (kbase + (r & 3) + 8 * (r >> 2) >= Nk) cur[r] = -INFINITY;
     }
     // MFMA i of the S chain (0: the reference offset, 1..8: the head-dim steps) and of the pending P.V (ks = i / 5, block i % 5)
     auto S = [&](auto Ic) __attribute__((always_inline)) {
@@ -464,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   auto tile = [&](int j, auto Bc, auto FIRSTc) __attribute__((always_inline)) {
     constexpr int B = decltype(Bc)::value, NB = (B + 1) % 3, WB = (B + 2) % 3;
     constexpr int FIRST = decltype(FIRSTc)::value;
-    const bool rag = (j == nkv - 1) && (N & (W4_KV - 1));
+    const bool rag = (j == nkv - 1) && (Nk & (W4_KV - 1));
     // (kb0, q0): S(kb0, q1);  pending (tile j-1: kb1, q1);  reload kf <- K(j) kb1, vf <- V(j) kb0
     step(IC<0>{}, IC<!FIRST>{}, IC<FIRST>{}, IC<B * W4_KT + 32 * W4_KROW>{}, IC<B * W4_VT>{}, IC<0>{}, 0, rag, j * W4_KV);
     // (kb0, q1): S(kb1, q0);  pending (kb0, q0);  + staging: tile j + 2 (requested one tile ago) goes into the buffer tile j - 1
@@ -496,6 +535,25 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   }
   W4_DRAIN_MFMA();                               // the last MFMA results before the VALU reads them
 
+  // ---- tail split: un-normalised O (fp32), row sum and reference maximum of this key range -> part [tile][range][row][132]
+  if (kpart >= 0) {
+    float* pp = part + ((int64_t)ptile * nsplit + kpart) * (256 * W4_PROW);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float* pr = pp + (wave * 64 + qb * 32 + l31) * W4_PROW;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+          *reinterpret_cast<f32x4*>(pr + db * 32 + qd * 8 + hi * 4) =
+              f32x4{o[qb][db][qd * 4 + 0], o[qb][db][qd * 4 + 1], o[qb][db][qd * 4 + 2], o[qb][db][qd * 4 + 3]};
+      if (hi == 0) {
+        pr[128] = ol[qb][0];
+        pr[129] = m_ref[qb];
+      }
+    }
+    return;
+  }
   // ---- finish: every row of the ones-block holds the full row sum.  The normalised bf16 rows go through a wave-private LDS
   // tile (the K / V ring is free: every wave's last fragment read lies before the last barrier) and leave as whole 256-byte
   // rows, 16 lanes x 16 bytes each (row-per-lane 8-byte stores touch 32 lines per instruction and queue up at the end of
@@ -527,6 +585,54 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   }
 }
 
+// Finishes the q-tiles of a tail split: O = sum_r o_r 2^(m_r - m) / sum_r l_r 2^(m_r - m), m = max_r m_r (exp2 domain, the
+// kernel's own bookkeeping).  One thread per (row, 4 head-dim columns).
+__global__ __launch_bounds__(256) void attn_w4_merge_kernel(const float* part, bf16_t* O, int64_t ldo, int64_t o_bs, int H, int N,
+                                                            int nqb, int xsplit, int nsplit) {
+  const int rg = blockIdx.x * 8 + (threadIdx.x >> 5), c = (threadIdx.x & 31) * 4;
+  const int ptile = rg >> 8, r = rg & 255;
+  const int pair = H * nqb - xsplit + ptile % xsplit, b = ptile / xsplit, h = pair / nqb, qblk = pair % nqb;
+  const int row = qblk * 256 + r;
+  if (row >= N) return;
+  const float* pr = part + ((int64_t)ptile * nsplit * 256 + r) * W4_PROW;
+  float m = -INFINITY;
+  for (int k = 0; k < nsplit; ++k) m = fmaxf(m, pr[(int64_t)k * 256 * W4_PROW + 129]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int k = 0; k < nsplit; ++k) {
+    const float* pk = pr + (int64_t)k * 256 * W4_PROW;
+    const float w = __builtin_amdgcn_exp2f(pk[129] - m);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(pk + c);
+    acc += v * w;
+    l += pk[128] * w;
+  }
+  const float inv = 1.0f / l;
+  u32x2 o2;
+  o2[0] = pack_bf2(acc[0] * inv, acc[1] * inv);
+  o2[1] = pack_bf2(acc[2] * inv, acc[3] * inv);
+  *reinterpret_cast<u32x2*>(O + b * o_bs + (int64_t)row * ldo + h * W4_HD + c) = o2;
+}
+
+// scratch of the tail split: allocated once (never inside a stream capture, never freed: captured graphs keep the pointer)
+static float* g_w4_part = nullptr;
+static int g_w4_cus = 0;
+static constexpr int W4_PART_TILES = 1024;   // (q-tile, key range) slots: 2 rounds of a 512-CU chip, 138 MB
+static int g_w4_split = 1;                   // bench knob (tfx_set_option attention_tail_split): 0 never split
+void set_attention_tail_split(int v) { g_w4_split = v; }
+
+int attention_w4_prepare() {
+  if (g_w4_part) return 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&g_w4_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_w4_cus < 8) g_w4_cus = 256;
+  if (hipMalloc((void**)&g_w4_part, (size_t)W4_PART_TILES * 256 * W4_PROW * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    g_w4_part = nullptr;
+    return fail("attention: cannot allocate the tail-split scratch");
+  }
+  return 0;
+}
+
 int joint_attention_w4(const AttnArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -542,10 +648,35 @@ int joint_attention_w4(const AttnArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int nqb = (a.N + 255) / 256;
-  const unsigned grid = (unsigned)(a.B * a.H * nqb);
+  const int T = a.B * a.H * nqb;
+  // Tail split: T workgroups of equal length on C CUs take ceil(T / C) rounds, and when the last one is partly filled the chip
+  // idles for the rest of it.  Cut the tiles of that last round -- the last m (head, q-tile) pairs of every sample, B m = the
+  // tail rounded up to a multiple of B -- into two key ranges: the ordinary workgroups then fill whole rounds and the halves one
+  // short one.  P1024 batch 8: 3456 workgroups = 13.5 rounds -> 3328 ordinary (13 rounds) + 256 halves: 1.861 -> 1.851 ms (a half
+  // costs ~0.6 of a whole, and the rounds of a long kernel are not in step any more: the ideal 3.6 % shrinks to 0.5 %); batch 2:
+  // 864 = 3.375 rounds -> 768 + 192 halves, 0.508 -> 0.481 ms.  Not
+  // taken when a half would be shorter than 24 key tiles (its prologue, Q load and partial store cost more than the round
+  // gains), without a full round in front, or when the last round is more than half full (the halves would need two rounds).
+  int nfull = T, nsplit = 1, nparts = 0, xsplit = 0;
+  if (g_w4_split && !g_w4_part) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) (void)attention_w4_prepare();
+    (void)hipGetLastError();
+  }
+  if (g_w4_split && g_w4_part) {
+    const int C = g_w4_cus, tail = T % C, nkv = (a.N + W4_KV - 1) / W4_KV;
+    const int m = (tail + a.B - 1) / a.B;
+    if (tail && T >= C && m * a.B * 2 <= C + 8 && nkv >= 48 && m < a.H * nqb && m * a.B * 2 <= W4_PART_TILES) {
+      xsplit = m; nsplit = 2; nfull = T - m * a.B; nparts = m * a.B * 2;
+    }
+  }
+  const unsigned grid = nsplit > 1 ? (unsigned)(((nfull + 7) & ~7) + nparts) : (unsigned)T;
   attn_w4_kernel<<<grid, 256, ATT_LDS_W4, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
                                                  a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
-                                                 a.N, nqb, a.scale * 1.4426950408889634f);
+                                                 a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, g_w4_part);
+  if (nsplit > 1)
+    attn_w4_merge_kernel<<<(unsigned)(xsplit * a.B * 32), 256, 0, st>>>(g_w4_part, (bf16_t*)a.o, a.ldo, a.o_bstride, a.H, a.N, nqb,
+                                                                              xsplit, nsplit);
   return 0;
 }
 

@@ -498,6 +498,7 @@ int tfx_set_option(const char* name, int value) {
     return 0;
   }
   if (!std::strcmp(name, "gemm_group_m")) { set_gemm_group_m(value); return 0; }
+  if (!std::strcmp(name, "attention_tail_split")) { set_attention_tail_split(value); return 0; }
   if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
   if (!std::strcmp(name, "gemm_splitk")) { set_gemm_splitk(value); return 0; }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only
@@ -576,6 +577,7 @@ int tfx_dit_step_capture(const tfx_step_desc* s, tfx_stream stream, tfx_graph* o
   if (!out) return fail("tfx_dit_step_capture: null output handle");
   if (!stream) return fail("tfx_dit_step_capture: the NULL stream cannot be captured; pass a created stream");
   hipStream_t st = S(stream);
+  (void)attention_w4_prepare();   // the attention kernel's scratch cannot be allocated inside a capture
   hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return fail("tfx_dit_step_capture: hipStreamBeginCapture: %s", hipGetErrorString(e));
   const int rc = step_enqueue(*s, st);
