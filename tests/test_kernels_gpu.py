@@ -333,8 +333,8 @@ def test_attention_online_softmax_rescale_branch(ops):
 @pytest.mark.parametrize("B,N", [(1, 3100), (2, 4608)])
 def test_attention_tail_split_matches_unsplit_and_reference(ops, B, N):
     """When the last round of workgroups is partly filled, the default kernel cuts its q-tiles into key ranges and a merge kernel
-    finishes them (attention_w4.hip: 312 / 864 workgroups on 256 CUs here, two ranges of >= 24 key tiles, a ragged last tile at
-    N = 3100).  The split result must agree with the unsplit kernel to bf16 rounding, with the fp32 reference like every other
+    finishes them (attention_w4.hip, option attention_tail_split = 1, off by default: 312 / 864 workgroups on 256 CUs here, two
+    ranges of >= 24 key tiles, a ragged last tile at N = 3100).  The split result must agree with the unsplit kernel to bf16 rounding, with the fp32 reference like every other
     shape, be deterministic, and survive the in-place-over-q layout of the blocks."""
     H, D = 24, 24 * 128
     y = (rnd((B, N, 4 * D), 61) * 1.5).to(BF).cuda()
@@ -347,17 +347,18 @@ def test_attention_tail_split_matches_unsplit_and_reference(ops, B, N):
         ops.set_option("attention_tail_split", 1)
         split = ops.attention(q, k, v)
         again = ops.attention(q, k, v)
+        pad_before = y[:, :, 3 * D:].clone()
+        ops.attention(q, k, v, out=q)
+        inplace_q, pad_after = y[:, :, 2 * D:3 * D].clone(), y[:, :, 3 * D:].clone()
     finally:
-        ops.set_option("attention_tail_split", 1)
+        ops.set_option("attention_tail_split", 0)     # the default: off (batch-size invariance, see attention_w4.hip)
     assert torch.equal(split, again)
     assert not torch.equal(split, plain)                        # the split path really ran (different summation order somewhere)
     close(split, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
     close(plain, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
     d = (split.float() - plain.float()).abs()
     assert d.max().item() <= 2.0 ** -7 * ref.abs().max().item() and d.mean().item() <= 1e-3 * ref.abs().mean().item()
-    pad_before = y[:, :, 3 * D:].clone()
-    ops.attention(q, k, v, out=q)
-    assert torch.equal(y[:, :, 2 * D:3 * D], split) and torch.equal(y[:, :, 3 * D:], pad_before)
+    assert torch.equal(inplace_q, split) and torch.equal(pad_after, pad_before)
 
 
 def test_attention_strided_inplace_over_q(ops):

@@ -617,7 +617,9 @@ __global__ __launch_bounds__(256) void attn_w4_merge_kernel(const float* part, b
 static float* g_w4_part = nullptr;
 static int g_w4_cus = 0;
 static constexpr int W4_PART_TILES = 1024;   // (q-tile, key range) slots: 2 rounds of a 512-CU chip, 138 MB
-static int g_w4_split = 1;                   // bench knob (tfx_set_option attention_tail_split): 0 never split
+// tfx_set_option attention_tail_split: OFF by default -- a sample's attention output must not depend on how many samples share its
+// batch (tests/test_fullsize_gpu.py asserts it bit for bit), and which tiles fall into the last round does; 1 = split when it pays
+static int g_w4_split = 0;
 void set_attention_tail_split(int v) { g_w4_split = v; }
 
 int attention_w4_prepare() {

@@ -26,4 +26,4 @@ for B, N in [(8, 4608), (1, 4608), (4, 5248), (1, 1664), (8, 8704), (2, 4608)]:
     for sp in (0, 1):
         print(f"B={B} N={N} H=24 tail_split={sp}: {best[sp]:.4f} ms  {4.0 * B * 24 * N * N * 128 / best[sp] / 1e9:.1f} TFLOP/s", flush=True)
     print("   max |diff| between the two:", (outs[0] - outs[1]).abs().max().item(), " mean |o|:", outs[0].abs().mean().item(), flush=True)
-ops.set_option("attention_tail_split", 1)
+ops.set_option("attention_tail_split", 0)
