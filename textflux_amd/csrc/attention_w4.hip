@@ -35,7 +35,8 @@
 // right behind a chain (prologue) and the output sit behind an explicit drain.  (An MFMA's A / B operands, on the other
 // hand, are safe as soon as it has issued: tools/ubench/mfma_war.)
 // LDS: ring of 3 tiles (K rows padded to 272 B -> conflict-free b128 reads from ONE per-lane base register + immediates;
-// V rows 256 B with their 64-byte segments XOR-swizzled for the transpose reads; 0 bank conflicts in PMC), one barrier per
+// V rows 256 B with their 64-byte segments XOR-swizzled for the transpose reads; PMC: 2.6 M conflict cycles in 199 M LDS-array
+// cycles = 1.3 %, profiles/r03_attention_pmc.json), one barrier per
 // 64-key tile.  Staging global -> registers -> LDS runs as a stream in the MFMA gaps of step 1 of every tile: piece g of tile
 // j + 2 goes to LDS and its register is refilled with the same piece of tile j + 3 right behind, four steps (> 1 us) before
 // it is needed -- with one wave per SIMD nothing else runs while a wave waits for memory.  The buffer descriptors are sized
