@@ -624,7 +624,7 @@ static int g_w4_split = 0;
 void set_attention_tail_split(int v) { g_w4_split = v; }
 
 int attention_w4_prepare() {
-  if (g_w4_part) return 0;
+  if (g_w4_part || !g_w4_split) return 0;      // nothing to allocate while the tail split is off (the default)
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&g_w4_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_w4_cus < 8) g_w4_cus = 256;
