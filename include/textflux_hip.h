@@ -336,7 +336,10 @@ int tfx_mul_act(const void* a, int64_t lda, const void* b, int64_t ldb, void* ou
  *      half-tile (attention_hp.hip).  Bench builds only (-DTFX_BENCH): 12 / 4 = two independent 256-thread workgroups per
  *      CU of 10 / 8; 9 = 8 with 128 keys per barrier; 16 = softmax / MFMA ping-pong between the wave groups.  All compute
  *      the same softmax; 10, 12, 20 and 30 differ from the others in rounding only (one extra bf16 rounding of q * scale,
- *      row sums of the bf16 weights).  "gemm_group_m": row tiles per group of the GEMM tile order (default 4).
+ *      row sums of the bf16 weights); 40 = 30 on v_mfma_f32_16x16x32_bf16 (attention_w16.hip); 0 restores the default.
+ *      "attention_tail_split": 1 lets kernel 30 cut the q-tiles of a partly filled last round of workgroups into two key ranges
+ *      (+ a merge kernel; faster at small batches, but a sample's bits then depend on the batch size: default 0).
+ *      "gemm_group_m": row tiles per group of the GEMM tile order (default 0 = by shape: 1 for N <= 3072, else 4).
  *      "gemm_place": slot assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip).
  *      "gemm_splitk": 0 disables the split-K path of few-tile GEMMs (default 1). */
 int tfx_set_option(const char* name, int value);
