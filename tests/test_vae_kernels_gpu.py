@@ -113,6 +113,36 @@ def test_vae_nhwc_path_matches_oracle():
     assert torch.equal(img[..., :3].permute(0, 3, 1, 2), dec)
 
 
+def test_vae_slicing_is_bit_identical_to_the_batched_path():
+    """enable_slicing() (reference: autoencoder_kl.py:120-132, 263-275, 301-306) runs one sample at a time; every output row of the
+    implicit-GEMM convolutions, every GroupNorm group and every attention row depends on its own sample only, so the result must
+    equal the batched one bit for bit -- through the VAE object and through the pipeline's enable_vae_slicing()."""
+    from oracle import vae_oracle as vo
+    from textflux_amd.vae import AutoencoderKL
+    kw = dict(block_out_channels=(64, 128, 128), layers_per_block=1, latent_channels=16, norm_num_groups=16)
+    sd = vo.seeded_state_dict(vo.VaeConfig(**kw), 77)
+    vae = AutoencoderKL(**kw).load_state_dict(sd, device="cuda")
+    x = rnd((3, 3, 48, 40), 13).clamp(-1, 1).to(BF).cuda()
+    z = rnd((3, 16, 12, 10), 14).to(BF).cuda()
+    enc, dec = vae.encode(x).latent_dist.mean, vae.decode(z, return_dict=False)[0]
+    vae.enable_slicing()
+    try:
+        enc_s, dec_s = vae.encode(x).latent_dist.mean, vae.decode(z, return_dict=False)[0]
+    finally:
+        vae.disable_slicing()
+    assert torch.equal(enc, enc_s) and torch.equal(dec, dec_s)
+    assert not torch.equal(dec[0], dec[1])                           # three different samples went through
+    from textflux_amd.pipeline import FluxFillPipeline
+    pipe = FluxFillPipeline.__new__(FluxFillPipeline)
+    pipe.vae = vae
+    pipe.enable_vae_slicing()
+    assert vae.use_slicing
+    pipe.disable_vae_slicing()
+    assert not vae.use_slicing
+    with pytest.warns(UserWarning, match="enable_vae_tiling"):
+        pipe.enable_vae_tiling()
+
+
 def test_vae_rejects_configs_the_kernels_do_not_cover():
     from textflux_amd.vae import AutoencoderKL
     with pytest.raises(ValueError):

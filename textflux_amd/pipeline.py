@@ -184,18 +184,25 @@ class FluxFillPipeline:
     def maybe_free_model_hooks(self):
         pass                         # nothing is offloaded (reference: D/pipelines/pipeline_utils.py offload hooks)
 
-    def _vae_memory_knob(self, name):
+    def enable_vae_slicing(self):
+        """One sample at a time through the VAE (reference: pipeline_flux_fill.py enable_vae_slicing -> AutoencoderKL.enable_slicing);
+        bit-identical to the batched result here."""
+        self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        self.vae.disable_slicing()
+
+    def enable_vae_tiling(self):
         import warnings
         if not getattr(self, "_warned_vae_knob", False):
             self._warned_vae_knob = True
-            warnings.warn(f"{name}() has no effect here: the VAE runs untiled / unsliced at every supported geometry "
-                          "(288 GB of HBM per MI355X); the call is accepted for drop-in compatibility", stacklevel=3)
+            warnings.warn("enable_vae_tiling() has no effect here: the VAE runs untiled at every supported geometry (288 GB of HBM "
+                          "per MI355X; 1024 x 1024 at batch 8 is a test) -- the reference's tiled decode blends overlapping tiles, "
+                          "i.e. computes a DIFFERENT image; use enable_vae_slicing() to bound the working set.  The call is "
+                          "accepted for drop-in compatibility", stacklevel=2)
 
-    def enable_vae_slicing(self):
-        self._vae_memory_knob("enable_vae_slicing")
-
-    def enable_vae_tiling(self):
-        self._vae_memory_knob("enable_vae_tiling")
+    def disable_vae_tiling(self):
+        pass
 
     @property
     def guidance_scale(self):

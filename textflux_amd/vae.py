@@ -198,9 +198,35 @@ class AutoencoderKL:
         return self._res(x, p + ".resnets.1")
 
     # ---- NHWC entry points (what the pipeline uses) ----------------------------------------------------------------
+    # enable_slicing() / disable_slicing(): the reference's memory knob (D/models/autoencoders/autoencoder_kl.py:120-132,
+    # 263-275, 301-306): with it, encode / decode run one sample at a time and concatenate.  Here every row of an implicit-GEMM
+    # convolution and every GroupNorm group depends on its own sample only, so the sliced result is bit-identical to the batched
+    # one (tests/test_vae_kernels_gpu.py); it bounds the activation working set to one image's.
+    use_slicing = False
+
+    def enable_slicing(self):
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    def _sliced(self, fn, x: torch.Tensor) -> torch.Tensor:
+        if not self.use_slicing or x.shape[0] <= 1:
+            return fn(x)
+        out = None
+        for i in range(x.shape[0]):
+            o = fn(x[i:i + 1])
+            if out is None:
+                out = torch.empty(x.shape[0], *o.shape[1:], dtype=o.dtype, device=o.device)
+            out[i:i + 1].copy_(o)        # device-to-device copy of one sample's result
+        return out
+
     @torch.no_grad()
     def encode_moments_nhwc(self, x8: torch.Tensor) -> torch.Tensor:
         """x8 [B, H, W, 8] NHWC bf16 (tfx_prep_image) -> posterior moments [B, H/8, W/8, 2 * latent] NHWC (mean | logvar)."""
+        return self._sliced(self._encode_moments_nhwc, x8)
+
+    def _encode_moments_nhwc(self, x8: torch.Tensor) -> torch.Tensor:
         c = self.config
         h = self._conv(x8, "encoder.conv_in")
         n = len(c.block_out_channels)
@@ -215,6 +241,9 @@ class AutoencoderKL:
     @torch.no_grad()
     def decode_nhwc(self, z: torch.Tensor) -> torch.Tensor:
         """z [B, h, w, latent] NHWC bf16 -> image [B, 8h, 8w, 8] NHWC bf16 (first out_channels channels valid)."""
+        return self._sliced(self._decode_nhwc, z)
+
+    def _decode_nhwc(self, z: torch.Tensor) -> torch.Tensor:
         c = self.config
         if z.shape[-1] != _narrow(c.latent_channels):
             zp = torch.zeros(*z.shape[:-1], _narrow(c.latent_channels), dtype=z.dtype, device=z.device)
