@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--sampler", choices=["euler", "amo"], default="euler")
     ap.add_argument("--layers", type=int, nargs=2, default=[19, 38], help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pil-delta", action="store_true", help="skip the untimed output_type='pil' vs 'pt' comparison")
     ap.add_argument("--cpu-baseline-c1", action="store_true", help="only run BASELINE config 1 on the host cores (minutes, ~50 GB RAM) and print it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of per-step hipGraph replay")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help=argparse.SUPPRESS)  # tuning knobs (tfx_set_option)
@@ -262,9 +263,11 @@ def main():
     for k in range(a.steps):
         out = one_call()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0        # this rank's own K calls, before it waits for the others (diagnostics only)
     tdist.barrier()
     torch.cuda.synchronize()
     elapsed = tdist.max_over_ranks(time.perf_counter() - t0, dev)
+    own_all = tdist.all_ranks(own, dev)
     # roofline sample: ONE MORE call, untimed and eager (the library's per-launch HIP events only see eager launches; a
     # replayed graph's kernels are not individually timed), so that the sample is every GEMM / attention launch of a whole
     # call -- 30 steps, VAE, text encoders -- not just the eager first step of a graph-replayed call
@@ -275,6 +278,21 @@ def main():
     torch.cuda.synchronize()
     ops.prof_enable(False)
     pipe.enable_hip_graph(not a.no_graph)
+    # what the timed calls leave out of a17: output_type="pt" keeps the decoded images on the device; one untimed call with
+    # output_type="pil" (device -> host copy + uint8 / PIL conversion of the batch) gives the difference
+    pil_delta_ms = None
+    if rank == 0 and not a.no_pil_delta:
+        def timed(kind):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, image=image, mask_image=mask, height=H, width=W,
+                     num_inference_steps=1, guidance_scale=30.0, generator=gen, output_type=kind)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+        timed("pt")
+        t_pt, t_pil = min(timed("pt"), timed("pt")), min(timed("pil"), timed("pil"))
+        pil_delta_ms = (t_pil - t_pt) * 1e3
     seen = tdist.ranks_seen(dev)   # ranks that answered an RCCL all-reduce
 
     if rank == 0:
@@ -287,7 +305,7 @@ def main():
         # rocm-smi its own sustained loops): they are READ from the newest committed profile and say so -- "live": false,
         # the file, and the round it was collected in -- so that no future run can pass them off as measured by this run.
         def committed(stem):
-            for rnd in ("r03", "r02"):
+            for rnd in ("r04", "r03", "r02"):
                 fn = os.path.join(REPO, "profiles", f"{rnd}_{stem}.json")
                 if os.path.exists(fn):
                     with open(fn) as f:
@@ -329,11 +347,16 @@ def main():
                                       "injected random prompt embeddings; text encoders bypassed)"),
             "config": {"workload": f"{'P1024' if (H, W) == (1024, 1024) else f'{H}x{W}'}: FluxFillPipeline.__call__ {H}x{W}, {n} {a.sampler} steps, guidance 30, "
                                    f"batch {B}/GPU (S={S} image + 512 text tokens), "
-                                   + ("T5-XXL (8 prompts per rank) + CLIP-L prompt encoding, " if use_te else "") + "VAE encode+decode included"
+                                   + ("T5-XXL (8 prompts per rank) + CLIP-L prompt encoding from stand-in token ids (no tokenizer vocabularies offline), " if use_te else "")
+                                   + "VAE encode+decode included, output_type='pt' (decoded images stay in HBM: the D2H copy + uint8/PIL conversion "
+                                     "of a17 is outside the timed region, see pil_output_delta_ms_per_call)"
                                    + ("" if full else f" [REDUCED MODEL {a.layers} - not a valid headline]")
                                    + (" [fp8 linears: BASELINE config 5 precision, not the bf16 headline]" if a.fp8 else ""),
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards; shared CLIP conditioning broadcast over RCCL, T5 prompts encoded per rank)"},
             "rccl_ranks_seen": seen,
+            "elapsed_s": elapsed, "elapsed_per_rank_s": {"min": min(own_all), "max": max(own_all), "ranks": own_all,
+                                                         "note": "each rank's own K calls up to its synchronize(), before the closing barrier"},
+            "pil_output_delta_ms_per_call": pil_delta_ms,
             "sec_per_img_per_gpu": elapsed / (B * a.steps),
             "dit_algorithmic_tflops_per_gpu": dit_flops(S) * n * B * a.steps / elapsed / 1e12 if full else None,
             "roofline": {"bound": "mfma", "kernel": "tfx::gemm8pp_kernel (persistent MFMA GEMM, all epilogues; + gemm8p_kernel for K % 128 != 0)", "achieved": achieved,
@@ -345,6 +368,12 @@ def main():
                          "attention": {"achieved": att_fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0,
                                        "launches": att_n, "avg_launch_ms": att_ms / max(att_n, 1)}},
         }
+        peak = MFMA_PEAK_TFLOPS * (2 if a.fp8 else 1)
+        rec["roofline"]["attention"]["frac"] = rec["roofline"]["attention"]["achieved"] / MFMA_PEAK_TFLOPS     # attention is bf16 in both modes
+        # the number north_star's ">= 60 % MFMA utilisation on the DiT block" is written against: algorithmic DiT FLOPs of the timed
+        # region (GEMMs + attention, text encoders / VAE / everything else counted as time but not as FLOPs) over the bf16 dense peak
+        rec["roofline"]["dit_achieved"] = rec["dit_algorithmic_tflops_per_gpu"]
+        rec["roofline"]["dit_frac"] = rec["dit_algorithmic_tflops_per_gpu"] / MFMA_PEAK_TFLOPS if full and not a.fp8 else None
         rec["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(H, W, n)   # rank 0 at N = 1 only
         if rec["cpu_baseline"] is not None:
             try:   # the full BASELINE config-1 run (minutes of CPU): measured once per round by `--cpu-baseline-c1`, committed

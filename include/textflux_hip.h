@@ -27,6 +27,13 @@ typedef void* tfx_stream;
 /* ---- library -------------------------------------------------------------------------------------------- */
 const char* tfx_version(void);
 const char* tfx_last_error(void);
+/* ABI stamp.  TFX_ABI_VERSION is bumped whenever a struct below grows or the meaning of a field / entry point changes;
+ * tfx_abi_info writes {TFX_ABI_VERSION the library was built with, sizeof(tfx_gemm_args), sizeof(tfx_attn_args),
+ * sizeof(tfx_dit_desc), sizeof(tfx_step_desc)} (as many as fit in n) and returns how many values there are.  A binding
+ * compares them with its own view of this header BEFORE the first call that passes a struct: a library built from an older
+ * header would otherwise ignore the tail fields of a grown struct silently (no reference counterpart: the reference has no FFI). */
+#define TFX_ABI_VERSION 4
+int tfx_abi_info(int32_t* out, int n);
 /* Writes the gcnArchName of the current device (e.g. "gfx950:sramecc+:xnack-") into buf.  Needs a GPU. */
 int tfx_query_arch(char* buf, int buflen);
 

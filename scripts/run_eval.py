@@ -44,19 +44,24 @@ def load_data_from_json(json_path):
     return lst
 
 
-def build_parser():
+def build_parser(lora: bool = False):
+    """lora=True: the interface of scripts/run_eval_lora.py (reference :219-232) -- --lora_weights_path instead of --weights_path,
+    --scheduler defaults to "overshoot"."""
     ap = argparse.ArgumentParser(description="Batched multi-GPU stitching and FLUX-Fill inference (TextFlux evaluation driver)")
     ap.add_argument("--json_path", type=str, help="Path to the annos.json file containing annotation information")
     ap.add_argument("--original_images_dir", type=str, help="Path to the folder containing original images")
     ap.add_argument("--output_dir", type=str, default="visualization_results", help="Main output folder for results")
-    ap.add_argument("--weights_path", type=str, help="Path to transformer weights")
+    if lora:
+        ap.add_argument("--lora_weights_path", type=str, help="Path to lora weights")
+    else:
+        ap.add_argument("--weights_path", type=str, help="Path to transformer weights")
     ap.add_argument("--font_path", type=str, default="./resource/font/Arial-Unicode-Regular.ttf", help="Path to the font file (.ttf or .ttc)")
     ap.add_argument("--text_height_ratio", type=float, default=0.1667, help="Ratio of top text line height to image width (default: 1/6)")
     ap.add_argument("--steps", type=int, default=30, help="Inference steps")
     ap.add_argument("--guidance_scale", type=float, default=30, help="Guidance scale")
     ap.add_argument("--seed", type=int, default=42, help="Random seed")
     ap.add_argument("--num_gpus", type=int, default=4, help="Number of GPUs to use")
-    ap.add_argument("--scheduler", type=str, default="", help='Sampler, None or "overshoot"')
+    ap.add_argument("--scheduler", type=str, default="overshoot" if lora else "", help='Sampler, None or "overshoot"')
     # not in the reference: batching, and the {image, mask, text} list interface of the earlier rounds
     ap.add_argument("--batch_size", type=int, default=8, help="same-geometry images per pipeline call")
     ap.add_argument("--items", type=str, default=None, help="JSON list of {image, mask, text} instead of --json_path")
@@ -79,14 +84,47 @@ def select_tasks(data_list):
     return tasks, skipped
 
 
-def main(argv=None):
-    a = build_parser().parse_args(argv)
+def load_lora_transformer(lora_weights_path, base_transformer=None):
+    """The reference worker's load sequence (scripts/run_eval_lora.py:148-167): the BASE FLUX.1-Fill-dev transformer, the LoRA file
+    through FluxFillPipeline.lora_state_dict(return_alphas=True), the format check (every key names a LoRA / DoRA tensor, else
+    ValueError("Invalid LoRA checkpoint.")), then load_lora_into_transformer -- which here MERGES the update into the fused weights
+    once (textflux_amd/lora.py) instead of wrapping every Linear in a PEFT layer.  `base_transformer`: an already loaded
+    transformer (tests); default = $TEXTFLUX_BASE/transformer, the local copy of black-forest-labs/FLUX.1-Fill-dev/transformer."""
+    import torch
+    import run_inference as ri
+    from textflux_amd.pipeline import FluxFillPipeline
+    from textflux_amd.transformer import FluxTransformer2DModel
+    transformer = base_transformer if base_transformer is not None else FluxTransformer2DModel.from_pretrained(
+        ri.BASE, subfolder="transformer", torch_dtype=torch.bfloat16)
+    state_dict, network_alphas = FluxFillPipeline.lora_state_dict(lora_weights_path, return_alphas=True)
+    if not all("lora" in key or "dora_scale" in key for key in state_dict.keys()):
+        raise ValueError("Invalid LoRA checkpoint.")
+    FluxFillPipeline.load_lora_into_transformer(state_dict=state_dict, network_alphas=network_alphas, transformer=transformer)
+    return transformer
+
+
+def main(argv=None, lora: bool = False, script: str = __file__):
+    a = build_parser(lora).parse_args(argv)
     legacy = a.items is not None
-    if not legacy and not (a.json_path and a.original_images_dir and a.weights_path):
-        raise SystemExit("--json_path, --original_images_dir and --weights_path are required")
+    weights = a.lora_weights_path if lora else a.weights_path
+    if not legacy and not (a.json_path and a.original_images_dir and weights):
+        raise SystemExit(f"--json_path, --original_images_dir and --{'lora_' if lora else ''}weights_path are required")
     from textflux_amd import distributed as tdist
-    n_gpus = a.gpus if (legacy and a.gpus is not None) else (a.gpus or a.num_gpus)
-    tdist.respawn_under_torchrun(n_gpus, __file__, sys.argv[1:])
+    # --items (legacy) mode: --gpus only, no respawn without it (as before the reference CLI was added); the reference interface
+    # defaults to --num_gpus 4 like the reference, clamped to the GPUs this host has
+    if legacy:
+        n_gpus = a.gpus
+    else:
+        n_gpus = a.gpus or a.num_gpus
+        try:
+            import torch
+            have = torch.cuda.device_count()
+        except Exception:
+            have = 0
+        if have and n_gpus > have:
+            print(f"--num_gpus {n_gpus} > {have} visible GPUs: using {have}")
+            n_gpus = have
+    tdist.respawn_under_torchrun(n_gpus, script, sys.argv[1:] if argv is None else list(argv))
     rank, world, local = tdist.init_from_env()
     import run_inference as ri
     from textflux_amd import batch_driver, glyph
@@ -113,8 +151,14 @@ def main(argv=None):
             font = glyph.load_font(None)
             print(f"Font '{a.font_path}' not found, using default font.")
         eval_cfg = dict(original_images_dir=a.original_images_dir, font=font, text_height_ratio=a.text_height_ratio)
-        ri.TRANSFORMER = a.weights_path
-    pipe = ri.load_flux_pipeline(text_encoders=True)     # every rank encodes its own prompts: no rank-0 straggler
+        if not lora:
+            ri.TRANSFORMER = a.weights_path
+    if lora and weights:      # every rank (the reference: every worker) loads the base transformer and merges the LoRA into it
+        import torch
+        from textflux_amd.pipeline import FluxFillPipeline
+        pipe = FluxFillPipeline.from_pretrained(ri.BASE, transformer=load_lora_transformer(weights), torch_dtype=torch.bfloat16).to("cuda")
+    else:
+        pipe = ri.load_flux_pipeline(text_encoders=True)     # every rank encodes its own prompts: no rank-0 straggler
     if a.scheduler == "overshoot":
         ri.use_overshoot_sampler(pipe)
     pipe.enable_hip_graph(True)

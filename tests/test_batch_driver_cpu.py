@@ -241,6 +241,46 @@ def test_run_eval_cli_speaks_the_reference_flags(tmp_path):
     assert re_.load_data_from_json(str(tmp_path / "bad.json")) == []
 
 
+def test_run_eval_lora_cli_and_format_check():
+    """scripts/run_eval_lora.py (reference :148-167, :219-232): --lora_weights_path instead of --weights_path, the sampler
+    defaults to "overshoot", and a file whose keys are not all LoRA / DoRA tensors is refused with the reference's message
+    BEFORE anything is merged (the check sits between lora_state_dict and load_lora_into_transformer)."""
+    sys.path.insert(0, os.path.join(REPO, "scripts"))
+    import importlib
+    re_ = importlib.import_module("run_eval")
+    a = re_.build_parser(lora=True).parse_args(["--json_path", "annos.json", "--original_images_dir", "o", "--lora_weights_path", "l"])
+    assert (a.lora_weights_path, a.scheduler, a.steps, a.guidance_scale, a.seed, a.num_gpus, a.text_height_ratio) == (
+        "l", "overshoot", 30, 30, 42, 4, 0.1667)
+    assert not hasattr(a, "weights_path")
+    with pytest.raises(SystemExit):
+        re_.build_parser(lora=True).parse_args(["--weights_path", "w"])           # the LoRA script has no such flag
+    with pytest.raises(SystemExit):
+        re_.main(["--json_path", "annos.json", "--original_images_dir", "o"], lora=True)   # --lora_weights_path is required
+    merged = []
+
+    class StubTr:
+        pass
+
+    from textflux_amd.pipeline import FluxFillPipeline
+    real = FluxFillPipeline.load_lora_into_transformer
+    FluxFillPipeline.load_lora_into_transformer = classmethod(lambda cls, state_dict, network_alphas, transformer, **k: merged.append(
+        (sorted(state_dict), sorted(network_alphas), transformer)))
+    try:
+        tr = StubTr()
+        good = {"transformer.x.lora_A.weight": torch.zeros(2, 4), "transformer.x.lora_B.weight": torch.zeros(4, 2),
+                "transformer.x.alpha": torch.tensor(2.0)}
+        assert re_.load_lora_transformer(good, base_transformer=tr) is tr
+        assert merged == [(["transformer.x.lora_A.weight", "transformer.x.lora_B.weight"], ["transformer.x.alpha"], tr)]
+        bad = dict(good, **{"transformer.x.weight": torch.zeros(4, 4)})
+        with pytest.raises(ValueError, match="Invalid LoRA checkpoint."):
+            re_.load_lora_transformer(bad, base_transformer=tr)
+        assert len(merged) == 1
+    finally:
+        FluxFillPipeline.load_lora_into_transformer = real
+    src = open(os.path.join(REPO, "scripts", "run_eval_lora.py")).read()
+    assert "run_eval.main(lora=True" in src
+
+
 def test_single_process_driver_needs_no_process_group():
     pipe, saved = StubPipe(0), {}
     res = bd.run_items(_items()[:3], pipe, None, batch_size=8, device="cpu", loader=_loader, save=lambda i, im: saved.__setitem__(i, im.size))

@@ -35,6 +35,34 @@ def test_version_and_error_strings(lib):
     assert isinstance(lib.tfx_last_error(), bytes)
 
 
+def test_abi_stamp_matches_the_binding_and_a_foreign_library_is_refused(lib, monkeypatch):
+    """a libtextflux_hip.so that arrives without its source hash is not rebuilt -- so it must prove it was built
+    from THIS header: tfx_abi_info = {TFX_ABI_VERSION, sizeof the four argument structs}, compared in _lib.lib()."""
+    import ctypes as C
+    got = (C.c_int32 * 5)()
+    assert lib.tfx_abi_info(got, 5) == 5
+    assert list(got) == [L.header_abi_version(), C.sizeof(L.GemmArgs), C.sizeof(L.AttnArgs), C.sizeof(L.DitDesc), C.sizeof(L.StepDesc)]
+    two = (C.c_int32 * 2)(-1, -1)
+    assert lib.tfx_abi_info(two, 1) == 5 and list(two) == [L.header_abi_version(), -1]     # writes only what fits
+    L._check_abi(lib)
+    monkeypatch.setattr(L, "header_abi_version", lambda: L.header_abi_version.__wrapped__() + 1 if hasattr(L.header_abi_version, "__wrapped__") else 10 ** 6)
+    with pytest.raises(RuntimeError, match="ABI stamp"):
+        L._check_abi(lib)                               # a library of another header version
+    monkeypatch.undo()
+
+    class Grown(C.Structure):
+        _fields_ = list(L.StepDesc._fields_) + [("new_tail_field", C.c_void_p)]
+    monkeypatch.setattr(L, "StepDesc", Grown)
+    with pytest.raises(RuntimeError, match="ABI stamp"):
+        L._check_abi(lib)                               # the binding grew a struct the library does not know
+
+    class NoStamp:
+        def __getattr__(self, name):
+            raise AttributeError(name)
+    with pytest.raises(RuntimeError, match="predates the ABI stamp"):
+        L._check_abi(NoStamp())
+
+
 def test_null_arguments_are_rejected_without_a_gpu(lib):
     assert lib.tfx_gemm_bf16(None, -1, None) != 0
     assert b"null" in lib.tfx_last_error()

@@ -97,6 +97,25 @@ def test_lora_pipeline_from_checkpoint_directory(env):
     ri.PIPE = None
 
 
+def test_run_eval_lora_load_sequence(env):
+    """scripts/run_eval_lora.py's worker load (reference :148-167): base transformer from <BASE>/transformer + the LoRA file ->
+    the merged weights run_inference_lora.py's loader produces; a non-LoRA key is refused."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import run_eval
+    tr = run_eval.load_lora_transformer(env["lora"])
+    D = tr.inner_dim
+    got = tr.w["d0.qkv_img.w"][2 * D:3 * D].float().cpu()
+    want, base = env["merged"]["transformer_blocks.0.attn.to_q.weight"], env["sd"]["transformer_blocks.0.attn.to_q.weight"]
+    assert (got - want).abs().max().item() <= 2 ** -7 * want.abs().max().item() and (got - base).abs().mean().item() > 1e-3
+    from safetensors.torch import load_file
+    from textflux_amd import lora
+    sd = load_file(os.path.join(env["lora"], lora.LORA_WEIGHT_NAME_SAFE))
+    sd["transformer.transformer_blocks.0.attn.to_q.weight"] = torch.zeros(4, 4)
+    with pytest.raises(ValueError, match="Invalid LoRA checkpoint."):
+        run_eval.load_lora_transformer(sd)
+
+
 def test_batch_driver_matches_single_image_calls(env, tmp_path):
     """scripts/run_eval.py's engine (textflux_amd/batch_driver.run_items) on the real pipeline: same-geometry items go
     through ONE batched call with per-item generators, and reproduce the single-image run_inference results."""

@@ -85,6 +85,7 @@ class StepDesc(C.Structure):
 SIGNATURES = {
     "tfx_version": (c_char_p, []),
     "tfx_last_error": (c_char_p, []),
+    "tfx_abi_info": (c_int, [C.POINTER(c_int32), c_int]),
     "tfx_query_arch": (c_int, [c_char_p, c_int]),
     "tfx_gemm_bf16": (c_int, [C.POINTER(GemmArgs), c_int, c_void_p]),
     "tfx_gemm_bf16_f32": (c_int, [C.POINTER(GemmArgs), c_void_p]),
@@ -168,11 +169,35 @@ def _src_hash() -> str:
     return h.hexdigest()
 
 
+def header_abi_version() -> int:
+    """TFX_ABI_VERSION of the include/textflux_hip.h this binding mirrors."""
+    import re
+    with open(os.path.join(os.path.dirname(_HERE), "include", "textflux_hip.h")) as f:
+        return int(re.search(r"#define\s+TFX_ABI_VERSION\s+(\d+)", f.read()).group(1))
+
+
+def _check_abi(l: C.CDLL) -> None:
+    """A library that does not export tfx_abi_info, or reports another TFX_ABI_VERSION / other struct sizes than this binding's
+    ctypes mirrors, was built from a different header: refuse it (a grown struct's tail fields would be ignored silently)."""
+    try:
+        fn = l.tfx_abi_info
+    except AttributeError:
+        raise RuntimeError(f"{LIB_PATH} predates the ABI stamp (no tfx_abi_info): rebuild it (`make -C textflux_amd/csrc -B`)") from None
+    fn.restype, fn.argtypes = c_int, [C.POINTER(c_int32), c_int]
+    got = (c_int32 * 5)()
+    n = fn(got, 5)
+    want = [header_abi_version(), C.sizeof(GemmArgs), C.sizeof(AttnArgs), C.sizeof(DitDesc), C.sizeof(StepDesc)]
+    if n != 5 or list(got) != want:
+        raise RuntimeError(f"{LIB_PATH} was built from another include/textflux_hip.h: ABI stamp {list(got)[:n]} != the binding's "
+                           f"{want} (version, sizeof gemm_args / attn_args / dit_desc / step_desc); rebuild it")
+
+
 def is_stale() -> bool:
     """True when libtextflux_hip.so is missing or was not built from the sources now in csrc/ (content hash kept in a
     side file next to the library; mtimes do not survive the copy to the GPU box).  A library that arrives WITHOUT its
-    hash file (the file is git-ignored; a hand-copied build) is taken as it is: never recompiled behind the caller's back,
-    and usable where hipcc is absent."""
+    hash file (the file is git-ignored; a hand-copied build) is not recompiled behind the caller's back and stays usable where
+    hipcc is absent -- but it is not trusted blindly either: lib() checks its ABI stamp (tfx_abi_info: TFX_ABI_VERSION and the
+    struct sizes) against this binding and refuses a library built from another header."""
     if os.environ.get("TFX_LIB"):
         return not os.path.exists(LIB_PATH)          # an explicitly chosen build is the caller's business
     if not os.path.exists(LIB_PATH):
@@ -223,6 +248,7 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  textflux_amd has no CPU / eager fallback.")
         l = C.CDLL(LIB_PATH)
+        _check_abi(l)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args

@@ -771,7 +771,6 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
 #endif  // TFX_BENCH
 
 static int g_attn_waves = 30;  // 30 (default) one wave per SIMD, 64 rows per wave, 32x32x16 MFMA (attention_w4.hip); 10 matrix-pipe softmax, 8 waves x 32 rows; 8 exact-online-max lock-step kernel; 4 / 12 = 4-wave workgroups of 8 / 10; 9 = 128 keys per barrier; 16 = ping-pong
-static int g_attn_force = 0;   // set by an explicit tfx_set_option("attention_waves", .): no size heuristic, the named kernel runs
 static unsigned long long* g_attn_dbg = nullptr;  // bench-only phase timing buffer
 void set_attention_debug(void* p) {
   g_attn_dbg = (unsigned long long*)p;
@@ -780,8 +779,8 @@ void set_attention_debug(void* p) {
 static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
 void set_attention_waves(int nw) {
-  if (nw == 0) { g_attn_force = 0; g_attn_waves = 30; return; }
-  g_attn_force = 1; g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || nw == 30 || nw == 40) ? nw : 16;
+  if (nw == 0) { g_attn_waves = 30; return; }
+  g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || nw == 30 || nw == 40) ? nw : 16;
 }
 
 // The product library carries the default kernel (30: attention_w4.hip; it needs 16-byte aligned output rows and falls back to

@@ -45,6 +45,7 @@
 // Measured (MI355X, B = 8, H = 24, N = 4608, random data): 1.12-1.14 PFLOP/s vs 1.04-1.07 for attn_mx_kernel on the same
 // box, 480 vs 495 ms per 57-block DiT forward; on zero data (no power cap) 1.44 PFLOP/s.  Both are power-limited on random
 // data: 1.9 GHz at 1300 W.
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -614,26 +615,42 @@ __global__ __launch_bounds__(256) void attn_w4_merge_kernel(const float* part, b
   *reinterpret_cast<u32x2*>(O + b * o_bs + (int64_t)row * ldo + h * W4_HD + c) = o2;
 }
 
-// scratch of the tail split: allocated once (never inside a stream capture, never freed: captured graphs keep the pointer)
-static float* g_w4_part = nullptr;
-static int g_w4_cus = 0;
+// scratch of the tail split: one per (device, stream) that ever ran a split launch -- two launches in flight on different streams
+// (a graph replay on a side stream next to an eager call) must not share partials.  Allocated on first use outside a stream
+// capture, never freed (captured graphs keep the pointer); a launch on a stream without scratch (first seen during capture, or
+// the table is full) simply runs unsplit.
 static constexpr int W4_PART_TILES = 1024;   // (q-tile, key range) slots: 2 rounds of a 512-CU chip, 138 MB
+static constexpr int W4_PART_SLOTS = 8;
+struct W4Scratch { int dev; hipStream_t st; float* part; int cus; };
+static W4Scratch g_w4_scr[W4_PART_SLOTS];
+static int g_w4_nscr = 0;
+static std::mutex g_w4_mu;
 // tfx_set_option attention_tail_split: OFF by default -- a sample's attention output must not depend on how many samples share its
 // batch (tests/test_fullsize_gpu.py asserts it bit for bit), and which tiles fall into the last round does; 1 = split when it pays
 static int g_w4_split = 0;
 void set_attention_tail_split(int v) { g_w4_split = v; }
 
-int attention_w4_prepare() {
-  if (g_w4_part || !g_w4_split) return 0;      // nothing to allocate while the tail split is off (the default)
+// the scratch of (current device, st); allocates it when `may_alloc` (never inside a stream capture)
+static const W4Scratch* w4_scratch(hipStream_t st, bool may_alloc) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (hipDeviceGetAttribute(&g_w4_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_w4_cus < 8) g_w4_cus = 256;
-  if (hipMalloc((void**)&g_w4_part, (size_t)W4_PART_TILES * 256 * W4_PROW * sizeof(float)) != hipSuccess) {
+  std::lock_guard<std::mutex> lk(g_w4_mu);
+  for (int i = 0; i < g_w4_nscr; ++i)
+    if (g_w4_scr[i].dev == dev && g_w4_scr[i].st == st) return &g_w4_scr[i];
+  if (!may_alloc || g_w4_nscr == W4_PART_SLOTS) return nullptr;
+  W4Scratch s{dev, st, nullptr, 256};
+  if (hipDeviceGetAttribute(&s.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || s.cus < 8) s.cus = 256;
+  if (hipMalloc((void**)&s.part, (size_t)W4_PART_TILES * 256 * W4_PROW * sizeof(float)) != hipSuccess) {
     (void)hipGetLastError();
-    g_w4_part = nullptr;
-    return fail("attention: cannot allocate the tail-split scratch");
+    return nullptr;
   }
-  return 0;
+  g_w4_scr[g_w4_nscr] = s;
+  return &g_w4_scr[g_w4_nscr++];
+}
+
+int attention_w4_prepare(hipStream_t st) {
+  if (!g_w4_split) return 0;      // nothing to allocate while the tail split is off (the default)
+  return w4_scratch(st, true) ? 0 : fail("attention: cannot allocate the tail-split scratch");
 }
 
 int joint_attention_w4(const AttnArgs& a, hipStream_t st) {
@@ -661,24 +678,25 @@ int joint_attention_w4(const AttnArgs& a, hipStream_t st) {
   // taken when a half would be shorter than 24 key tiles (its prologue, Q load and partial store cost more than the round
   // gains), without a full round in front, or when the last round is more than half full (the halves would need two rounds).
   int nfull = T, nsplit = 1, nparts = 0, xsplit = 0;
-  if (g_w4_split && !g_w4_part) {
+  float* part = nullptr;
+  if (g_w4_split) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) (void)attention_w4_prepare();
+    const bool capturing = !(hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone);
     (void)hipGetLastError();
-  }
-  if (g_w4_split && g_w4_part) {
-    const int C = g_w4_cus, tail = T % C, nkv = (a.N + W4_KV - 1) / W4_KV;
-    const int m = (tail + a.B - 1) / a.B;
-    if (tail && T >= C && m * a.B * 2 <= C + 8 && nkv >= 48 && m < a.H * nqb && m * a.B * 2 <= W4_PART_TILES) {
-      xsplit = m; nsplit = 2; nfull = T - m * a.B; nparts = m * a.B * 2;
+    if (const W4Scratch* sc = w4_scratch(st, !capturing)) {
+      const int C = sc->cus, tail = T % C, nkv = (a.N + W4_KV - 1) / W4_KV;
+      const int m = (tail + a.B - 1) / a.B;
+      if (tail && T >= C && m * a.B * 2 <= C + 8 && nkv >= 48 && m < a.H * nqb && m * a.B * 2 <= W4_PART_TILES) {
+        xsplit = m; nsplit = 2; nfull = T - m * a.B; nparts = m * a.B * 2; part = sc->part;
+      }
     }
   }
   const unsigned grid = nsplit > 1 ? (unsigned)(((nfull + 7) & ~7) + nparts) : (unsigned)T;
   attn_w4_kernel<<<grid, 256, ATT_LDS_W4, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
                                                  a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
-                                                 a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, g_w4_part);
+                                                 a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, part);
   if (nsplit > 1)
-    attn_w4_merge_kernel<<<(unsigned)(xsplit * a.B * 32), 256, 0, st>>>(g_w4_part, (bf16_t*)a.o, a.ldo, a.o_bstride, a.H, a.N, nqb,
+    attn_w4_merge_kernel<<<(unsigned)(xsplit * a.B * 32), 256, 0, st>>>(part, (bf16_t*)a.o, a.ldo, a.o_bstride, a.H, a.N, nqb,
                                                                               xsplit, nsplit);
   return 0;
 }

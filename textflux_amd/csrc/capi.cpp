@@ -220,6 +220,12 @@ extern "C" {
 
 const char* tfx_version(void) { return "textflux_hip 0.1 (gfx950)"; }
 const char* tfx_last_error(void) { return last_error(); }
+int tfx_abi_info(int32_t* out, int n) {
+  const int32_t v[5] = {TFX_ABI_VERSION, (int32_t)sizeof(tfx_gemm_args), (int32_t)sizeof(tfx_attn_args), (int32_t)sizeof(tfx_dit_desc),
+                        (int32_t)sizeof(tfx_step_desc)};
+  for (int i = 0; i < 5 && i < n; ++i) out[i] = v[i];
+  return 5;
+}
 
 int tfx_query_arch(char* buf, int buflen) {
   int dev = 0;
@@ -577,7 +583,7 @@ int tfx_dit_step_capture(const tfx_step_desc* s, tfx_stream stream, tfx_graph* o
   if (!out) return fail("tfx_dit_step_capture: null output handle");
   if (!stream) return fail("tfx_dit_step_capture: the NULL stream cannot be captured; pass a created stream");
   hipStream_t st = S(stream);
-  (void)attention_w4_prepare();   // the attention kernel's scratch cannot be allocated inside a capture
+  (void)attention_w4_prepare(st);   // the attention kernel's scratch (of this stream) cannot be allocated inside a capture
   hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return fail("tfx_dit_step_capture: hipStreamBeginCapture: %s", hipGetErrorString(e));
   const int rc = step_enqueue(*s, st);

@@ -84,7 +84,7 @@ struct AttnArgs {
 int joint_attention(const AttnArgs& a, hipStream_t st);
 int joint_attention_hp(const AttnArgs& a, hipStream_t st);   // half-tile software-pipelined kernel (attention_hp.hip)
 int joint_attention_w16(const AttnArgs& a, hipStream_t st);  // one wave per SIMD on v_mfma_f32_16x16x32_bf16 (attention_w16.hip)
-int attention_w4_prepare();                                    // allocates the tail-split scratch (call outside stream capture)
+int attention_w4_prepare(hipStream_t st);                      // allocates the tail-split scratch of `st` (call outside stream capture)
 void set_attention_tail_split(int v);                          // 0 = never split the last round's q-tiles by keys (bench knob)
 int joint_attention_w4(const AttnArgs& a, hipStream_t st);   // one wave per SIMD, 64 query rows per wave (attention_w4.hip)
 void set_attention_ablation(int a);

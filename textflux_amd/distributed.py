@@ -117,6 +117,16 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def all_ranks(value: float, device) -> List[float]:
+    """The value of every rank, in rank order (diagnostics: which rank was the straggler)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == "nccl":      # name the device: RCCL would otherwise guess it from the rank

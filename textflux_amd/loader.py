@@ -121,6 +121,10 @@ class ShardStreamer:
                 raise RuntimeError(f"{path}: destination of {k} must be contiguous with {e['shape']} elements")
             if hi > lo:
                 todo.append((lo, hi, dst, dt))
+        if self.cuda:
+            # the destinations were allocated on the CURRENT stream: if the caching allocator handed out blocks that kernels queued
+            # there are still using (a transformer swapped right after dropping the old one), the side-stream DMAs must queue behind them
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
         fd = os.open(path, os.O_RDONLY)
         try:
             i = 0

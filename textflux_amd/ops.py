@@ -13,7 +13,7 @@ import torch
 from . import _lib as L
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES, EPI_BIAS_RES = 0, 1, 2, 3
-DEFAULT_ATTENTION = 0      # tfx_set_option("attention_waves", 0): back to the library's own choice (40, or 30 for grids smaller than the chip)
+DEFAULT_ATTENTION = 0      # tfx_set_option("attention_waves", 0): back to the library's default kernel (30 = attn_w4_kernel)
 BF16 = torch.bfloat16
 
 
