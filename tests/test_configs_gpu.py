@@ -4,6 +4,7 @@
   C3  ML1024  2048 x 1024 (S = 8192, N = 8704)   batch 8, Euler      (N = 8704 attention, M = 69 632 GEMM rows)
   C4  SL1024  1184 x 1024 (S = 4736, N = 5248)   batch 4, AMO sampler c = 2, rank-128 LoRA merged at load
   C5  P1024   1024 x 1024 (S = 4096, N = 4608)   batch 8, fp8 (e4m3) block linears, hipGraph-captured step (50 steps)
+  HL  P1024   1024 x 1024 (S = 4096, N = 4608)   batch 8, Euler, bf16: the headline geometry of bench.py
 
 The model is the FLUX.1-Fill architecture at its real width (D = 3072, 24 heads, T5 width 4096, CLIP width 768, T = 512)
 with the depth cut to 1 double + 2 single blocks so that the fp32 CPU oracle finishes in seconds; every kernel runs at the
@@ -156,6 +157,13 @@ def test_c2_sl512_whole_30_step_trajectory(weights):
 
 def test_c3_ml1024_2048x1024_batch8(weights):
     run_config(weights, weights, 2048, 1024, 8, "euler")
+
+
+def test_headline_p1024_1024x1024_batch8_bf16(weights):
+    """The geometry bench.py's headline is quoted on -- P1024: 1024 x 1024 (S = 4096, N = 4608), batch 8, 30 Euler steps -- in bf16
+    through the oracle (round 3 only had it kernel by kernel and as the fp8 configuration C5): per-step latent MAE <= 1e-3 over the
+    first three steps, batch consistency, hipGraph replay == eager over the whole 30-step schedule."""
+    run_config(weights, weights, 1024, 1024, 8, "euler")
 
 
 def test_c4_sl1024_amo_lora_batch4(weights):

@@ -230,3 +230,45 @@ def test_pil_resample_tables_reproduce_pillow_bicubic():
         if ho != h:
             x = one_pass(x, *pil_resample_tables(h, ho), axis=0)
         assert np.array_equal(x, np.array(Image.fromarray(a).resize((wo, ho))))
+
+
+def test_fill_polygon_slanted_and_concave_properties():
+    """glyph.fill_polygon (reference: cv2.fillPoly, scripts/run_eval.py:92-96) on slanted and concave polygons: the properties
+    OpenCV's rasteriser and this one share -- vertices white, every pixel whose centre is strictly inside white, every pixel
+    further than one pixel from the polygon black, all three channels equal."""
+    import numpy as np
+    from textflux_amd import glyph
+
+    def inside(px, py, poly):        # even-odd rule, point strictly inside
+        n, c = len(poly), False
+        for i in range(n):
+            (x0, y0), (x1, y1) = poly[i], poly[(i + 1) % n]
+            if (y0 > py) != (y1 > py) and px < (x1 - x0) * (py - y0) / (y1 - y0) + x0:
+                c = not c
+        return c
+
+    def dist_to_poly(px, py, poly):
+        best = 1e9
+        for i in range(len(poly)):
+            (x0, y0), (x1, y1) = poly[i], poly[(i + 1) % len(poly)]
+            dx, dy = x1 - x0, y1 - y0
+            t = 0.0 if dx == dy == 0 else max(0.0, min(1.0, ((px - x0) * dx + (py - y0) * dy) / (dx * dx + dy * dy)))
+            best = min(best, ((px - x0 - t * dx) ** 2 + (py - y0 - t * dy) ** 2) ** 0.5)
+        return best
+
+    polys = [[[10, 5], [90, 20], [70, 60], [15, 45]],                         # slanted convex quadrilateral
+             [[5, 5], [95, 8], [50, 30], [92, 62], [8, 58], [30, 30]],         # concave (two notches)
+             [[20.9, 10.2], [80.7, 15.9], [60.1, 55.5]]]                       # float vertices truncate like np.int32
+    for poly in polys:
+        m = glyph.fill_polygon(70, 100, poly)
+        assert m.shape == (70, 100, 3) and m.dtype == np.uint8 and set(np.unique(m)) <= {0, 255}
+        assert (m[..., 0] == m[..., 1]).all() and (m[..., 0] == m[..., 2]).all()
+        ip = [(int(x), int(y)) for x, y in poly]
+        for x, y in ip:
+            assert m[y, x, 0] == 255
+        for y in range(70):
+            for x in range(100):
+                if inside(x, y, ip) and dist_to_poly(x, y, ip) > 0.75:
+                    assert m[y, x, 0] == 255, (x, y)
+                if not inside(x, y, ip) and dist_to_poly(x, y, ip) > 1.0:
+                    assert m[y, x, 0] == 0, (x, y)

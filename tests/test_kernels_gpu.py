@@ -219,7 +219,7 @@ def test_attention(ops, B, H, N):
     close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
-@pytest.mark.parametrize("nw", [8, 10, 20, 30, 40])
+@pytest.mark.parametrize("nw", [8, 10, 20, 30, 31, 32, 33, 40])
 def test_attention_waves_variants(ops, nw):
     """The other kernels of the product library (8: exact online maximum, 10: matrix-pipe softmax with 8 waves x 32 rows, 20:
     half-tile software-pipelined) compute the same thing as the default (30: one wave per SIMD, 64 rows per wave).  The
@@ -236,10 +236,11 @@ def test_attention_waves_variants(ops, nw):
     close(got, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
-@pytest.mark.parametrize("nw", [30, 40])
+@pytest.mark.parametrize("nw", [30, 31, 32, 33, 40])
 @pytest.mark.parametrize("B,H,N", [(1, 1, 1), (2, 3, 8), (1, 2, 33), (1, 1, 64), (1, 1, 65), (2, 2, 96), (1, 3, 300), (2, 2, 1664), (1, 24, 520)])
 def test_attention_one_wave_per_simd_kernels_shape_sweep(ops, nw, B, H, N):
-    """Both one-wave-per-SIMD kernels (30: 32 x 32 x 16 MFMA, 40: 16 x 16 x 32 MFMA) over the ragged / tiny-N sweep, whichever
+    """The one-wave-per-SIMD kernels (30 / 31 / 32: 32 x 32 x 16 MFMA with the softmax bookkeeping on the matrix pipe / the row sums
+    on the VALU / + the reference offset only when a row has one; 40: 16 x 16 x 32 MFMA) over the ragged / tiny-N sweep, whichever
     of them is the default."""
     q, k, v = (rnd((B, N, H * 128), s).to(BF) for s in (20, 21, 22))
     qh, kh, vh = (t.float().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
@@ -286,7 +287,7 @@ def test_attention_unaligned_output_rows_take_the_fallback_kernel(ops):
     assert (buf[:, :, H * 128:] == 0).all()
 
 
-@pytest.mark.parametrize("nw", [8, 10, 20, 30, 40])
+@pytest.mark.parametrize("nw", [8, 10, 20, 30, 31, 32, 33, 40])
 def test_attention_reference_maximum_paths_vs_fp64(ops, nw):
     """Inputs that drive every path of the (lazy) reference-maximum logic, against an fp64 softmax: scores that are all
     very negative (first tile must pin the reference to the true maximum: no underflow of the row sum), a maximum that
@@ -306,8 +307,22 @@ def test_attention_reference_maximum_paths_vs_fp64(ops, nw):
     k_spike[0, 900, :128] = q[0, 17, :128] * 6.0
     k_spike[1, 1100, 128:] = q[1, 300, 128:] * 9.0
     ramp = (torch.arange(N).view(1, N, 1) / N * 6).to(BF).expand(B, N, H * 128).contiguous()
+    # option 32 keeps a row's reference at 0 while its scores stay inside +-64 (exp2 domain) and issues the reference MFMA only
+    # while some row of the wave has one: "far negative" (every score around -110: the first tile must pin), "wide" (row maxima on
+    # both sides of 64 inside one wave: pinned and unpinned rows side by side from the first tile on; planted keys rather than scaled
+    # queries: at |score| ~ 100 the one extra bf16 rounding of the pre-scaled q -- common to every kernel but the textbook one -- moves
+    # near-tied weights by more than the bound, which is a property of the scaling, not of the reference logic under test) and "late far spike" (a +150 score in a late tile of
+    # a row whose reference was 0 until then) drive those paths; the other kernels must of course get them right too
+    k_wide = k.clone()                   # sixteen keys of the FIRST tile each aligned with one even query row of the first wave: those rows
+    for j in range(16):                  # see a score around +114 there (their neighbours at most ~ +-30 from the same keys)
+        k_wide[0, j, :128] = q[0, 2 * j, :128] * 7.0
+        k_wide[1, 32 + j, 128:] = q[1, 64 + 2 * j, 128:] * 7.0
+    k_far = k.clone()
+    k_far[0, 1000, :128] = q[0, 40, :128] * 9.0
+    k_far[1, 70, 128:] = q[1, 1200, 128:] * 10.0
     cases = {"very negative": (q.abs() + 0.5, -(k.abs() + 0.5) * 2, v), "growing maximum": (q.abs() + 0.1, ramp, v),
-             "late spikes": (q, k_spike, v), "peaked": (q * 3, k, v)}
+             "late spikes": (q, k_spike, v), "peaked": (q * 3, k, v),
+             "far negative": (q.abs() + 0.5, -(k.abs() + 0.5) * 4, v), "wide": (q, k_wide, v), "late far spike": (q * 0.5, k_far, v)}
     ops.set_option("attention_waves", nw)
     try:
         for name, (qq, kk, vv) in cases.items():

@@ -780,7 +780,7 @@ static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
 void set_attention_waves(int nw) {
   if (nw == 0) { g_attn_waves = 30; return; }
-  g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || nw == 30 || nw == 40) ? nw : 16;
+  g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || (nw >= 30 && nw <= 33) || nw == 40) ? nw : 16;
 }
 
 // The product library carries the default kernel (30: attention_w4.hip; it needs 16-byte aligned output rows and falls back to
@@ -818,19 +818,19 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     if (prof) prof_end(1, st);
     return rc ? rc : check_launch("joint_attention");
   }
-  if ((g_attn_waves == 30 || g_attn_waves == 40) && w4_ok) {
+  if (((g_attn_waves >= 30 && g_attn_waves <= 33) || g_attn_waves == 40) && w4_ok) {
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
-    const int rc = joint_attention_w4(a, st);
+    const int rc = joint_attention_w4(a, st, g_attn_waves >= 30 && g_attn_waves <= 33 ? g_attn_waves - 30 : 0);
     if (prof) prof_end(1, st);
     return rc ? rc : check_launch("joint_attention");
   }
 #ifndef TFX_BENCH
-  if (g_attn_waves != 8 && g_attn_waves != 10 && g_attn_waves != 30 && g_attn_waves != 40)
+  if (g_attn_waves != 8 && g_attn_waves != 10 && !(g_attn_waves >= 30 && g_attn_waves <= 33) && g_attn_waves != 40)
     return fail("attention: kernel variant %d is a bench-only schedule (build with -DTFX_BENCH)", g_attn_waves);
   if (g_attn_abl) return fail("attention: ablations are bench-only (build with -DTFX_BENCH)");
 #endif
-  const int NW = (g_attn_waves == 16 || g_attn_waves == 9 || g_attn_waves == 10 || g_attn_waves == 30 || g_attn_waves == 40) ? 8 : g_attn_waves == 12 ? 4 : g_attn_waves;
+  const int NW = (g_attn_waves == 16 || g_attn_waves == 9 || g_attn_waves == 10 || g_attn_waves >= 30) ? 8 : g_attn_waves == 12 ? 4 : g_attn_waves;
   const int qblk = NW * 32;
   static bool attr_set = false;
   if (!attr_set) {
@@ -895,7 +895,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     attn_kernel<4><<<grid, 256, ATT_LDS, st>>>(ATT_ARGS);
   } else
 #endif
-  if (g_attn_waves == 10 || g_attn_waves == 30)   // matrix-pipe softmax, one 8-wave workgroup per CU (30 lands here when its alignment needs are not met)
+  if (g_attn_waves == 10 || (g_attn_waves >= 30 && g_attn_waves <= 33))   // matrix-pipe softmax, one 8-wave workgroup per CU (30 lands here when its alignment needs are not met)
     attn_mx_kernel<8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS);
   else                               // exact online maximum
     attn_kernel<8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS);

@@ -61,7 +61,8 @@ constexpr int W4_KT = W4_KV * W4_KROW;         // K tile bytes
 constexpr int W4_NBUF = 3;
 constexpr int W4_KBASE = W4_NBUF * W4_VT;      // V tiles first, then K tiles
 constexpr int W4_PROW = 132;                   // floats per row of a tail-split partial: 128 d + row sum + reference maximum + pad
-constexpr float W4_THR = 4.0f;                 // lazy-reference threshold (log2 units), as attn_mx_kernel
+constexpr float W4_THR = 4.0f;                 // lazy-reference threshold (log2 units), as attn_mx_kernel (MODE 0 / 1)
+constexpr float W4_BIG = 64.0f;                // MODE 2: a row's reference stays 0 while its scores stay inside +-W4_BIG
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 template <int V>
@@ -72,7 +73,7 @@ constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
 
 #define W4_GAP() __builtin_amdgcn_sched_barrier(0)
 #ifndef W4_ABL
-#define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier
+#define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier, 64 no staging writes (requests kept), 128 no staging requests (writes kept)
 #endif
 // wait until every issued MFMA has written its result (there is no counter for the matrix pipe): 24 x 16 idle issue slots,
 // used twice per workgroup (before the first softmax, before the output)
@@ -130,18 +131,35 @@ __device__ __forceinline__ float w4_max(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// l += p.lo + p.hi (the two bf16 weights of a packed register, times 1.0 each), fp32 accumulate
+__device__ __forceinline__ void w4_dot2c(float& l, uint32_t p) {
+  asm volatile("v_dot2c_f32_bf16 %0, 0x3f803f80, %1" : "+v"(l) : "v"(p));
+}
 __device__ __forceinline__ uint32_t w4_cvt_pk(float lo, float hi) {
   uint32_t r;
   asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
 
+// MODE 0: the round-2 bookkeeping (row sums and the reference offset on the matrix pipe: 76 MFMAs per 64-key tile, 64 of them
+// Q.K^T / P.V).  MODE 1: the row sums leave the matrix pipe -- with the swapped Q.K^T a query row is lane-local, so l += sum p is
+// eight v_dot2c_f32_bf16 (p0 * 1 + p1 * 1 + l: exactly the bf16 weights P.V multiplies) per unit, issued one step later in the
+// MFMA shadow of the step's first regions; per-lane partial sums (each lane holds 16 of a unit's 32 keys), the two halves of a
+// row meet once, at the end: 68 MFMAs per tile.  MODE 2: as 1, and the reference offset (one MFMA per unit whose only job is
+// to subtract m_ref) is issued only while some row of the wave HAS a non-zero reference: the reference stays 0 as long as a row's
+// scores stay inside +-W4_BIG (exp2 domain; softmax does not depend on the reference, and fp32 / bf16 share an exponent range
+// that holds 2^+-64 weights and their sums over 2^13 keys with room to spare), is pinned to the row maximum by the first tile
+// only when that lies outside, and moves later only when a row's maximum exceeds it by more than W4_BIG: 64 MFMAs per tile on
+// ordinary data, the MODE-1 stream otherwise (a wave-uniform, not-taken branch in front of the chain).  MODE 3: MODE 0's stream
+// (row sums on the matrix pipe) with MODE 2's lazy reference offset: 72 MFMAs per tile, no VALU instruction more than MODE 0.
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
                                                          const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq, int64_t ldk,
                                                          int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
                                                          int64_t o_bs, int H, int N, int nqb, float scale_log2e, int nfull,
                                                          int nparts, int nsplit, int xsplit, float* part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool LV = MODE == 1 || MODE == 2, LZ = MODE >= 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
@@ -305,6 +323,8 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   if (hi == 0) kone[0] = (__bf16)1.0f;
   asm volatile("" : "+a"(kone), "+a"(vone));   // constants of the bookkeeping MFMAs: AccVGPR residents, not re-materialised
   float m_ref[2] = {0.f, 0.f};   // bf16-exact lazy reference maximum per q-block row (exp2 domain); -m_ref sits in qm[.][0]
+  float lsum[2] = {0.f, 0.f};    // LV: this lane's share (16 of every 32 keys) of the row sums; the halves meet at the end
+  bool any_ref = false;          // LZ: some row of this wave has a non-zero reference (wave-uniform): the offset MFMA is needed
 
 #ifdef W4_DEBUG_CLEAR_LDS
   for (int i = tid * 16; i < ATT_LDS_W4; i += 256 * 16) *reinterpret_cast<u32x4*>(smem + i) = u32x4{0, 0, 0, 0};
@@ -341,9 +361,15 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
 #pragma unroll
   for (int s = 0; s < 8; ++s) kf[s] = kread(0, s);
   W4_GAP();
-  w4_mfma_s0(sc[0], kone, qm[0]);                 // reference 0: a zero product, starts the accumulate chain
+  if constexpr (LZ) {
+    w4_mfma_s0(sc[0], kf[0], qf[0][0]);           // every reference is 0 at the start: the chain starts from a zero C operand
 #pragma unroll
-  for (int s = 0; s < 8; ++s) w4_mfma_s(sc[0], kf[s], qf[0][s]);
+    for (int s = 1; s < 8; ++s) w4_mfma_s(sc[0], kf[s], qf[0][s]);
+  } else {
+    w4_mfma_s0(sc[0], kone, qm[0]);               // reference 0: a zero product, starts the accumulate chain
+#pragma unroll
+    for (int s = 0; s < 8; ++s) w4_mfma_s(sc[0], kf[s], qf[0][s]);
+  }
   // the only place a score is read right after its chain's last MFMA.  MFMAs are issued ahead of their execution (a
   // dependent chain queues up), so the wait covers the whole chain: 9 x 32 cycles
   W4_DRAIN_MFMA();
@@ -362,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     constexpr int KN = decltype(KNc)::value, VN = decltype(VNc)::value, STG = decltype(STGc)::value;
     f32x16& cur = sc[QB];
     f32x16& nxt = sc[OQ];
-    if (__builtin_expect(rag, 0)) {
+    if (__builtin_expect_with_probability(rag, 0, 1.0)) {
       int kbase = kb_abs + 4 * hi;
       asm volatile("" : "+v"(kbase));     // keep the index arithmetic inside the (last-tile-only) branch
 #pragma unroll
@@ -374,11 +400,33 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       constexpr int i = decltype(Ic)::value;
       if constexpr (i == 0) {
         w4_mfma_s0(nxt, kone, qm[OQ]);
+      } else if constexpr (i == 1 && LZ) {
+        // the chain starts here; the reference offset joins it (one more MFMA, out of line) only while some row of this wave has one
+        w4_mfma_s0(nxt, kf[0], qf[OQ][0]);
+        if (__builtin_expect_with_probability(any_ref, 0, 1.0)) w4_mfma_s(nxt, kone, qm[OQ]);
       } else {
         w4_mfma_s(nxt, kf[i - 1], qf[OQ][i - 1]);
         // reloaded two MFMAs after its last reader: spreads the LDS reads over the regions
         if constexpr (EVEN && i >= 2 && !(W4_ABL & 2)) kf[i - 2] = kread(KN, i - 2);
       }
+    };
+    // LV: eight P.V MFMAs (ks = i / 4, d block i % 4), no row-sum MFMA; each V fragment is reloaded one MFMA after its use, the last
+    // one and kf[7] by RL() behind the step's last MFMA
+    auto PL = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value, ks = i / 4, db = i % 4;
+      if constexpr (PV) w4_mfma_o(o[OQ][db], vf[ks][db], pf[OQ][ks]);
+      if constexpr (EVEN && i >= 1 && !(W4_ABL & 2)) vf[(i - 1) / 4][(i - 1) % 4] = vread(VN, (i - 1) / 4, (i - 1) % 4);
+    };
+    auto RL = [&]() __attribute__((always_inline)) {
+      if constexpr (EVEN && !(W4_ABL & 2)) {
+        vf[1][3] = vread(VN, 1, 3);
+        kf[7] = kread(KN, 7);
+      }
+    };
+    // LV: row sums of the PENDING unit (other q-block, weights pf[OQ] finished last step) -- one v_dot2c_f32_bf16 per packed pair
+    auto DL = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int c = decltype(Ic)::value;
+      if constexpr (PV && !(W4_ABL & 1)) w4_dot2c(lsum[OQ], pf[OQ][c >> 2][c & 3]);
     };
     auto P = [&](auto Ic) __attribute__((always_inline)) {
       constexpr int i = decltype(Ic)::value, ks = i / 5, db = i % 5;
@@ -398,12 +446,14 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     auto F = [&](auto Ic) __attribute__((always_inline)) {
       constexpr int k = decltype(Ic)::value;
       if constexpr (W4_ABL & 1) return;
-      constexpr bool is_c = (k == 23) || (k >= 3 && k < 22 && k % 3 == 0);
+      // LV modes end  e13 e14 e15 c6 c7  (no MFMA region separates the last pack from its exponentials there)
+      constexpr bool is_c = LV ? (k >= 22 || (k >= 3 && k <= 18 && k % 3 == 0)) : ((k == 23) || (k >= 3 && k < 22 && k % 3 == 0));
       if constexpr (is_c) {
-        constexpr int c = k == 23 ? 7 : k / 3 - 1;
+        constexpr int c = LV ? (k >= 22 ? k - 16 : k / 3 - 1) : (k == 23 ? 7 : k / 3 - 1);
         pf[QB][c >> 2][c & 3] = w4_cvt_pk(cur[2 * c], cur[2 * c + 1]);
       } else {
-        constexpr int e = k < 3 ? k : k == 22 ? 15 : k - (k / 3);      // exponentials seen so far = index minus packs before it
+        constexpr int e = LV ? (k < 3 ? k : k >= 19 ? k - 6 : k - (k / 3))
+                             : (k < 3 ? k : k == 22 ? 15 : k - (k / 3));      // exponentials seen so far = index minus packs before it
         cur[e] = __builtin_amdgcn_exp2f(cur[e]);
       }
     };
@@ -416,8 +466,8 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       if constexpr ((STG & 3) == 1 && !(W4_ABL & 4)) {
         constexpr bool is_w = n == 0 || n == 1 || (n < 15 && (n & 1));   // W0 W1 | L0 W2 L1 W3 ... L5 W7 | L6 L7
         constexpr int g = n < 2 ? n : is_w ? (n + 1) / 2 : n == 15 ? 7 : n / 2 - 1;
-        if constexpr (is_w) write_piece(STG >> 2, IC<g / 2>{}, (g & 1) == 0);
-        else load_piece(jst, stg_ko, stg_vo, IC<g / 2>{}, (g & 1) == 0);
+        if constexpr (is_w) { if constexpr (!(W4_ABL & 64)) write_piece(STG >> 2, IC<g / 2>{}, (g & 1) == 0); }
+        else { if constexpr (!(W4_ABL & 128)) load_piece(jst, stg_ko, stg_vo, IC<g / 2>{}, (g & 1) == 0); }
       }
     };
     // One MFMA per scheduling region, each with <= ~24 issue cycles of other work behind it (an MFMA that finds the pipe busy
@@ -426,45 +476,69 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     // and the first of the next before anything reads the scores -- an MFMA result needs ~11 issued instructions before a
     // VALU read, and hipcc cannot insert that wait in front of the inline-asm maxima (it does not know they are VALU).
     float mx = 0.f;
+    // the four pieces of the row maximum (VALU, inline asm) and the rare reference move, shared by the three region lists below
+    auto MX = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(Ic)::value;
+      if constexpr (W4_ABL & 8) return;
+      if constexpr (i == 0) mx = w4_max7(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6]);
+      if constexpr (i == 1) mx = w4_max7(mx, cur[7], cur[8], cur[9], cur[10], cur[11], cur[12]);
+      if constexpr (i == 2) mx = w4_max4(mx, cur[13], cur[14], cur[15]);
+      if constexpr (i == 3) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = w4_max(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // both 32-key halves of the row
+      }
+    };
+    auto MOVE = [&]() __attribute__((always_inline)) {
+      // out of line: with one wave per SIMD nothing hides the instruction-fetch bubble of a TAKEN branch, so the common
+      // path must be the fall-through
+      bool take;
+      if constexpr (LZ) take = !(W4_ABL & 8) && !__all(FIRST ? fabsf(mx) <= W4_BIG : mx <= W4_BIG);
+      else take = FIRST || (!(W4_ABL & 8) && !__all(mx <= W4_THR));
+      if (__builtin_expect_with_probability(take, FIRST && !LZ, 1.0)) {
+        // move the reference: everything q-block QB accumulated against the old one is rescaled exactly once (no MFMA on
+        // o[QB] / ol[QB] is in this step's stream), the scores of this unit are shifted before they are exponentiated
+        float m_new;
+        if constexpr (LZ) {   // only the rows that need it: a first tile's maximum outside +-W4_BIG pins, a later excess beyond W4_BIG moves
+          const bool mv = FIRST ? fabsf(mx) > W4_BIG : mx > W4_BIG;
+          m_new = mv ? round_bf(m_ref[QB] + mx) : m_ref[QB];
+        } else {
+          m_new = round_bf(m_ref[QB] + (FIRST ? mx : fmaxf(mx, 0.f)));
+        }
+        const float d = m_new - m_ref[QB];
+        m_ref[QB] = m_new;
+        qm[QB][0] = (__bf16)(hi == 0 ? -m_new : 0.f);
+        if constexpr (LZ) any_ref = __any(m_ref[0] != 0.f || m_ref[1] != 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cur[r] -= d;
+        if constexpr (!FIRST) {
+          const float f = __builtin_amdgcn_exp2f(-d);
+          if constexpr (LV) lsum[QB] *= f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (!LV) ol[QB][r] *= f;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[QB][db][r] *= f;
+          }
+        }
+      }
+    };
+    if constexpr (MODE == 0) {
     S(IC<0>{});
     W4_TOUCH(cur);
-    if constexpr (!(W4_ABL & 8)) mx = w4_max7(cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6]);
+    MX(IC<0>{});
     W4_GAP();
     S(IC<1>{});
-    if constexpr (!(W4_ABL & 8)) mx = w4_max7(mx, cur[7], cur[8], cur[9], cur[10], cur[11], cur[12]);
+    MX(IC<1>{});
     W4_GAP();
     P(IC<0>{});
-    if constexpr (!(W4_ABL & 8)) mx = w4_max4(mx, cur[13], cur[14], cur[15]);
+    MX(IC<2>{});
     W4_GAP();
     S(IC<2>{});
-    if constexpr (!(W4_ABL & 8)) {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = w4_max(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // both 32-key halves of the row
-    }
+    MX(IC<3>{});
     W4_GAP();
     P(IC<1>{});
     W4_GAP();
-    // out of line: with one wave per SIMD nothing hides the instruction-fetch bubble of a TAKEN branch, so the common
-    // path must be the fall-through
-    if (FIRST || (!(W4_ABL & 8) && __builtin_expect(!__all(mx <= W4_THR), 0))) {
-      // move the reference: everything q-block QB accumulated against the old one is rescaled exactly once (no MFMA on
-      // o[QB] / ol[QB] is in this step's stream), the scores of this unit are shifted before they are exponentiated
-      const float m_new = round_bf(m_ref[QB] + (FIRST ? mx : fmaxf(mx, 0.f)));
-      const float d = m_new - m_ref[QB];
-      m_ref[QB] = m_new;
-      qm[QB][0] = (__bf16)(hi == 0 ? -m_new : 0.f);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cur[r] -= d;
-      if constexpr (!FIRST) {
-        const float f = __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          ol[QB][r] *= f;
-#pragma unroll
-          for (int db = 0; db < 4; ++db) o[QB][db][r] *= f;
-        }
-      }
-    }
+    MOVE();
     W4_GAP();
     S(IC<3>{}); F(IC<0>{}); F(IC<1>{}); G(IC<0>{});
     W4_GAP();
@@ -499,6 +573,136 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     W4_GAP();
     F(IC<23>{});
     W4_GAP();
+    } else if constexpr (MODE == 1) {
+    // 17 MFMAs: S0..S8 interleaved with the eight P.V; the pending unit's row sums (DL) ride behind the first five, the staging
+    // stream (G, one step in four) one piece per region
+    S(IC<0>{}); W4_TOUCH(cur); MX(IC<0>{}); G(IC<0>{});
+    W4_GAP();
+    S(IC<1>{}); MX(IC<1>{}); DL(IC<0>{}); G(IC<1>{});
+    W4_GAP();
+    PL(IC<0>{}); MX(IC<2>{}); DL(IC<1>{}); DL(IC<2>{}); G(IC<2>{});
+    W4_GAP();
+    S(IC<2>{}); MX(IC<3>{}); DL(IC<3>{}); DL(IC<4>{}); G(IC<3>{});
+    W4_GAP();
+    PL(IC<1>{}); DL(IC<5>{}); DL(IC<6>{}); DL(IC<7>{}); G(IC<4>{});
+    W4_GAP();
+    MOVE();
+    W4_GAP();
+    S(IC<3>{}); F(IC<0>{}); F(IC<1>{}); G(IC<5>{});
+    W4_GAP();
+    PL(IC<2>{}); F(IC<2>{}); F(IC<3>{}); G(IC<6>{});
+    W4_GAP();
+    S(IC<4>{}); F(IC<4>{}); F(IC<5>{}); G(IC<7>{});
+    W4_GAP();
+    PL(IC<3>{}); F(IC<6>{}); F(IC<7>{}); G(IC<8>{});
+    W4_GAP();
+    S(IC<5>{}); F(IC<8>{}); F(IC<9>{}); G(IC<9>{});
+    W4_GAP();
+    PL(IC<4>{}); F(IC<10>{}); F(IC<11>{}); G(IC<10>{});
+    W4_GAP();
+    S(IC<6>{}); F(IC<12>{}); F(IC<13>{}); G(IC<11>{});
+    W4_GAP();
+    PL(IC<5>{}); F(IC<14>{}); F(IC<15>{}); G(IC<12>{});
+    W4_GAP();
+    S(IC<7>{}); F(IC<16>{}); F(IC<17>{}); G(IC<13>{});
+    W4_GAP();
+    PL(IC<6>{}); F(IC<18>{}); F(IC<19>{}); G(IC<14>{});
+    W4_GAP();
+    S(IC<8>{}); F(IC<20>{}); F(IC<21>{}); G(IC<15>{});
+#ifdef W4_HAZARD_SELFTEST
+    { const float t_ = w4_max(nxt[0], nxt[1]); asm volatile("" ::"v"(t_)); }
+#endif
+    W4_GAP();
+    PL(IC<7>{}); F(IC<22>{}); RL(); F(IC<23>{});
+    W4_GAP();
+    } else if constexpr (MODE == 3) {
+    // MODE 0's stream without the reference-offset MFMA (it joins S(1), out of line, only while a row of the wave has a reference):
+    // 18 MFMAs, the VALU stream unchanged
+    S(IC<1>{}); W4_TOUCH(cur); MX(IC<0>{});
+    W4_GAP();
+    P(IC<0>{}); MX(IC<1>{});
+    W4_GAP();
+    S(IC<2>{}); MX(IC<2>{});
+    W4_GAP();
+    P(IC<1>{}); MX(IC<3>{});
+    W4_GAP();
+    MOVE();
+    W4_GAP();
+    S(IC<3>{}); F(IC<0>{}); F(IC<1>{}); G(IC<0>{});
+    W4_GAP();
+    P(IC<2>{}); F(IC<2>{}); F(IC<3>{}); G(IC<1>{});
+    W4_GAP();
+    S(IC<4>{}); F(IC<4>{}); F(IC<5>{}); G(IC<2>{});
+    W4_GAP();
+    P(IC<3>{}); F(IC<6>{}); F(IC<7>{}); G(IC<3>{});
+    W4_GAP();
+    S(IC<5>{}); F(IC<8>{}); F(IC<9>{}); G(IC<4>{});
+    W4_GAP();
+    P(IC<4>{}); F(IC<10>{}); F(IC<11>{}); G(IC<5>{});
+    W4_GAP();
+    S(IC<6>{}); F(IC<12>{}); F(IC<13>{}); G(IC<6>{});
+    W4_GAP();
+    P(IC<5>{}); F(IC<14>{}); F(IC<15>{}); G(IC<7>{});
+    W4_GAP();
+    S(IC<7>{}); F(IC<16>{}); F(IC<17>{}); G(IC<8>{});
+    W4_GAP();
+    P(IC<6>{}); F(IC<18>{}); F(IC<19>{}); G(IC<9>{});
+    W4_GAP();
+    S(IC<8>{}); F(IC<20>{}); F(IC<21>{}); G(IC<10>{});
+#ifdef W4_HAZARD_SELFTEST
+    { const float t_ = w4_max(nxt[0], nxt[1]); asm volatile("" ::"v"(t_)); }
+#endif
+    W4_GAP();
+    P(IC<7>{}); F(IC<22>{}); G(IC<11>{});
+    W4_GAP();
+    P(IC<8>{}); G(IC<12>{}); G(IC<13>{});
+    W4_GAP();
+    P(IC<9>{}); G(IC<14>{}); G(IC<15>{});
+    W4_GAP();
+    F(IC<23>{});
+    W4_GAP();
+    } else {
+    // 16 MFMAs on ordinary data (S(1) starts the chain; the reference offset joins it, out of line, only while a row has one)
+    S(IC<1>{}); W4_TOUCH(cur); MX(IC<0>{}); G(IC<0>{});
+    W4_GAP();
+    PL(IC<0>{}); MX(IC<1>{}); DL(IC<0>{}); G(IC<1>{});
+    W4_GAP();
+    S(IC<2>{}); MX(IC<2>{}); DL(IC<1>{}); DL(IC<2>{}); G(IC<2>{});
+    W4_GAP();
+    PL(IC<1>{}); MX(IC<3>{}); DL(IC<3>{}); DL(IC<4>{}); G(IC<3>{});
+    W4_GAP();
+    S(IC<3>{}); DL(IC<5>{}); DL(IC<6>{}); DL(IC<7>{}); G(IC<4>{});
+    W4_GAP();
+    MOVE();
+    W4_GAP();
+    PL(IC<2>{}); F(IC<0>{}); F(IC<1>{}); G(IC<5>{});
+    W4_GAP();
+    S(IC<4>{}); F(IC<2>{}); F(IC<3>{}); G(IC<6>{});
+    W4_GAP();
+    PL(IC<3>{}); F(IC<4>{}); F(IC<5>{}); G(IC<7>{});
+    W4_GAP();
+    S(IC<5>{}); F(IC<6>{}); F(IC<7>{}); G(IC<8>{});
+    W4_GAP();
+    PL(IC<4>{}); F(IC<8>{}); F(IC<9>{}); G(IC<9>{});
+    W4_GAP();
+    S(IC<6>{}); F(IC<10>{}); F(IC<11>{}); G(IC<10>{});
+    W4_GAP();
+    PL(IC<5>{}); F(IC<12>{}); F(IC<13>{}); G(IC<11>{});
+    W4_GAP();
+    S(IC<7>{}); F(IC<14>{}); F(IC<15>{}); G(IC<12>{});
+    W4_GAP();
+    PL(IC<6>{}); F(IC<16>{}); F(IC<17>{}); G(IC<13>{});
+    W4_GAP();
+    S(IC<8>{}); F(IC<18>{}); F(IC<19>{}); G(IC<14>{});
+#ifdef W4_HAZARD_SELFTEST
+    { const float t_ = w4_max(nxt[0], nxt[1]); asm volatile("" ::"v"(t_)); }
+#endif
+    W4_GAP();
+    PL(IC<7>{}); F(IC<20>{}); F(IC<21>{}); G(IC<15>{}); RL();
+    W4_GAP();
+    F(IC<22>{}); F(IC<23>{});
+    W4_GAP();
+    }
   };
 
   // one 64-key tile j out of ring buffer B (compile-time: every fragment address is a per-lane base plus an immediate)
@@ -533,9 +737,20 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) w4_mfma_o(o[1][db], vf[ks][db], pf[1][ks]);
-    w4_mfma_l(ol[1], vone, pf[1][ks]);
+    if constexpr (!LV) w4_mfma_l(ol[1], vone, pf[1][ks]);
+  }
+  float ltot[2];                                 // full row sums (LV: the two 16-key halves of every unit live in lanes l and l ^ 32)
+  if constexpr (LV) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w4_dot2c(lsum[1], pf[1][c >> 2][c & 3]);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) ltot[qb] = lsum[qb] + __shfl_xor(lsum[qb], 32, 64);
   }
   W4_DRAIN_MFMA();                               // the last MFMA results before the VALU reads them
+  if constexpr (!LV) {
+    ltot[0] = ol[0][0];                          // every row of the ones-block holds the full row sum
+    ltot[1] = ol[1][0];
+  }
 
   // ---- tail split: un-normalised O (fp32), row sum and reference maximum of this key range -> part [tile][range][row][132]
   if (kpart >= 0) {
@@ -550,13 +765,13 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
           *reinterpret_cast<f32x4*>(pr + db * 32 + qd * 8 + hi * 4) =
               f32x4{o[qb][db][qd * 4 + 0], o[qb][db][qd * 4 + 1], o[qb][db][qd * 4 + 2], o[qb][db][qd * 4 + 3]};
       if (hi == 0) {
-        pr[128] = ol[qb][0];
+        pr[128] = ltot[qb];
         pr[129] = m_ref[qb];
       }
     }
     return;
   }
-  // ---- finish: every row of the ones-block holds the full row sum.  The normalised bf16 rows go through a wave-private LDS
+  // ---- finish.  The normalised bf16 rows go through a wave-private LDS
   // tile (the K / V ring is free: every wave's last fragment read lies before the last barrier) and leave as whole 256-byte
   // rows, 16 lanes x 16 bytes each (row-per-lane 8-byte stores touch 32 lines per instruction and queue up at the end of
   // the block, when every wave of the workgroup stores at once)
@@ -564,7 +779,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   char* ot = smem + wave * (64 * OROW);
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    const float inv = 1.0f / ol[qb][0];
+    const float inv = 1.0f / ltot[qb];
     char* orow = ot + (qb * 32 + l31) * OROW + 8 * hi;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -653,20 +868,30 @@ int attention_w4_prepare(hipStream_t st) {
   return w4_scratch(st, true) ? 0 : fail("attention: cannot allocate the tail-split scratch");
 }
 
-int joint_attention_w4(const AttnArgs& a, hipStream_t st) {
+template <int MODE>
+static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, int nfull, int nparts, int nsplit, int xsplit, float* part) {
   static bool attr_set = false;
+  const void* fn = (const void*)attn_w4_kernel<MODE>;
   if (!attr_set) {
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, (const void*)attn_w4_kernel) != hipSuccess) return fail("attention: no attn_w4_kernel in this build");
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return fail("attention: no attn_w4_kernel<%d> in this build", MODE);
     (void)hipGetLastError();
     // built without -mllvm -amdgpu-mfma-vgpr-form (see Makefile) the accumulators land in the AccVGPRs and ~500 registers spill
     if (fa.localSizeBytes != 0)
-      return fail("attention: attn_w4_kernel spills %zu bytes per lane -- attention_w4.hip must be compiled with "
-                  "-mllvm -amdgpu-mfma-vgpr-form", (size_t)fa.localSizeBytes);
-    if (hipFuncSetAttribute((const void*)attn_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_W4) != hipSuccess)
+      return fail("attention: attn_w4_kernel<%d> spills %zu bytes per lane -- attention_w4.hip must be compiled with "
+                  "-mllvm -amdgpu-mfma-vgpr-form", MODE, (size_t)fa.localSizeBytes);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_W4) != hipSuccess)
       return fail("attention: cannot raise dynamic LDS limit to %d bytes", ATT_LDS_W4);
     attr_set = true;
   }
+  attn_w4_kernel<MODE><<<grid, 256, ATT_LDS_W4, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
+                                                       a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
+                                                       a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, part);
+  return 0;
+}
+
+// mode: 0 .. 3 = attn_w4_kernel<MODE> (tfx_set_option attention_waves 30 .. 33)
+int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode) {
   const int nqb = (a.N + 255) / 256;
   const int T = a.B * a.H * nqb;
   // Tail split: T workgroups of equal length on C CUs take ceil(T / C) rounds, and when the last one is partly filled the chip
@@ -692,9 +917,11 @@ int joint_attention_w4(const AttnArgs& a, hipStream_t st) {
     }
   }
   const unsigned grid = nsplit > 1 ? (unsigned)(((nfull + 7) & ~7) + nparts) : (unsigned)T;
-  attn_w4_kernel<<<grid, 256, ATT_LDS_W4, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
-                                                 a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
-                                                 a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, part);
+  const int rc = mode == 3 ? w4_launch<3>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
+               : mode == 2 ? w4_launch<2>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
+               : mode == 1 ? w4_launch<1>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
+                           : w4_launch<0>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part);
+  if (rc) return rc;
   if (nsplit > 1)
     attn_w4_merge_kernel<<<(unsigned)(xsplit * a.B * 32), 256, 0, st>>>(part, (bf16_t*)a.o, a.ldo, a.o_bstride, a.H, a.N, nqb,
                                                                               xsplit, nsplit);

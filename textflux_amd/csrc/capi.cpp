@@ -498,8 +498,8 @@ int tfx_set_option(const char* name, int value) {
   if (!name) return fail("tfx_set_option: null name");
   if (!std::strcmp(name, "attention_waves")) {
     if (value == 0) { set_attention_waves(0); return 0; }     // back to the library default and its size heuristic
-    if (value != 4 && value != 8 && value != 9 && value != 10 && value != 12 && value != 16 && value != 20 && value != 30 && value != 40)
-      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves), 16 (ping-pong), 20 (half-tile pipelined), 30 (one wave per SIMD, 32x32x16 MFMA) or 40 (one wave per SIMD, 16x16x32 MFMA)");
+    if (value != 4 && value != 8 && value != 9 && value != 10 && value != 12 && value != 16 && value != 20 && !(value >= 30 && value <= 33) && value != 40)
+      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves), 16 (ping-pong), 20 (half-tile pipelined), 30 .. 33 (one wave per SIMD, 32x32x16 MFMA: bookkeeping on the matrix pipe / row sums on the VALU / + lazy reference offset / 30 + lazy reference offset) or 40 (one wave per SIMD, 16x16x32 MFMA)");
     set_attention_waves(value);
     return 0;
   }

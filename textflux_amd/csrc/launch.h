@@ -86,7 +86,7 @@ int joint_attention_hp(const AttnArgs& a, hipStream_t st);   // half-tile softwa
 int joint_attention_w16(const AttnArgs& a, hipStream_t st);  // one wave per SIMD on v_mfma_f32_16x16x32_bf16 (attention_w16.hip)
 int attention_w4_prepare(hipStream_t st);                      // allocates the tail-split scratch of `st` (call outside stream capture)
 void set_attention_tail_split(int v);                          // 0 = never split the last round's q-tiles by keys (bench knob)
-int joint_attention_w4(const AttnArgs& a, hipStream_t st);   // one wave per SIMD, 64 query rows per wave (attention_w4.hip)
+int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode);   // one wave per SIMD, 64 query rows per wave (attention_w4.hip); mode: 0 bookkeeping on the matrix pipe, 1 row sums on the VALU, 2 + lazy reference offset
 void set_attention_ablation(int a);
 void set_attention_debug(void* p);
 void set_attention_waves(int nw);  // 8 (one 512-thread workgroup per CU) or 4 (two independent 256-thread workgroups)

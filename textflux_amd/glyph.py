@@ -71,9 +71,13 @@ def draw_glyph(font, text: str, width: int, height: int, max_font_size: int = 14
 def fill_polygon(height: int, width: int, polygon) -> np.ndarray:
     """uint8 [height, width, 3] mask: the polygon (list of [x, y] vertices, truncated to ints as np.int32 does) filled white on
     black, boundary pixels included -- the reference's cv2.fillPoly(zeros, [polygon], (255, 255, 255)) (scripts/run_eval.py:
-    92-96).  cv2 is absent here; PIL's scan-line polygon fill plus its outline follows the same rule (interior by scan line,
-    edges drawn as lines): identical for the axis-aligned and convex cases of tests/test_host_logic.py, pixel parity on
-    arbitrary slanted edges is unpinned."""
+    92-96).  cv2 is absent here; PIL's scan-line polygon fill plus its outline follows the same rule as OpenCV's FillPoly for
+    non-antialiased lines (every edge drawn as an 8-connected Bresenham line, the interior filled by scan line between the
+    edges).  Pinned: the axis-aligned rectangle and the triangle of tests/test_batch_driver_cpu.py::
+    test_eval_schema_items_follow_the_reference_rule (exact pixel counts), and for slanted / concave polygons the properties both
+    rasterisers share (tests/test_host_logic.py::test_fill_polygon_slanted_and_concave_properties: vertices and edge lines
+    white, every pixel centre strictly inside white, nothing further than one pixel outside).  Pixel-for-pixel parity with cv2
+    on the boundary pixels of slanted edges stays unpinned (no cv2 offline to rasterise goldens with)."""
     pts = [(int(p[0]), int(p[1])) for p in np.asarray(polygon).reshape(-1, 2).tolist()]
     m = Image.new("L", (width, height), 0)
     d = ImageDraw.Draw(m)
