@@ -32,7 +32,7 @@ const char* tfx_last_error(void);
  * sizeof(tfx_dit_desc), sizeof(tfx_step_desc)} (as many as fit in n) and returns how many values there are.  A binding
  * compares them with its own view of this header BEFORE the first call that passes a struct: a library built from an older
  * header would otherwise ignore the tail fields of a grown struct silently (no reference counterpart: the reference has no FFI). */
-#define TFX_ABI_VERSION 4
+#define TFX_ABI_VERSION 5
 int tfx_abi_info(int32_t* out, int n);
 /* Writes the gcnArchName of the current device (e.g. "gfx950:sramecc+:xnack-") into buf.  Needs a GPU. */
 int tfx_query_arch(char* buf, int buflen);
@@ -109,6 +109,12 @@ typedef struct tfx_attn_args {
   int64_t q_bstride, k_bstride, v_bstride, o_bstride;
   int32_t B, H, N;
   float scale;
+  /* optional promise of the caller: |scale * q . k| <= score_bound for every (query, key) pair, 0 = unknown.  Softmax does not
+   * depend on the reference that is subtracted before the exponential; with a bound of at most 41 (2^+-60 in fp32 / bf16, whose
+   * exponent range holds such weights and their sums over 2^13 keys) the kernel subtracts none: no running row maximum, no
+   * rescaling branch.  tfx_dit_forward derives the bound from the q / k RMSNorm weights (after the norm |q| <= sqrt(128) max|w_q|,
+   * RoPE preserves it).  A wrong promise can overflow to inf / NaN; 0 keeps the kernel's own overflow guard. */
+  float score_bound;
 } tfx_attn_args;
 int tfx_joint_attention(const tfx_attn_args* args, tfx_stream stream);
 
@@ -191,6 +197,9 @@ typedef struct tfx_dit_desc {
    * bit-identical to tfx_euler_step on the stored model output -- i.e. the latent state lives IN the x_embedder input, `out` is
    * not written, and there is neither a scheduler launch nor a copy of the new latents into the next step's input. */
   const void* euler_gate; int64_t euler_gate_bstride;
+  /* optional: tfx_attn_args.score_bound for every attention launch of the forward (0 = unknown).  The caller derives it from the
+   * q / k RMSNorm weights of all blocks: 128 * max|w_q| * max|w_k| * 128^-0.5 (text-stream norms included), see tfx_attn_args. */
+  float attn_score_bound;
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
 

@@ -30,10 +30,12 @@ def isa(src, tmp_path, *flags):
 def test_default_attention_kernel_has_no_mfma_result_hazard(tmp_path):
     import check_mfma_hazard as ck
     asm = isa("attention_w4.hip", tmp_path)
-    (name, n, n_mfma, rep), = [k for k in ck.check_all(asm) if "attn_w4_kernel" in k[0]]      # (the file also holds the tail-split merge kernel)
-    assert "attn_w4_kernel" in name and n_mfma > 250 and n > 3000      # the kernel was really parsed
-    assert asm.count("v_readfirstlane_b32") >= 16                       # the compiler-visible touches are in the stream
-    assert rep == [], rep[:5]
+    ks = [k for k in ck.check_all(asm) if "attn_w4_kernel" in k[0]]      # (the file also holds the tail-split merge kernel)
+    assert len(ks) == 5                                                  # attn_w4_kernel<0 .. 4>: every bookkeeping mode is checked
+    for name, n, n_mfma, rep in ks:
+        assert n_mfma > 250 and n > 3000, name                           # the kernel was really parsed
+        assert rep == [], (name, rep[:5])
+    assert asm.count("v_readfirstlane_b32") >= 5 * 16                    # the compiler-visible touches are in the stream
 
 
 def test_attention_w16_kernel_has_no_mfma_or_transcendental_result_hazard(tmp_path):
@@ -51,12 +53,14 @@ def test_checker_catches_a_shortened_distance(tmp_path):
     """The self-test variant reads a score from inline asm right behind its chain's last MFMA, with the touch removed."""
     import check_mfma_hazard as ck
     asm = isa("attention_w4.hip", tmp_path, "-DW4_NO_TOUCH", "-DW4_HAZARD_SELFTEST")
-    (_, _, _, rep), = [k for k in ck.check_all(asm) if "attn_w4_kernel" in k[0]]
-    assert len(rep) >= 4 and all("mfma write" in r for r in rep), rep[:3]
+    reps = [k[3] for k in ck.check_all(asm) if "attn_w4_kernel" in k[0]]
+    assert len(reps) == 5
+    for rep in reps:
+        assert len(rep) >= 4 and all("mfma write" in r for r in rep), rep[:3]
     # ... and the touch alone is what makes the compiler pad: same shortened read, touch in place right behind the MFMA
     padded = isa("attention_w4.hip", tmp_path, "-DW4_HAZARD_SELFTEST")
-    (_, _, _, rep2), = [k for k in ck.check_all(padded) if "attn_w4_kernel" in k[0]]
-    assert len(rep2) == len(rep)          # the unprotected asm read is still flagged (the touch sits in front of the REAL reads only)
+    reps2 = [k[3] for k in ck.check_all(padded) if "attn_w4_kernel" in k[0]]
+    assert len(reps2) == 5 and all(len(r) >= 4 and all("mfma write" in x for x in r) for r in reps2)   # the unprotected asm read is still flagged (the touch sits in front of the REAL reads only)
 
 
 def test_checker_agrees_with_hipcc_on_visible_instructions(tmp_path):

@@ -336,6 +336,43 @@ def test_attention_reference_maximum_paths_vs_fp64(ops, nw):
         ops.set_option("attention_waves", ops.DEFAULT_ATTENTION)
 
 
+def test_attention_score_bound_selects_the_reference_free_stream(ops):
+    """tfx_attn_args.score_bound (the caller's promise |scale q.k| <= bound; the DiT derives it from the q / k RMSNorm weights):
+    with a bound of at most 41 the default kernel runs without any reference maximum (attn_w4_kernel<4>, option 34) -- same
+    softmax, checked against fp32 SDPA; a bound that is too large, or none, leaves the guarded kernel in place (bit-identical
+    to a call without the field); `attention_use_bound 0` switches the shortcut off."""
+    B, H, N = 2, 3, 1500
+    q, k, v = (rnd((B, N, H * 128), s).to(BF) for s in (41, 42, 43))
+    qh, kh, vh = (t.float().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
+    sc = (qh @ kh.transpose(-1, -2)) * 128 ** -0.5
+    bound = sc.abs().max().item() * 1.01
+    assert bound < 41
+    ref = torch.softmax(sc, -1) @ vh
+    ref = ref.transpose(1, 2).reshape(B, N, H * 128)
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    plain = ops.attention(qc, kc, vc)
+    bounded = ops.attention(qc, kc, vc, score_bound=bound)
+    close(bounded, ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+    assert (bounded.float() - plain.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert torch.equal(ops.attention(qc, kc, vc, score_bound=100.0), plain)          # bound too large: the guarded kernel
+    try:
+        ops.set_option("attention_waves", 34)
+        assert torch.equal(ops.attention(qc, kc, vc, score_bound=bound), bounded)    # 34 with a bound = what the default picked
+        close(ops.attention(qc, kc, vc), ref.to(BF), max_rel=2e-2, mae_rel=4e-3)     # 34 without one: lazy-reference kernel (33)
+        ops.set_option("attention_waves", ops.DEFAULT_ATTENTION)
+        ops.set_option("attention_use_bound", 0)
+        assert torch.equal(ops.attention(qc, kc, vc, score_bound=bound), plain)      # shortcut off: the field is ignored
+    finally:
+        ops.set_option("attention_waves", ops.DEFAULT_ATTENTION)
+        ops.set_option("attention_use_bound", 1)
+    # ragged N, tiny N and the first-tile-only case through the reference-free stream
+    for (b, h, n) in [(1, 1, 1), (2, 3, 8), (1, 2, 33), (1, 1, 65), (1, 3, 300)]:
+        q2, k2, v2 = (rnd((b, n, h * 128), s).to(BF) for s in (51, 52, 53))
+        q2h, k2h, v2h = (t.float().view(b, n, h, 128).transpose(1, 2) for t in (q2, k2, v2))
+        r2 = torch.nn.functional.scaled_dot_product_attention(q2h, k2h, v2h).transpose(1, 2).reshape(b, n, h * 128)
+        close(ops.attention(q2.cuda(), k2.cuda(), v2.cuda(), score_bound=30.0), r2.to(BF), max_rel=2e-2, mae_rel=4e-3)
+
+
 def test_attention_online_softmax_rescale_branch(ops):
     """A key far above the rest in a LATE tile forces the running-max rescale of the accumulated output."""
     B, H, N = 1, 1, 256

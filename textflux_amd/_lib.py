@@ -38,7 +38,7 @@ class AttnArgs(C.Structure):
         ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p),
         ("ldq", c_int64), ("ldk", c_int64), ("ldv", c_int64), ("ldo", c_int64),
         ("q_bstride", c_int64), ("k_bstride", c_int64), ("v_bstride", c_int64), ("o_bstride", c_int64),
-        ("B", c_int32), ("H", c_int32), ("N", c_int32), ("scale", c_float),
+        ("B", c_int32), ("H", c_int32), ("N", c_int32), ("scale", c_float), ("score_bound", c_float),
     ]
 
 
@@ -73,6 +73,7 @@ class DitDesc(C.Structure):
         ("gemm_workspace", c_void_p), ("gemm_workspace_bytes", c_int64),
         ("rope_cs", c_void_p),
         ("euler_gate", c_void_p), ("euler_gate_bstride", c_int64),
+        ("attn_score_bound", c_float),
     ]
 
 

@@ -770,6 +770,8 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
 
 #endif  // TFX_BENCH
 
+static int g_attn_bound = 1;   // 0: ignore AttnArgs::score_bound (A/B knob, tfx_set_option attention_use_bound)
+void set_attention_use_bound(int v) { g_attn_bound = v; }
 static int g_attn_waves = 30;  // 30 (default) one wave per SIMD, 64 rows per wave, 32x32x16 MFMA (attention_w4.hip); 10 matrix-pipe softmax, 8 waves x 32 rows; 8 exact-online-max lock-step kernel; 4 / 12 = 4-wave workgroups of 8 / 10; 9 = 128 keys per barrier; 16 = ping-pong
 static unsigned long long* g_attn_dbg = nullptr;  // bench-only phase timing buffer
 void set_attention_debug(void* p) {
@@ -780,7 +782,7 @@ static int g_attn_abl = 0;  // bench-only (tools/bench_kernels.py)
 void set_attention_ablation(int a) { g_attn_abl = a; }
 void set_attention_waves(int nw) {
   if (nw == 0) { g_attn_waves = 30; return; }
-  g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || (nw >= 30 && nw <= 33) || nw == 40) ? nw : 16;
+  g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || (nw >= 30 && nw <= 34) || nw == 40) ? nw : 16;
 }
 
 // The product library carries the default kernel (30: attention_w4.hip; it needs 16-byte aligned output rows and falls back to
@@ -818,15 +820,20 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     if (prof) prof_end(1, st);
     return rc ? rc : check_launch("joint_attention");
   }
-  if (((g_attn_waves >= 30 && g_attn_waves <= 33) || g_attn_waves == 40) && w4_ok) {
+  if (((g_attn_waves >= 30 && g_attn_waves <= 34) || g_attn_waves == 40) && w4_ok) {
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
-    const int rc = joint_attention_w4(a, st, g_attn_waves >= 30 && g_attn_waves <= 33 ? g_attn_waves - 30 : 0);
+    // 30 (the default) takes the reference-free stream (34) when the caller's score bound allows it: 41 natural-log units = 59 in the
+    // exp2 domain, inside W4_BIG with room for the bf16 rounding of the pre-scaled q; an explicit 31 .. 33 runs as named
+    const bool bounded = a.score_bound > 0.f && a.score_bound <= 41.0f;
+    const int mode = g_attn_waves == 34 ? (bounded ? 4 : 3) : g_attn_waves == 30 ? (bounded && g_attn_bound ? 4 : 0)
+                   : g_attn_waves >= 31 && g_attn_waves <= 33 ? g_attn_waves - 30 : 0;
+    const int rc = joint_attention_w4(a, st, mode);
     if (prof) prof_end(1, st);
     return rc ? rc : check_launch("joint_attention");
   }
 #ifndef TFX_BENCH
-  if (g_attn_waves != 8 && g_attn_waves != 10 && !(g_attn_waves >= 30 && g_attn_waves <= 33) && g_attn_waves != 40)
+  if (g_attn_waves != 8 && g_attn_waves != 10 && !(g_attn_waves >= 30 && g_attn_waves <= 34) && g_attn_waves != 40)
     return fail("attention: kernel variant %d is a bench-only schedule (build with -DTFX_BENCH)", g_attn_waves);
   if (g_attn_abl) return fail("attention: ablations are bench-only (build with -DTFX_BENCH)");
 #endif
@@ -895,7 +902,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     attn_kernel<4><<<grid, 256, ATT_LDS, st>>>(ATT_ARGS);
   } else
 #endif
-  if (g_attn_waves == 10 || (g_attn_waves >= 30 && g_attn_waves <= 33))   // matrix-pipe softmax, one 8-wave workgroup per CU (30 lands here when its alignment needs are not met)
+  if (g_attn_waves == 10 || (g_attn_waves >= 30 && g_attn_waves <= 34))   // matrix-pipe softmax, one 8-wave workgroup per CU (30 lands here when its alignment needs are not met)
     attn_mx_kernel<8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS);
   else                               // exact online maximum
     attn_kernel<8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS);

@@ -140,6 +140,14 @@ __device__ __forceinline__ uint32_t w4_cvt_pk(float lo, float hi) {
   asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+// the same behind one idle issue slot: for schedules in which hipcc is free to sink the (compiler-visible) v_exp_f32 of the region
+// before to that region's end, i.e. right in front of this (invisible) reader of its result -- a transcendental result needs one
+// instruction in between (tools/check_mfma_hazard.py found exactly that in MODE 4's first, P.V-less step)
+__device__ __forceinline__ uint32_t w4_cvt_pk_gap(float lo, float hi) {
+  uint32_t r;
+  asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
 
 // MODE 0: the round-2 bookkeeping (row sums and the reference offset on the matrix pipe: 76 MFMAs per 64-key tile, 64 of them
 // Q.K^T / P.V).  MODE 1: the row sums leave the matrix pipe -- with the swapped Q.K^T a query row is lane-local, so l += sum p is
@@ -152,6 +160,9 @@ __device__ __forceinline__ uint32_t w4_cvt_pk(float lo, float hi) {
 // only when that lies outside, and moves later only when a row's maximum exceeds it by more than W4_BIG: 64 MFMAs per tile on
 // ordinary data, the MODE-1 stream otherwise (a wave-uniform, not-taken branch in front of the chain).  MODE 3: MODE 0's stream
 // (row sums on the matrix pipe) with MODE 2's lazy reference offset: 72 MFMAs per tile, no VALU instruction more than MODE 0.
+// MODE 4: no reference at all (no row maximum, no branch, no offset MFMA) -- only launched when the caller vouches for
+// |score| <= W4_BIG in the exp2 domain (AttnArgs::score_bound; the DiT derives it from the q / k RMSNorm weights: after the
+// norm |q| <= sqrt(128) max|w_q|, RoPE preserves the norm, so |q . k| scale log2 e <= 128 max|w_q| max|w_k| 0.1275).
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
                                                          const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq, int64_t ldk,
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
                                                          int64_t o_bs, int H, int N, int nqb, float scale_log2e, int nfull,
                                                          int nparts, int nsplit, int xsplit, float* part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool LV = MODE == 1 || MODE == 2, LZ = MODE >= 2;
+  constexpr bool LV = MODE == 1 || MODE == 2, LZ = MODE >= 2, NOREF = MODE == 4, FT = LV || NOREF;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
@@ -403,7 +414,9 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       } else if constexpr (i == 1 && LZ) {
         // the chain starts here; the reference offset joins it (one more MFMA, out of line) only while some row of this wave has one
         w4_mfma_s0(nxt, kf[0], qf[OQ][0]);
-        if (__builtin_expect_with_probability(any_ref, 0, 1.0)) w4_mfma_s(nxt, kone, qm[OQ]);
+        if constexpr (!NOREF) {
+          if (__builtin_expect_with_probability(any_ref, 0, 1.0)) w4_mfma_s(nxt, kone, qm[OQ]);
+        }
       } else {
         w4_mfma_s(nxt, kf[i - 1], qf[OQ][i - 1]);
         // reloaded two MFMAs after its last reader: spreads the LDS reads over the regions
@@ -446,13 +459,13 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     auto F = [&](auto Ic) __attribute__((always_inline)) {
       constexpr int k = decltype(Ic)::value;
       if constexpr (W4_ABL & 1) return;
-      // LV modes end  e13 e14 e15 c6 c7  (no MFMA region separates the last pack from its exponentials there)
-      constexpr bool is_c = LV ? (k >= 22 || (k >= 3 && k <= 18 && k % 3 == 0)) : ((k == 23) || (k >= 3 && k < 22 && k % 3 == 0));
+      // LV modes and MODE 4 end  e13 e14 e15 c6 c7  (no MFMA region separates the last pack from its exponentials there)
+      constexpr bool is_c = FT ? (k >= 22 || (k >= 3 && k <= 18 && k % 3 == 0)) : ((k == 23) || (k >= 3 && k < 22 && k % 3 == 0));
       if constexpr (is_c) {
-        constexpr int c = LV ? (k >= 22 ? k - 16 : k / 3 - 1) : (k == 23 ? 7 : k / 3 - 1);
-        pf[QB][c >> 2][c & 3] = w4_cvt_pk(cur[2 * c], cur[2 * c + 1]);
+        constexpr int c = FT ? (k >= 22 ? k - 16 : k / 3 - 1) : (k == 23 ? 7 : k / 3 - 1);
+        pf[QB][c >> 2][c & 3] = NOREF ? w4_cvt_pk_gap(cur[2 * c], cur[2 * c + 1]) : w4_cvt_pk(cur[2 * c], cur[2 * c + 1]);
       } else {
-        constexpr int e = LV ? (k < 3 ? k : k >= 19 ? k - 6 : k - (k / 3))
+        constexpr int e = FT ? (k < 3 ? k : k >= 19 ? k - 6 : k - (k / 3))
                              : (k < 3 ? k : k == 22 ? 15 : k - (k / 3));      // exponentials seen so far = index minus packs before it
         cur[e] = __builtin_amdgcn_exp2f(cur[e]);
       }
@@ -658,6 +671,50 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     P(IC<8>{}); G(IC<12>{}); G(IC<13>{});
     W4_GAP();
     P(IC<9>{}); G(IC<14>{}); G(IC<15>{});
+    W4_GAP();
+    F(IC<23>{});
+    W4_GAP();
+    } else if constexpr (MODE == 4) {
+    // the caller vouches for |score| <= W4_BIG (AttnArgs::score_bound): no reference at all -- no row maximum, no branch, no offset
+    // MFMA; the exponentials start with the step and spread over all 18 regions (one staging piece each in 16 of them)
+    S(IC<1>{}); W4_TOUCH(cur); F(IC<0>{}); G(IC<0>{});
+    W4_GAP();
+    P(IC<0>{}); F(IC<1>{}); G(IC<1>{});
+    W4_GAP();
+    S(IC<2>{}); F(IC<2>{}); G(IC<2>{});
+    W4_GAP();
+    P(IC<1>{}); F(IC<3>{}); F(IC<4>{}); G(IC<3>{});
+    W4_GAP();
+    S(IC<3>{}); F(IC<5>{}); G(IC<4>{});
+    W4_GAP();
+    P(IC<2>{}); F(IC<6>{}); G(IC<5>{});
+    W4_GAP();
+    S(IC<4>{}); F(IC<7>{}); F(IC<8>{}); G(IC<6>{});
+    W4_GAP();
+    P(IC<3>{}); F(IC<9>{}); G(IC<7>{});
+    W4_GAP();
+    S(IC<5>{}); F(IC<10>{}); G(IC<8>{});
+    W4_GAP();
+    P(IC<4>{}); F(IC<11>{}); F(IC<12>{}); G(IC<9>{});
+    W4_GAP();
+    S(IC<6>{}); F(IC<13>{}); G(IC<10>{});
+    W4_GAP();
+    P(IC<5>{}); F(IC<14>{}); G(IC<11>{});
+    W4_GAP();
+    S(IC<7>{}); F(IC<15>{}); F(IC<16>{}); G(IC<12>{});
+    W4_GAP();
+    P(IC<6>{}); F(IC<17>{}); G(IC<13>{});
+    W4_GAP();
+    S(IC<8>{}); F(IC<18>{}); G(IC<14>{});
+#ifdef W4_HAZARD_SELFTEST
+    { const float t_ = w4_max(nxt[0], nxt[1]); asm volatile("" ::"v"(t_)); }
+#endif
+    W4_GAP();
+    P(IC<7>{}); F(IC<19>{}); G(IC<15>{});
+    W4_GAP();
+    P(IC<8>{}); F(IC<20>{}); F(IC<21>{});
+    W4_GAP();
+    P(IC<9>{}); F(IC<22>{});
     W4_GAP();
     F(IC<23>{});
     W4_GAP();
@@ -890,7 +947,7 @@ static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, 
   return 0;
 }
 
-// mode: 0 .. 3 = attn_w4_kernel<MODE> (tfx_set_option attention_waves 30 .. 33)
+// mode: 0 .. 4 = attn_w4_kernel<MODE> (tfx_set_option attention_waves 30 .. 34; 34 only when AttnArgs::score_bound allows it)
 int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode) {
   const int nqb = (a.N + 255) / 256;
   const int T = a.B * a.H * nqb;
@@ -917,7 +974,8 @@ int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode) {
     }
   }
   const unsigned grid = nsplit > 1 ? (unsigned)(((nfull + 7) & ~7) + nparts) : (unsigned)T;
-  const int rc = mode == 3 ? w4_launch<3>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
+  const int rc = mode == 4 ? w4_launch<4>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
+               : mode == 3 ? w4_launch<3>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
                : mode == 2 ? w4_launch<2>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
                : mode == 1 ? w4_launch<1>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
                            : w4_launch<0>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part);

@@ -115,7 +115,7 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
     a.q = y + 2 * D; a.k = y; a.v = y + D; a.o = y + 2 * D;
     a.ldq = a.ldk = a.ldv = a.ldo = D7;
     a.q_bstride = a.k_bstride = a.v_bstride = a.o_bstride = y_bs;
-    a.B = B; a.H = H; a.N = N; a.scale = att_scale;
+    a.B = B; a.H = H; a.N = N; a.scale = att_scale; a.score_bound = d.attn_score_bound;
     return joint_attention(a, st);
   };
 
@@ -343,7 +343,7 @@ int tfx_joint_attention(const tfx_attn_args* g, tfx_stream stream) {
   a.q = g->q; a.k = g->k; a.v = g->v; a.o = g->o;
   a.ldq = g->ldq; a.ldk = g->ldk; a.ldv = g->ldv; a.ldo = g->ldo;
   a.q_bstride = g->q_bstride; a.k_bstride = g->k_bstride; a.v_bstride = g->v_bstride; a.o_bstride = g->o_bstride;
-  a.B = g->B; a.H = g->H; a.N = g->N; a.scale = g->scale;
+  a.B = g->B; a.H = g->H; a.N = g->N; a.scale = g->scale; a.score_bound = g->score_bound;
   return joint_attention(a, S(stream));
 }
 
@@ -498,13 +498,14 @@ int tfx_set_option(const char* name, int value) {
   if (!name) return fail("tfx_set_option: null name");
   if (!std::strcmp(name, "attention_waves")) {
     if (value == 0) { set_attention_waves(0); return 0; }     // back to the library default and its size heuristic
-    if (value != 4 && value != 8 && value != 9 && value != 10 && value != 12 && value != 16 && value != 20 && !(value >= 30 && value <= 33) && value != 40)
-      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves), 16 (ping-pong), 20 (half-tile pipelined), 30 .. 33 (one wave per SIMD, 32x32x16 MFMA: bookkeeping on the matrix pipe / row sums on the VALU / + lazy reference offset / 30 + lazy reference offset) or 40 (one wave per SIMD, 16x16x32 MFMA)");
+    if (value != 4 && value != 8 && value != 9 && value != 10 && value != 12 && value != 16 && value != 20 && !(value >= 30 && value <= 34) && value != 40)
+      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves), 16 (ping-pong), 20 (half-tile pipelined), 30 .. 33 (one wave per SIMD, 32x32x16 MFMA: bookkeeping on the matrix pipe / row sums on the VALU / + lazy reference offset / 30 + lazy reference offset / 33, or no reference at all when the call carries a score bound) or 40 (one wave per SIMD, 16x16x32 MFMA)");
     set_attention_waves(value);
     return 0;
   }
   if (!std::strcmp(name, "gemm_group_m")) { set_gemm_group_m(value); return 0; }
   if (!std::strcmp(name, "attention_tail_split")) { set_attention_tail_split(value); return 0; }
+  if (!std::strcmp(name, "attention_use_bound")) { set_attention_use_bound(value); return 0; }
   if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
   if (!std::strcmp(name, "gemm_splitk")) { set_gemm_splitk(value); return 0; }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only

@@ -80,6 +80,7 @@ struct AttnArgs {
   int64_t q_bstride, k_bstride, v_bstride, o_bstride;
   int B, H, N;
   float scale;
+  float score_bound = 0.f;   // caller's promise |scale * q . k| <= score_bound (0 = unknown): see tfx_attn_args
 };
 int joint_attention(const AttnArgs& a, hipStream_t st);
 int joint_attention_hp(const AttnArgs& a, hipStream_t st);   // half-tile software-pipelined kernel (attention_hp.hip)
@@ -88,6 +89,7 @@ int attention_w4_prepare(hipStream_t st);                      // allocates the 
 void set_attention_tail_split(int v);                          // 0 = never split the last round's q-tiles by keys (bench knob)
 int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode);   // one wave per SIMD, 64 query rows per wave (attention_w4.hip); mode: 0 bookkeeping on the matrix pipe, 1 row sums on the VALU, 2 + lazy reference offset
 void set_attention_ablation(int a);
+void set_attention_use_bound(int v);   // 0: ignore AttnArgs::score_bound
 void set_attention_debug(void* p);
 void set_attention_waves(int nw);  // 8 (one 512-thread workgroup per CU) or 4 (two independent 256-thread workgroups)
 

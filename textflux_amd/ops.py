@@ -184,8 +184,9 @@ def rmsnorm_rope_(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, wq_
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: Optional[torch.Tensor] = None,
-              scale: Optional[float] = None) -> torch.Tensor:
-    """q,k,v: [B,N,H*128] (views with row/batch strides allowed) -> out [B,N,H*128]."""
+              scale: Optional[float] = None, score_bound: float = 0.0) -> torch.Tensor:
+    """q,k,v: [B,N,H*128] (views with row/batch strides allowed) -> out [B,N,H*128].  score_bound: the caller's promise
+    |scale * q . k| <= score_bound (0 = unknown), see tfx_attn_args."""
     _chk_dev(q, k, v, out)
     B, N, HD = q.shape
     H = HD // 128
@@ -198,6 +199,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: Optional[t
     a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.B, a.H, a.N = B, H, N
     a.scale = scale if scale is not None else 128 ** -0.5
+    a.score_bound = float(score_bound)
     L.check(L.lib().tfx_joint_attention(C.byref(a), _stream()), "joint_attention")
     return out
 

@@ -323,6 +323,20 @@ class FluxTransformer2DModel:
         return self._lin(ops.silu(temb), "mod")
 
     # ------------------------------------------------------------------ sessions / forward
+    def attn_score_bound(self) -> float:
+        """tfx_dit_desc.attn_score_bound: an upper bound of |q . k| * 128^-0.5 over every attention launch of the forward, from the
+        q / k RMSNorm weights (attention_processor.py:2001-2004, 2023-2037: after RMSNorm |q|^2 = sum_i (x_i / rms)^2 w_i^2 <=
+        128 max w^2, RoPE is a rotation) -- lets the attention kernel drop its running-maximum bookkeeping when the bound shows that
+        exp2 cannot overflow.  Joint attention mixes the image and text streams: the larger of the two norms on each side.
+        2 % on top for the bf16 roundings of the normalised values."""
+        c, w, m = self.config, self.w, 0.0
+        amax = lambda n: float(w[n].float().abs().max().item())
+        for i in range(c.num_layers):
+            m = max(m, max(amax(f"d{i}.norm_q"), amax(f"d{i}.norm_added_q")) * max(amax(f"d{i}.norm_k"), amax(f"d{i}.norm_added_k")))
+        for j in range(c.num_single_layers):
+            m = max(m, amax(f"s{j}.norm_q") * amax(f"s{j}.norm_k"))
+        return 1.02 * 128.0 * m * 128 ** -0.5
+
     def session(self, B: int, S: int, T: int) -> "DitSession":
         s = self._session
         if s is None or (s.B, s.S, s.T) != (B, S, T):
@@ -430,6 +444,7 @@ class DitSession:
         d.first_block, d.last_block, d.flags = 0, -1, 0
         d.cos_tab, d.sin_tab = self.cos.data_ptr(), self.sin.data_ptr()
         d.rope_cs = self.rope_cs.data_ptr() if model.fuse_qk_norm_rope else None
+        d.attn_score_bound = model.attn_score_bound()
         if self.fp8:
             d.q8, d.q8_scale = self.q8.data_ptr(), self.q8_scale.data_ptr()
         # scratch for the split-K path of few-tile GEMMs (text stream, small batch x resolution): fp32 partials of at most
