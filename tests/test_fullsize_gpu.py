@@ -112,8 +112,21 @@ def test_full_model_batch_consistency_and_determinism():
         n2 = m(hidden_states=hs.repeat(2, 1, 1), encoder_hidden_states=pe.repeat(2, 1, 1),
                pooled_projections=pooled.repeat(2, 1), timestep=t1.repeat(2), guidance=g1.repeat(2), **kw)[0]
     finally:
-        ops.set_option("gemm_splitk", 1)
+        ops.set_option("gemm_splitk", 2)
     assert torch.equal(n2[0], n2[1]) and torch.equal(n2[0], n1[0])
+    # round 4: the text and image projections of a double block run as ONE launch over the joint rows (row-split weights) -- the same
+    # tiles computed by the same code, so with the K-slicing off (which the joint launch's other tile count would plan differently)
+    # the outputs are bit-identical to the two-launch form, at either batch size
+    ops.set_option("gemm_splitk", 0)
+    ops.set_option("gemm_group_streams", 0)
+    try:
+        s1 = m(hidden_states=hs, encoder_hidden_states=pe, pooled_projections=pooled, timestep=t1, guidance=g1, **kw)[0]
+        s2 = m(hidden_states=hs.repeat(2, 1, 1), encoder_hidden_states=pe.repeat(2, 1, 1),
+               pooled_projections=pooled.repeat(2, 1), timestep=t1.repeat(2), guidance=g1.repeat(2), **kw)[0]
+    finally:
+        ops.set_option("gemm_splitk", 2)
+        ops.set_option("gemm_group_streams", 1)
+    assert torch.equal(s1, n1) and torch.equal(s2, n2)
 
 
 def test_fused_qk_norm_rope_epilogue_matches_separate_pass():

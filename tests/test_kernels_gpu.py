@@ -135,7 +135,39 @@ def test_gemm_split_k_matches_unsplit(ops, B, M, N, K):
     try:
         assert torch.equal(ops.gemm(a, w, bias, variant=1, workspace=ws), ops.gemm(a, w, bias, variant=3))
     finally:
-        ops.set_option("gemm_splitk", 1)
+        ops.set_option("gemm_splitk", 2)
+
+
+@pytest.mark.parametrize("B,M,N,K", [(1, 4096, 9216, 3072), (2, 2048, 9216, 3072), (1, 1664, 21504, 3072), (1, 1280, 15360, 3072)])
+def test_gemm_tail_split_matches_unsplit(ops, B, M, N, K):
+    """Round 4: a SMALL GEMM (fewer than 8 rounds of the chip) whose last round of 256 x 256 tiles is partly filled has the tiles of
+    that round K-sliced (the last r tile positions of EVERY batch sample, so that identical samples keep identical bits; fp32
+    partials, tail_reduce_kernel) -- 576 tiles = 2 rounds + 64 tiles in 4 slices, 588 = 2 rounds + 76 in 3 (ragged M), 300 = 1
+    round + 44 in 4.  Same contract as the whole-GEMM split: against the unsplit persistent kernel only the fp32 summation order
+    of the sliced tiles differs; `gemm_splitk` 1 (round 3's behaviour) and 0 leave these shapes unsplit, bit for bit."""
+    a, w = rnd((B, M, K), 61).to(BF).cuda(), rnd((N, K), 62, 0.03).to(BF).cuda()
+    bias, gate, res = rnd((N,), 63).to(BF).cuda(), rnd((B, N), 64).to(BF).cuda(), rnd((B, M, N), 65).to(BF).cuda()
+    if B > 1:
+        a[1], res[1], gate[1] = a[0], res[0], gate[0]
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")        # the engine's scratch size: 256 units of 256 KiB
+    cases = [(ops.EPI_BIAS, {}), (ops.EPI_BIAS_GELU, dict(gelu_from_col=max(0, (N // 256 - 2) * 256))),
+             (ops.EPI_BIAS_GATE_RES, dict(gate=gate, res=res)), (ops.EPI_BIAS_RES, dict(res=res))]
+    for epi, kw in cases:
+        unsplit = ops.gemm(a, w, bias, epilogue=epi, variant=3, **kw)
+        split = ops.gemm(a, w, bias, epilogue=epi, variant=1, workspace=ws, **kw)
+        d = (unsplit.float() - split.float()).abs()
+        assert torch.isfinite(split).all()
+        assert d.max().item() <= 2 ** -7 * unsplit.float().abs().max().item()
+        frac = (d > 0).float().mean().item()
+        assert 0 < frac < 2e-2, (epi, frac)            # something WAS sliced (isolated one-ulp flips), and only a sliver
+        if B > 1:
+            assert torch.equal(split[0], split[1])     # identical samples: identical bits (same tile positions sliced in both)
+        for lvl in (1, 0):
+            ops.set_option("gemm_splitk", lvl)
+            try:
+                assert torch.equal(ops.gemm(a, w, bias, epilogue=epi, variant=1, workspace=ws, **kw), unsplit)
+            finally:
+                ops.set_option("gemm_splitk", 2)
 
 
 def test_gemm_persistent_rejects_odd_k_tiles(ops):

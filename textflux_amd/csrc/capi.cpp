@@ -33,6 +33,13 @@ struct Gemm {
     return *this;
   }
   Gemm& scratch(void* ws, int64_t bytes) { a.workspace = ws; a.workspace_bytes = bytes; return *this; }
+  // row-split weights: rows [0, split_row) of every sample (the text rows of the joint stream) take l2 / gate2 (/ norm weights wq2, wk2)
+  Gemm& rowsplit(int split_row, const tfx_linear& l2, const void* gate2 = nullptr) {
+    a.split_row = split_row; a.W2 = l2.w; a.bias2 = l2.b; a.gate2 = gate2;
+    return *this;
+  }
+  Gemm& qknorm2(const void* wq2, const void* wk2) { a.qkn_wq2 = wq2; a.qkn_wk2 = wk2; return *this; }
+  bool rowsplit_ok() const { return gemm_rowsplit_ok(a); }
   // fused per-head RMSNorm + RoPE on the k / q column ranges [0, D) / [2D, 3D) of a [k | v | q | ...] projection
   Gemm& qknorm(const void* wq, const void* wk, const float* cs, int pos0, int D, float eps) {
     a.qkn_wq = wq; a.qkn_wk = wk; a.qkn_rope_cs = cs; a.qkn_pos0 = pos0;
@@ -43,6 +50,7 @@ struct Gemm {
   bool qknorm_ok(const void* wq, const void* wk, const float* cs, int pos0, int D, float eps) const {
     Gemm t = *this;
     t.qknorm(wq, wk, cs, pos0, D, eps);
+    if (t.a.split_row > 0 && !(t.a.qkn_wq2 && t.a.qkn_wk2)) return false;
     return gemm_qkn_ok(t.a);
   }
   int run(hipStream_t st) const { return gemm_bf16(a, st); }
@@ -72,6 +80,8 @@ struct Gemm {
   do {                    \
     if (int _e = (x)) return _e; \
   } while (0)
+
+static int g_group_streams = 1;   // tfx_set_option gemm_group_streams: 0 = the text and image GEMMs of a double block as separate launches (A/B knob)
 
 int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
   const int D = d.D, H = d.H, B = d.B, Sn = d.S, T = d.T, N = Sn + T;
@@ -126,7 +136,9 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
   // (bf16 mode, persistent kernel, enough tiles to fill the chip unsplit), else the GEMM followed by the separate pass
   const bool may_fuse = d.rope_cs && !q8;
   auto fused_here = [&](const Gemm& gm, int row0, const void* nq, const void* nk) -> bool {
-    return may_fuse && gm.qknorm_ok(nq, nk, d.rope_cs, row0, D, eps);
+    Gemm t = gm;      // with the scratch the launch will have: a GEMM the auto path K-slices cannot carry the fused epilogue
+    t.scratch(d.gemm_workspace, d.gemm_workspace_bytes);
+    return may_fuse && t.qknorm_ok(nq, nk, d.rope_cs, row0, D, eps);
   };
   auto norm_gemm = [&](const uint16_t* src, int row0, int rows, const uint16_t* shift, const uint16_t* scale, Gemm gm) -> int {
     gm.scratch(d.gemm_workspace, d.gemm_workspace_bytes);
@@ -146,6 +158,34 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
       const tfx_double_block& w = d.dbl[blk];
       const uint16_t* mi = mod + (int64_t)blk * 12 * D;  // img: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp
       const uint16_t* mt = mi + 6 * D;                   // txt: same six
+      // The text and image projections of the block as ONE launch each over the joint [text | image] rows (row-split weights) when
+      // the text length is a whole number of tiles and the two weight matrices sit in one allocation (the engine's loader puts
+      // them there); else two launches.  bf16 mode only.
+      Gemm jq(xn, D, hid_bs, w.qkv_img, D, y, D7, y_bs, N, 3 * D, D, B);
+      jq.rowsplit(T, w.qkv_txt).qknorm2(w.norm_added_q, w.norm_added_k).scratch(d.gemm_workspace, d.gemm_workspace_bytes);
+      Gemm jo(y + 2 * D, D7, y_bs, w.out_img, D, hid, D, hid_bs, N, D, D, B);
+      jo.gate_res(mi + 2 * D, mbs, hid, D, hid_bs).rowsplit(T, w.out_txt, mt + 2 * D).scratch(d.gemm_workspace, d.gemm_workspace_bytes);
+      Gemm j1(xn, D, hid_bs, w.ff1_img, D, y + 3 * D, D7, y_bs, N, 4 * D, D, B);
+      j1.gelu(0).rowsplit(T, w.ff1_txt).scratch(d.gemm_workspace, d.gemm_workspace_bytes);
+      Gemm j2(y + 3 * D, D7, y_bs, w.ff2_img, 4 * D, hid, D, hid_bs, N, D, 4 * D, B);
+      j2.gate_res(mi + 5 * D, mbs, hid, D, hid_bs).rowsplit(T, w.ff2_txt, mt + 5 * D).scratch(d.gemm_workspace, d.gemm_workspace_bytes);
+      const bool joint = g_group_streams && T > 0 && !q8 && jq.rowsplit_ok() && jo.rowsplit_ok() && j1.rowsplit_ok() && j2.rowsplit_ok();
+      if (joint) {
+        TRY(ln_modulate(hid_img, xn_img, mi, mi + D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
+        TRY(ln_modulate(hid, xn, mt, mt + D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
+        const bool fj = may_fuse && jq.qknorm_ok(w.norm_q, w.norm_k, d.rope_cs, 0, D, eps);
+        if (fj) jq.qknorm(w.norm_q, w.norm_k, d.rope_cs, 0, D, eps);
+        TRY(jq.run(st));
+        if (!fj)
+          TRY(rmsnorm_rope(y, D7, y_bs, 2 * D, 0, H, N, T, B, w.norm_q, w.norm_k, w.norm_added_q, w.norm_added_k, d.cos_tab, d.sin_tab, eps, st));
+        TRY(attention());
+        TRY(jo.run(st));                                                      // hidden += gate_msa * to_out(attn), both streams
+        TRY(ln_modulate(hid_img, xn_img, mi + 3 * D, mi + 4 * D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
+        TRY(ln_modulate(hid, xn, mt + 3 * D, mt + 4 * D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
+        TRY(j1.run(st));
+        TRY(j2.run(st));
+        continue;
+      }
       {
         Gemm gi(xn_img, D, hid_bs, w.qkv_img, D, y_img, D7, y_bs, Sn, 3 * D, D, B);
         const bool fi = fused_here(gi, T, w.norm_q, w.norm_k);
@@ -507,6 +547,7 @@ int tfx_set_option(const char* name, int value) {
   if (!std::strcmp(name, "attention_tail_split")) { set_attention_tail_split(value); return 0; }
   if (!std::strcmp(name, "attention_use_bound")) { set_attention_use_bound(value); return 0; }
   if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
+  if (!std::strcmp(name, "gemm_group_streams")) { g_group_streams = value; return 0; }
   if (!std::strcmp(name, "gemm_splitk")) { set_gemm_splitk(value); return 0; }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only
   return fail("tfx_set_option: unknown option '%s'", name);

@@ -60,8 +60,18 @@ struct GemmParams {
   int csh;                                          // log2(cin) when cin < 64 (narrow-input mode), else 0
   const bf16_t* zero;
   const float* a_scale; int64_t as_bs; const float* w_scale;   // fp8 kernel only
-  float* ws; int sk;                                             // split-K: fp32 partials [sk][batch][M][N], slices
-  int64_t ws_ld, ws_bs;                                           // row / (slice, batch) strides of ws in floats (fp32-output mode: ldc / c_bstride)
+  // K-sliced work units (SPLIT kernels).  Units [0, u_full) are whole tiles with the normal epilogue; the last tail_r tiles of every
+  // batch sample's tile order follow as (tile, slice) units, slice-major: sk slices of nt / sk K-tiles each, raw fp32 accumulators
+  // to ws [slice][tail tile][256][256] (compact), finished by tail_reduce_kernel<EPI> (slices summed in order, then the epilogue).
+  // tail_r = tiles per sample, u_full = 0: the whole GEMM is sliced (fewer tiles than CUs).  fp32-OUTPUT mode (ws_ld != 0, sk = 1,
+  // every tile a "slice" unit): the raw accumulators go straight to ws = C with row stride ws_ld and batch stride ws_bs.
+  float* ws; int sk, u_full, tail_r;
+  int64_t ws_ld, ws_bs;
+  // row-split weights (split_row > 0): tiles whose first row (inside the batch sample) lies below split_row -- the TEXT rows of the
+  // joint [text | image] stream -- take the second weight set: W at byte offset w2_off from W (same descriptor), bias2 / gate2 /
+  // nq_w2 / nk_w2 instead of bias / gate / nq_w / nk_w.  One launch for the text and image projections of a double block.
+  int split_row; uint32_t w2_off;
+  const bf16_t* bias2; const bf16_t* gate2; const bf16_t* nq_w2; const bf16_t* nk_w2;
   // fused per-head RMSNorm + RoPE of the q / k column ranges (QKN kernel instantiation; see GemmArgs)
   const bf16_t* nq_w; const bf16_t* nk_w; const float* rope_cs; int rope_pos0, nq0, nq1, nk0, nk1; float n_eps;
 };
@@ -215,7 +225,12 @@ __device__ __forceinline__ void mfma_section(f32x4 (&acc)[8][4], const bf16x8 (&
 template <int EPI, bool FP8, bool QKN, int RES_DEPTH>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmParams& p, const int m0, const int n0, const int b,
                                               const int g, const int wc, const int lane, char* stg, const char* stg_partner,
-                                              unsigned long long* tfx_stamp = nullptr) {
+                                              unsigned long long* tfx_stamp = nullptr, const bool second = false) {
+  // row-split weights: this tile's bias / gate / norm weights (block-uniform pointer selects)
+  const bf16_t* const p_bias = second ? p.bias2 : p.bias;
+  const bf16_t* const p_gate = second ? p.gate2 : p.gate;
+  const bf16_t* const p_nq = second ? p.nq_w2 : p.nq_w;
+  const bf16_t* const p_nk = second ? p.nk_w2 : p.nk_w;
   // lane-derived offsets are rebuilt from an opaque copy of the lane id: derived from `lane` they are loop invariants that
   // hipcc keeps in ~20 VGPRs across the K loop, which is what pushes the kernel into spilling
   int lane_e = lane;
@@ -269,8 +284,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
   }
   u32x2 bsr[4], gtr[4];   // bias / gate stay packed (bf16 pairs) until they are used
   u32x4 rr[RES_DEPTH][4];
-  const auto rsrcB = uniform_rsrc(p.bias ? p.bias : p.C, p.bias ? p.N * 2 : 0);
-  const auto rsrcG = uniform_rsrc(EPI == EPI_BIAS_GATE_RES ? p.gate + b * p.gate_bs : p.C, EPI == EPI_BIAS_GATE_RES ? p.N * 2 : 0);
+  const auto rsrcB = uniform_rsrc(p_bias ? p_bias : p.C, p_bias ? p.N * 2 : 0);
+  const auto rsrcG = uniform_rsrc(EPI == EPI_BIAS_GATE_RES ? p_gate + b * p.gate_bs : p.C, EPI == EPI_BIAS_GATE_RES ? p.N * 2 : 0);
 #pragma unroll
   for (int nj = 0; nj < 4; ++nj) {   // no bias / columns beyond N: zeros (computed, never stored)
     bsr[nj] = __builtin_amdgcn_raw_buffer_load_b64(rsrcB, (ncol + nj * 16) * 2, 0, 0);
@@ -293,7 +308,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
   float rinv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   u32x4 nw8 = u32x4{0u, 0u, 0u, 0u};     // norm weights of the 8 columns this lane stores (norm tiles)
   if (norm_tile) {
-    nw8 = *reinterpret_cast<const u32x4*>((in_q ? p.nq_w : p.nk_w) + (wc & 1) * 64 + cchunk * 8);
+    nw8 = *reinterpret_cast<const u32x4*>((in_q ? p_nq : p_nk) + (wc & 1) * 64 + cchunk * 8);
     // Linear output in bf16 (what the reference's RMSNorm sees), in place; sum of squares of this lane's 16 columns, then of
     // the row's 64 columns in this wave (the four lanes l, l ^ 16, l ^ 32, l ^ 48 hold one row)
     float ss[8];
@@ -749,9 +764,11 @@ constexpr int PP_LDS_TOTAL = PP_STG + 8 * PP_STG_WAVE;  // 163840 = all of the C
 // v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; 8 passes) per K-tile instead of two 16x16x32 bf16 (4 passes each),
 // i.e. the same 256 cycles per section for twice the k, and the epilogue applies the per-row / per-channel scales.
 // Lane l supplies row (l & 15), k bytes (l >> 4) * 32 .. +32 of the 128-k step = 16-byte chunks 2 (l >> 4), 2 (l >> 4) + 1.
-// SPLIT: the work unit is (tile, K slice): p.sk slices of nt / p.sk K-tiles each, units ordered slice-major; the epilogue
-// stores the raw fp32 accumulators to p.ws [slice][batch][M][N] and splitk_reduce_kernel<EPI> finishes (sum over the
-// slices in order, bias, activation, gate, residual).  Used when a GEMM has fewer tiles than the chip has CUs.
+// SPLIT: some or all work units are (tile, K slice) pairs (GemmParams::u_full / tail_r / sk): whole tiles first, with the normal
+// epilogue, then the last tail_r tiles of every sample's tile order cut into sk slices of nt / sk K-tiles each, whose raw fp32
+// accumulators go to p.ws and are finished by tail_reduce_kernel<EPI> (slices summed in order, bias, activation, gate,
+// residual).  Used when a GEMM has fewer tiles than the chip has CUs (every tile sliced), and -- round 4 -- when a SMALL GEMM's
+// last round of tiles would leave most CUs idle (the tiles of that round sliced so that they fill one short round instead).
 // QKN (the fused q | k | v (| mlp) projections of the DiT blocks): tiles inside the q / k column ranges -- a 256-column tile
 // is exactly two heads -- get the per-head RMSNorm (fp32 sum of squares over the 128 columns of the bf16-rounded Linear
 // output, * weight) and the interleaved-pair RoPE applied in the epilogue, rounding for rounding as rmsnorm_rope_kernel
@@ -766,12 +783,13 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   const int g = wave >> 2;
   const int wc = wave & 3;
   constexpr int ESZ = FP8 ? 1 : 2;       // bytes per operand element
-  const int nt = ((p.K * ESZ) >> 7) / (SPLIT ? p.sk : 1);   // K-tiles of 128 bytes per row (per slice)
+  const int nt_full = (p.K * ESZ) >> 7;                    // K-tiles of 128 bytes per row
+  const int nt_slice = SPLIT ? nt_full / p.sk : nt_full;   // ... of a (tile, slice) unit
 
   // ---- this block's tiles: XCD x owns a contiguous range of the (grouped) tile order; its blocks stride through it
   const int per_batch = p.tm * p.tn;
   const int T1 = p.batch * per_batch;               // tiles
-  const int T = SPLIT ? T1 * p.sk : T1;             // work units
+  const int T = SPLIT ? p.u_full + p.batch * p.tail_r * p.sk : T1;             // work units
   const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
   const int q8 = T >> 3, r8 = T & 7;
   const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -779,13 +797,25 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   int it = blockIdx.x >> 3;
   if (it >= xcnt) return;
 
-  struct Tile { int b, m0, n0, slice; uint32_t xoff, woff; };
+  struct Tile { int b, m0, n0, unit, nt; bool second; uint32_t xoff, woff; };   // unit: -1 = whole tile, else index of the (tile, slice) unit
   auto coords = [&](int id) {
     Tile t;
-    t.slice = SPLIT ? id / T1 : 0;
-    if (SPLIT) id -= t.slice * T1;
-    t.b = id / per_batch;
-    int idx = id - t.b * per_batch;
+    int idx, slice = 0;
+    t.unit = -1;
+    t.nt = nt_full;
+    if (SPLIT && id >= p.u_full) {
+      t.unit = id - p.u_full;                       // slice-major: neighbours in the unit order are neighbouring tiles of one K range
+      const int TT = p.batch * p.tail_r;
+      slice = t.unit / TT;
+      const int tt = t.unit - slice * TT;           // tail tile
+      t.b = tt / p.tail_r;
+      idx = per_batch - p.tail_r + (tt - t.b * p.tail_r);
+      t.nt = nt_slice;
+    } else {
+      const int full_per_batch = SPLIT ? per_batch - p.tail_r : per_batch;
+      t.b = id / full_per_batch;
+      idx = id - t.b * full_per_batch;
+    }
     const int GM = p.gm;
     const int grp = idx / (GM * p.tn);
     const int first_m = grp * GM;
@@ -793,8 +823,9 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     idx -= grp * GM * p.tn;
     t.m0 = (first_m + idx % gsz) * 256;
     t.n0 = (idx / gsz) * 256;
-    t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * ESZ) + (uint32_t)(t.slice * nt) * 128u;
-    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * ESZ) + (uint32_t)(t.slice * nt) * 128u;
+    t.second = t.m0 < p.split_row;
+    t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * ESZ) + (uint32_t)(slice * nt_slice) * 128u;
+    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * ESZ) + (uint32_t)(slice * nt_slice) * 128u + (t.second ? p.w2_off : 0u);
     return t;
   };
 
@@ -834,7 +865,8 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   // num_records: the operand's extent in bytes (< 2^32, persist_ok)
   const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.A, 0, (int)(uint32_t)((((int64_t)(p.batch - 1) * p.a_bs + (int64_t)(p.M - 1) * p.lda + p.K) * ESZ)), 0x00020000);
-  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)(uint32_t)((((int64_t)(p.N - 1) * p.ldw + p.K) * ESZ)), 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.W, 0, (int)((uint32_t)((((int64_t)(p.N - 1) * p.ldw + p.K) * ESZ)) + (p.split_row > 0 ? p.w2_off : 0u)), 0x00020000);
 
   // request item q of K-tile kt of the tile with origins (xo, wo) into buffer set `set`
   auto stage = [&](int q, uint32_t xo, uint32_t wo, int kt, int set) {
@@ -936,6 +968,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     // on the previous epilogue's stores, which retire in issue order with the requests.  The first K-tile's MFMAs start from
     // a zero C operand instead of zeroed accumulators.
     int u0 = 0;
+    const int nt = cur.nt;
     // (not in the fp8 gated-residual instantiation: there the two extra loop bodies tip hipcc's allocation into spills)
     if (nt >= 4 && !(FP8 && EPI == EPI_BIAS_GATE_RES)) {
       PP_TILE_W(0, cx, cw, 2, 0, 0, 0, true);
@@ -958,30 +991,39 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     TFX_STAMP(0);
 
     // ---- epilogue (tile_epilogue), one 32-row block of the accumulators at a time
-    if (SPLIT) {
+    if (SPLIT && cur.unit >= 0) {
       // raw fp32 partials: lane = row (l & 15) of each 16-row block, 4 consecutive columns per nj -> 16-byte stores
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       int le = lane;
       asm volatile("" : "+v"(le));
-      float* wsp = p.ws + (int64_t)(cur.slice * p.batch + cur.b) * p.ws_bs;
+      if (p.ws_ld == 0) {
+        // compact: this unit's own 256 x 256 fp32 tile (rows beyond M / columns beyond N hold zeros-times-garbage: never read)
+        float* wsp = p.ws + (int64_t)cur.unit * 65536 + (g * 128 + (le & 15)) * 256 + wc * 64 + (le >> 4) * 4;
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-        const int m = cur.m0 + g * 128 + mi * 16 + (le & 15);
+        for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) {
-          const int n = cur.n0 + wc * 64 + nj * 16 + (le >> 4) * 4;
-          if (m < p.M && n + 3 < p.N) {
-            *reinterpret_cast<f32x4*>(wsp + (int64_t)m * p.ws_ld + n) = acc[mi][nj];
-          } else if (m < p.M) {   // ragged right edge (fp32-output mode only: the split path has N % 8 == 0)
+          for (int nj = 0; nj < 4; ++nj) *reinterpret_cast<f32x4*>(wsp + mi * 16 * 256 + nj * 16) = acc[mi][nj];
+      } else {
+        float* wsp = p.ws + (int64_t)cur.b * p.ws_bs;     // fp32-output mode
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) wsp[(int64_t)m * p.ws_ld + n + e] = acc[mi][nj][e];
+        for (int mi = 0; mi < 8; ++mi) {
+          const int m = cur.m0 + g * 128 + mi * 16 + (le & 15);
+#pragma unroll
+          for (int nj = 0; nj < 4; ++nj) {
+            const int n = cur.n0 + wc * 64 + nj * 16 + (le >> 4) * 4;
+            if (m < p.M && n + 3 < p.N) {
+              *reinterpret_cast<f32x4*>(wsp + (int64_t)m * p.ws_ld + n) = acc[mi][nj];
+            } else if (m < p.M) {   // ragged right edge
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) wsp[(int64_t)m * p.ws_ld + n + e] = acc[mi][nj][e];
+            }
           }
         }
       }
     } else {
       tile_epilogue<EPI, FP8, QKN, (FP8 ? 1 : 2)>(acc, p, cur.m0, cur.n0, cur.b, g, wc, lane, stg,
-                                                  smem + PP_STG + (wave ^ 1) * PP_STG_WAVE, tfx_stamp);
+                                                  smem + PP_STG + (wave ^ 1) * PP_STG_WAVE, tfx_stamp, cur.second);
     }
 #ifdef TFX_BENCH
     TFX_STAMP(2);
@@ -1007,18 +1049,30 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #undef PP_TILE_W
 }
 
-// Second pass of the split-K path: C = epi(sum_s P[s] + bias), 8 columns per thread, slices summed in order.
+// Second pass of the K-sliced units: C = epi(sum_s P[s] + bias) over the tail tiles, 8 columns per thread, slices summed in order.
+// Thread i -> (tail tile i / 8192, row (i / 32) % 256, columns 8 (i % 32) .. + 8) of ws [slice][tail tile][256][256].
 template <int EPI, bool FP8 = false>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
-  const int64_t chunks_per_row = p.N >> 3;
+__global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams p) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)p.batch * p.M * chunks_per_row) return;
-  const int64_t row = i / chunks_per_row;       // b * M + m
-  const int n = (int)(i - row * chunks_per_row) * 8;
-  const int b = (int)(row / p.M);
-  const int m = (int)(row - (int64_t)b * p.M);
-  const int64_t slice_stride = (int64_t)p.batch * p.M * p.N;
-  const float* src = p.ws + row * p.N + n;
+  const int TT = p.batch * p.tail_r;
+  const int tt = (int)(i >> 13);
+  if (tt >= TT) return;
+  const int row = (int)(i >> 5) & 255, c8 = (int)i & 31;
+  // the tile's coordinates: the last tail_r positions of the sample's (grouped) tile order, as gemm8pp_kernel::coords
+  const int per_batch = p.tm * p.tn;
+  const int b = tt / p.tail_r;
+  int idx = per_batch - p.tail_r + (tt - b * p.tail_r);
+  const int GM = p.gm;
+  const int grp = idx / (GM * p.tn);
+  const int first_m = grp * GM;
+  const int gsz = min(GM, p.tm - first_m);
+  idx -= grp * GM * p.tn;
+  const int m = (first_m + idx % gsz) * 256 + row;
+  const int n = (idx / gsz) * 256 + c8 * 8;
+  if (m >= p.M || n >= p.N) return;
+  const bool second = (m - row) < p.split_row;
+  const int64_t slice_stride = (int64_t)TT * 65536;
+  const float* src = p.ws + (int64_t)tt * 65536 + row * 256 + c8 * 8;
   float v[8];
   {
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
@@ -1037,9 +1091,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = (v[e] * sa) * w0[e]; v[4 + e] = (v[4 + e] * sa) * w1[e]; }
   }
-  if (p.bias) {
+  const bf16_t* bias = second ? p.bias2 : p.bias;
+  if (bias) {
     float bs[8];
-    unpack8(*reinterpret_cast<const u32x4*>(p.bias + n), bs);
+    unpack8(*reinterpret_cast<const u32x4*>(bias + n), bs);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += bs[e];
   }
@@ -1049,7 +1104,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
   if (EPI == EPI_BIAS_GATE_RES) {
     float gt[8];
-    unpack8(*reinterpret_cast<const u32x4*>(p.gate + b * p.gate_bs + n), gt);
+    unpack8(*reinterpret_cast<const u32x4*>((second ? p.gate2 : p.gate) + b * p.gate_bs + n), gt);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = gt[e] * round_bf(v[e]);
   }
@@ -1066,7 +1121,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-static int g_gemm_splitk = 1;     // 0 disables the split-K path (A/B knob)
+static int g_gemm_splitk = 2;     // K-sliced work units: 0 never (A/B knob), 1 only GEMMs with fewer tiles than CUs (round 3), 2 also the last round of small GEMMs
 void set_gemm_splitk(int v) { g_gemm_splitk = v; }
 static int g_gemm_place = 2;      // request placement of the persistent kernel (bench knob, see gemm8pp_kernel)
 void set_gemm_place(int v) { g_gemm_place = v; }
@@ -1098,7 +1153,10 @@ static GemmParams make_params(const GemmArgs& a) {
   p.cstride = a.conv_stride; p.cup = a.conv_up_shift; p.cpad = a.conv_pad_lo; p.zero = (const bf16_t*)a.zero_page;
   p.csh = a.conv_cin == 8 ? 3 : a.conv_cin == 16 ? 4 : a.conv_cin == 32 ? 5 : 0;
   p.a_scale = a.a_scale; p.as_bs = a.a_scale_bstride; p.w_scale = a.w_scale;
-  p.ws = nullptr; p.sk = 1; p.ws_ld = a.N; p.ws_bs = (int64_t)a.M * a.N;
+  p.ws = nullptr; p.sk = 1; p.u_full = 0; p.tail_r = 0; p.ws_ld = 0; p.ws_bs = 0;
+  p.split_row = a.split_row; p.w2_off = 0;
+  p.bias2 = (const bf16_t*)a.bias2; p.gate2 = (const bf16_t*)a.gate2; p.nq_w2 = (const bf16_t*)a.qkn_wq2; p.nk_w2 = (const bf16_t*)a.qkn_wk2;
+  if (a.split_row > 0) p.w2_off = (uint32_t)((const char*)a.W2 - (const char*)a.W);
   p.nq_w = (const bf16_t*)a.qkn_wq; p.nk_w = (const bf16_t*)a.qkn_wk; p.rope_cs = a.qkn_rope_cs; p.rope_pos0 = a.qkn_pos0;
   p.nq0 = a.qkn_q0; p.nq1 = a.qkn_q1; p.nk0 = a.qkn_k0; p.nk1 = a.qkn_k1; p.n_eps = a.qkn_eps;
   return p;
@@ -1131,6 +1189,29 @@ static bool persist_ok(const GemmParams& p) {
   return p.cin == 0 && p.K % 128 == 0 &&
          ((int64_t)(p.batch - 1) * p.a_bs + (int64_t)p.tm * 256 * p.lda) * 2 < (1ll << 32) - 65536 &&
          (int64_t)p.tn * 256 * p.ldw * 2 < (1ll << 32) - 65536;
+}
+
+// Which work units of a persistent-kernel GEMM are K-sliced (GemmParams::sk / u_full / tail_r).  T < grid: every tile, so that
+// (tile, slice) units fill the chip.  Otherwise, for SMALL GEMMs only (fewer than 8 rounds of the chip -- beyond that the partly
+// filled round is under a ninth of the time and the fp32 round trip of its tiles costs what the slicing saves): the R = T mod grid
+// tiles of the last round when one short round of slices can take them (R c <= grid), the same tile positions in every batch
+// sample (identical samples keep identical bits).  Slices keep an even number >= 8 of K-tiles; ws: 256 KiB per unit.
+struct SlicePlan { int sk, u_full, tail_r; };
+static SlicePlan plan_slices(const GemmParams& p, int grid, int nt, void* ws, int64_t ws_bytes) {
+  SlicePlan pl{1, 0, 0};
+  if (!g_gemm_splitk || !ws || p.N % 8) return pl;
+  const int per_batch = p.tm * p.tn, T = p.batch * per_batch;
+  auto ok = [&](int units, int c) { return units * c <= grid && nt % (2 * c) == 0 && nt / c >= 8 && (int64_t)units * c * 262144 <= ws_bytes; };
+  if (T < grid) {
+    for (int c : {8, 6, 4, 3, 2})
+      if (ok(T, c)) return SlicePlan{c, 0, per_batch};
+    return pl;
+  }
+  const int R = T % grid;
+  if (R == 0 || T / grid >= 8 || R % p.batch || g_gemm_splitk < 2) return pl;
+  for (int c : {4, 3, 2})
+    if (ok(R, c)) return SlicePlan{c, T - R, R / p.batch};
+  return pl;
 }
 
 #ifdef TFX_BENCH
@@ -1184,15 +1265,12 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
     }
     const bool prof = prof_on(st);
     if (prof) prof_begin(0, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
-    // Fewer tiles than CUs: split K so that (tile, slice) units fill the chip (variant 1 = auto only; the caller must
-    // have passed a workspace for the fp32 partials).  Slices keep an even number >= 8 of K-tiles.
-    const int T = p.batch * p.tm * p.tn, nt = p.K >> 6;
-    int sk = 1;
-    if (variant == 1 && g_gemm_splitk && ws && T < grid && p.N % 8 == 0) {
-      for (int c = 4; c >= 2; --c)
-        if (T * c <= grid && nt % (2 * c) == 0 && nt / c >= 8 && (int64_t)c * p.batch * p.M * p.N * 4 <= ws_bytes) { sk = c; break; }
-    }
+    // K-sliced units (variant 1 = auto only; the caller must have passed a workspace for the fp32 partials): plan_slices
+    const int nt = p.K >> 6;
+    const SlicePlan pl = variant == 1 ? plan_slices(p, grid, nt, ws, ws_bytes) : SlicePlan{1, 0, 0};
+    const int sk = pl.sk;
     if (p.rope_cs) {   // fused q / k RMSNorm + RoPE epilogue: EPI_BIAS_GELU instantiation only (plain bias = gelu_from >= N)
+      if (sk > 1) return fail("gemm: the q/k norm + RoPE epilogue cannot ride on a K-sliced launch (gemm_qkn_ok)");
       if (EPI != EPI_BIAS_GELU) return fail("gemm: the q/k norm + RoPE epilogue rides on the bias(+GELU) epilogue");
       static bool attrq = false;
       const void* fn = (const void*)gemm8pp_kernel<EPI_BIAS_GELU, 2, false, false, true>;
@@ -1208,19 +1286,23 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
     } else if (sk > 1) {
       static bool attr = false;
       if (!attr) {
-        const void* fn = (const void*)gemm8pp_kernel<EPI_BIAS, 2, false, true>;
-        hipFuncAttributes fa;
-        (void)hipFuncGetAttributes(&fa, fn);
-        (void)hipGetLastError();
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess)
-          return fail("gemm: cannot raise dynamic LDS limit for the split-K kernel");
+        const void* fns[2] = {(const void*)gemm8pp_kernel<EPI_BIAS, 2, false, true>, (const void*)gemm8pp_kernel<EPI, 2, false, true>};
+        for (const void* fn : fns) {
+          hipFuncAttributes fa;
+          (void)hipFuncGetAttributes(&fa, fn);
+          (void)hipGetLastError();
+          if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess)
+            return fail("gemm: cannot raise dynamic LDS limit for the K-sliced kernel");
+        }
         attr = true;
       }
       GemmParams ps = p;
-      ps.ws = (float*)ws; ps.sk = sk;
-      gemm8pp_kernel<EPI_BIAS, 2, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(ps);
-      const int64_t chunks = (int64_t)p.batch * p.M * (p.N >> 3);
-      splitk_reduce_kernel<EPI><<<(unsigned)((chunks + 255) / 256), 256, 0, st>>>(ps);
+      ps.ws = (float*)ws; ps.sk = sk; ps.u_full = pl.u_full; ps.tail_r = pl.tail_r;
+      if (pl.u_full == 0)     // every tile sliced: no whole-tile epilogue in the stream, the bias-only instantiation serves every EPI
+        gemm8pp_kernel<EPI_BIAS, 2, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(ps);
+      else
+        gemm8pp_kernel<EPI, 2, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(ps);
+      tail_reduce_kernel<EPI><<<(unsigned)(p.batch * pl.tail_r * 32), 256, 0, st>>>(ps);
     } else if (g_gemm_place == 1) {
       gemm8pp_kernel<EPI, 1><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
     } else {
@@ -1268,6 +1350,7 @@ int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
   if (a.epilogue == EPI_BIAS_GATE_RES && (!a.gate || !a.res)) return fail("gemm: gate/res pointers required");
   if (a.epilogue == EPI_BIAS_RES && !a.res) return fail("gemm: res pointer required");
   const GemmParams p = make_params(a);
+  if (a.split_row > 0 && !((variant == 1 || variant == 3) && gemm_rowsplit_ok(a))) return fail("gemm: row-split weights need the persistent MFMA kernel");
   switch (a.epilogue) {
     case EPI_BIAS: return launch_variant<EPI_BIAS>(p, variant, a.workspace, a.workspace_bytes, st);
     case EPI_BIAS_GELU: return launch_variant<EPI_BIAS_GELU>(p, variant, a.workspace, a.workspace_bytes, st);
@@ -1277,7 +1360,22 @@ int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
   return fail("gemm: unknown epilogue %d", a.epilogue);
 }
 
+// Row-split weights need the persistent kernel (the tile origin decides the weight set), split_row on a tile boundary, the second
+// weight matrix behind the first inside one 32-bit descriptor range, and both bias / gate pointers (or neither).
+bool gemm_rowsplit_ok(const GemmArgs& a) {
+  if (a.split_row <= 0 || a.split_row % 256 || a.split_row >= a.M || !fast_ok(a) || a.conv_cin > 0 || !a.W2) return false;
+  const GemmParams p = make_params(a);
+  if (!persist_ok(p)) return false;
+  const int64_t d = (const char*)a.W2 - (const char*)a.W;
+  if (d <= 0 || d % 16 || d + (int64_t)p.tn * 256 * p.ldw * 2 >= (1ll << 32) - 65536) return false;
+  if ((a.bias == nullptr) != (a.bias2 == nullptr) || (uintptr_t)a.bias2 % 8) return false;
+  if (a.epilogue == EPI_BIAS_GATE_RES && (!a.gate2 || (uintptr_t)a.gate2 % 8)) return false;
+  if (a.qkn_rope_cs && (!a.qkn_wq2 || !a.qkn_wk2)) return false;
+  return true;
+}
+
 int gemm_bf16(const GemmArgs& a, hipStream_t st) {
+  if (a.split_row > 0 && !gemm_rowsplit_ok(a)) return fail("gemm: shape / layout not eligible for row-split weights (gemm_rowsplit_ok)");
   if (a.qkn_rope_cs && !gemm_qkn_ok(a)) return fail("gemm: shape not eligible for the fused q/k norm + RoPE epilogue");
   return gemm_bf16_variant(a, fast_ok(a) ? 1 : 0, st);
 }
@@ -1295,7 +1393,8 @@ bool gemm_qkn_ok(const GemmArgs& a) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-  return (int64_t)p.batch * p.tm * p.tn >= (cus & ~7);
+  // ... and no K-sliced units in the launch the auto path would make with this workspace (tail_reduce_kernel has no such epilogue)
+  return plan_slices(p, cus & ~7, p.K >> 6, a.workspace, a.workspace_bytes).sk == 1;
 }
 
 // ---- fp32 output (raw accumulators, no epilogue): C [batch][M, N] floats with row stride ldc.  The score GEMM of the
@@ -1308,7 +1407,7 @@ int gemm_bf16_f32out(const GemmArgs& a, hipStream_t st) {
   if (a.conv_cin > 0) return fail("gemm_f32out: no convolution mode");
   if ((uintptr_t)a.C % 16 || a.ldc % 4 || a.c_bstride % 4) return fail("gemm_f32out: C must be 16-byte aligned, ldc / c_bstride multiples of 4");
   GemmParams p = make_params(a);
-  p.ws = (float*)a.C; p.sk = 1; p.ws_ld = a.ldc; p.ws_bs = a.c_bstride;
+  p.ws = (float*)a.C; p.sk = 1; p.u_full = 0; p.tail_r = p.tm * p.tn; p.ws_ld = a.ldc; p.ws_bs = a.c_bstride;   // every tile a raw-store unit
   GemmArgs chk = a;
   chk.C = const_cast<void*>(a.A);   // alignment of the fp32 C was checked above; the remaining fast-path conditions are operand-side
   chk.ldc = 8; chk.c_bstride = 8;
@@ -1358,17 +1457,12 @@ static int launch_fp8(const GemmParams& p, void* ws, int64_t ws_bytes, hipStream
   const bool prof = prof_on(st);
   if (prof) prof_begin(2, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
   const int T = p.batch * p.tm * p.tn, nt = p.K >> 7;   // 128-byte K-tiles of e4m3
-  int sk = 1;
-  if (g_gemm_splitk && ws && T < grid) {
-    for (int c = 4; c >= 2; --c)
-      if (T * c <= grid && nt % (2 * c) == 0 && nt / c >= 8 && (int64_t)c * p.batch * p.M * p.N * 4 <= ws_bytes) { sk = c; break; }
-  }
-  if (sk > 1) {
+  SlicePlan pl = T < grid ? plan_slices(p, grid, nt, ws, ws_bytes) : SlicePlan{1, 0, 0};   // fp8: whole-GEMM slicing only
+  if (pl.sk > 1) {
     GemmParams ps = p;
-    ps.ws = (float*)ws; ps.sk = sk;
+    ps.ws = (float*)ws; ps.sk = pl.sk; ps.u_full = 0; ps.tail_r = pl.tail_r;
     gemm8pp_kernel<EPI_BIAS, 2, true, true><<<grid, 512, PP_LDS_TOTAL, st>>>(ps);
-    const int64_t chunks = (int64_t)p.batch * p.M * (p.N >> 3);
-    splitk_reduce_kernel<EPI, true><<<(unsigned)((chunks + 255) / 256), 256, 0, st>>>(ps);
+    tail_reduce_kernel<EPI, true><<<(unsigned)(p.batch * pl.tail_r * 32), 256, 0, st>>>(ps);
   } else {
     gemm8pp_kernel<EPI, 2, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
   }

@@ -54,9 +54,16 @@ struct GemmArgs {
   // (cos, sin) pairs qkn_rope_cs [tokens][64][2] fp32 at token qkn_pos0 + row; == rmsnorm_rope() applied afterwards
   const void* qkn_wq = nullptr; const void* qkn_wk = nullptr; const float* qkn_rope_cs = nullptr;
   int qkn_pos0 = 0, qkn_q0 = 0, qkn_q1 = 0, qkn_k0 = 0, qkn_k1 = 0; float qkn_eps = 1e-6f;
-  // optional scratch for split-K (fp32 partials); without it few-tile GEMMs run unsplit
+  // optional scratch for the K-sliced units (fp32 partials, 256 KiB per unit); without it few-tile GEMMs run unsplit
   void* workspace = nullptr; int64_t workspace_bytes = 0;
+  // row-split weights (persistent MFMA kernel only; split_row a multiple of 256, 0 = off): tiles whose first row inside the batch
+  // sample is below split_row use W2 / bias2 / gate2 / qkn_wq2 / qkn_wk2 instead of W / bias / gate / qkn_wq / qkn_wk -- the text and
+  // image projections of a double block in ONE launch over the joint [text | image] rows.  W2 must lie behind W within 4 GiB
+  // (one buffer descriptor): the engine allocates the pair as one tensor.
+  int split_row = 0;
+  const void* W2 = nullptr; const void* bias2 = nullptr; const void* gate2 = nullptr; const void* qkn_wq2 = nullptr; const void* qkn_wk2 = nullptr;
 };
+bool gemm_rowsplit_ok(const GemmArgs& a);                       // can this (split_row > 0) GEMM run as one launch?
 void set_gemm_group_m(int gm);
 void set_gemm_place(int v);
 void set_gemm_splitk(int v);

@@ -97,15 +97,19 @@ class FluxTransformer2DModel:
         lin("x_embedder", D, c.in_channels)
         lin("proj_out", self.out_channels, D)
         lin("mod", self.mod_len, D)
+        def lin_pair(img, txt, o, i):
+            # the image- and text-stream Linear of a double block side by side in ONE allocation ([img; txt]): a single buffer
+            # descriptor reaches both, which is what lets the engine run the two projections as one launch over the joint
+            # [text | image] rows (row-split weights, tfx_dit_forward); every other user sees two ordinary tensors
+            wp, bp = torch.empty(2, o, i, dtype=BF16, device=device), torch.empty(2, o, dtype=BF16, device=device)
+            self.w[img + ".w"], self.w[img + ".b"] = wp[0], bp[0]
+            self.w[txt + ".w"], self.w[txt + ".b"] = wp[1], bp[1]
+
         for i in range(c.num_layers):
-            for n in ("qkv_img", "qkv_txt"):
-                lin(f"d{i}.{n}", 3 * D, D)
-            for n in ("out_img", "out_txt"):
-                lin(f"d{i}.{n}", D, D)
-            for n in ("ff1_img", "ff1_txt"):
-                lin(f"d{i}.{n}", 4 * D, D)
-            for n in ("ff2_img", "ff2_txt"):
-                lin(f"d{i}.{n}", D, 4 * D)
+            lin_pair(f"d{i}.qkv_img", f"d{i}.qkv_txt", 3 * D, D)
+            lin_pair(f"d{i}.out_img", f"d{i}.out_txt", D, D)
+            lin_pair(f"d{i}.ff1_img", f"d{i}.ff1_txt", 4 * D, D)
+            lin_pair(f"d{i}.ff2_img", f"d{i}.ff2_txt", D, 4 * D)
             for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
                 self.w[f"d{i}.{n}"] = torch.empty(128, dtype=BF16, device=device)
         for j in range(c.num_single_layers):
