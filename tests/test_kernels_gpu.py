@@ -405,6 +405,32 @@ def test_attention_score_bound_selects_the_reference_free_stream(ops):
         close(ops.attention(q2.cuda(), k2.cuda(), v2.cuda(), score_bound=30.0), r2.to(BF), max_rel=2e-2, mae_rel=4e-3)
 
 
+@pytest.mark.parametrize("B,H,N", [(2, 24, 2000), (16, 24, 50), (3, 24, 1100), (1, 24, 4608)])
+def test_attention_persistent_form_is_bit_identical_to_one_workgroup_per_item(ops, B, H, N):
+    """Round 4: with more (b, h, q-tile) items than CUs the default kernel runs as ONE workgroup per CU walking its items, the next
+    item's Q rows and first K / V tile requested inside the current item's last tile (attention_persistent, on by default).  Same
+    arithmetic per item in the same order: bit-identical to the one-workgroup-per-item launch, for ragged N, single-tile items
+    (the first tile is also the last), with and without the reference-free stream, and against fp32 SDPA on sampled heads."""
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    q, k, v = (torch.randn(B, N, H * 128, generator=g).to(BF).cuda() for _ in range(3))
+    outs = {}
+    try:
+        for bound in (0.0, 30.0):
+            for pers in (1, 0):
+                ops.set_option("attention_persistent", pers)
+                outs[(bound, pers)] = ops.attention(q, k, v, score_bound=bound)
+            assert torch.equal(outs[(bound, 1)], outs[(bound, 0)]), bound
+            assert torch.equal(ops.attention(q, k, v, score_bound=bound), outs[(bound, 0)])      # and again (determinism)
+    finally:
+        ops.set_option("attention_persistent", 1)
+    for (bi, hi) in ((0, 0), (B - 1, H - 1), (B // 2, 7)):
+        sl = slice(hi * 128, (hi + 1) * 128)
+        ref = torch.nn.functional.scaled_dot_product_attention(q[bi:bi + 1, :, sl].float()[:, None], k[bi:bi + 1, :, sl].float()[:, None],
+                                                               v[bi:bi + 1, :, sl].float()[:, None])[:, 0]
+        for o in outs.values():
+            close(o[bi:bi + 1, :, sl], ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+
+
 def test_attention_online_softmax_rescale_branch(ops):
     """A key far above the rest in a LATE tile forces the running-max rescale of the accumulated output."""
     B, H, N = 1, 1, 256

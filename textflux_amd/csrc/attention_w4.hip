@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
                                                          const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq, int64_t ldk,
                                                          int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
                                                          int64_t o_bs, int H, int N, int nqb, float scale_log2e, int nfull,
-                                                         int nparts, int nsplit, int xsplit, float* part) {
+                                                         int nparts, int nsplit, int xsplit, float* part, int T_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool LV = MODE == 1 || MODE == 2, LZ = MODE >= 2, NOREF = MODE == 4, FT = LV || NOREF;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -183,8 +183,24 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   // in the dispatch order, so its K / V stay L2-resident among them.  (Measured alternatives: the last q-tile of EVERY head --
   // re-streams all K / V from HBM at the end, no gain; whole heads -- nfull is no longer a multiple of the CU count, some CUs run
   // three halves in a row, 1.4 % slower than no split.)
+  // PERSISTENT form (T_items > 0; round 4): one workgroup per CU walks its XCD's contiguous range of the T_items (b, h, q-tile)
+  // items.  A fresh workgroup costs ~10 us before its first tile and after its last (dispatch, two dependent memory round trips
+  // for Q and the first K / V tiles, the output: tools/attn_fixed_cost.py, 10 % of a 72-tile item); here the next item's Q rows and
+  // its first K / V tile are requested inside the current item's last tile and wait in registers, so that only the output
+  // of an item and the conversion of the next Q stand between two items' MFMA streams.
   int kpart = -1, ptile = 0, qblk, h, b;
-  if (nsplit > 1) {
+  int item = 0, item_step = 0, item_end = 0;
+  if (T_items > 0) {
+    const int nwg = gridDim.x, q = T_items >> 3, r = T_items & 7, xcd = bid & 7, slot = bid >> 3;
+    const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, xc = q + (xcd < r ? 1 : 0);
+    if (slot >= xc) return;
+    item = xs + slot;
+    item_step = nwg >> 3;
+    item_end = xs + xc;
+    qblk = item % nqb;
+    h = (item / nqb) % H;
+    b = item / (nqb * H);
+  } else if (nsplit > 1) {
     const int fpad = (nfull + 7) & ~7, pf = H * nqb - xsplit;      // pf: unsplit pairs per sample
     int pair;
     if (bid < fpad) {
@@ -211,6 +227,13 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     h = bid % H;
     b = bid / H;
   }
+  bf16x8 qn[2][8];               // persistent form: the NEXT item's Q rows (raw), requested inside this item's last tile
+  bool have_pref = false;        // ... and whether qn / kreg / vreg hold this item's Q rows / first K, V tile already
+  u32x4 kreg[4], vreg[4];        // staging registers: thread t moves the 16-byte chunks (row t / 16 + 16 i, chunk t % 16), i = 0..3, of a tile's K and V
+  for (;;) {                     // one pass per item (exactly one in the non-persistent form)
+  const bool has_next = item + item_step < item_end;      // (false in the non-persistent form: all three are 0)
+  const int item2 = item + item_step;
+  const int qblk2 = item2 % nqb, h2 = (item2 / nqb) % H, b2 = item2 / (nqb * H);
   const bf16_t* Qb = Q + b * q_bs + h * W4_HD;
   const bf16_t* Kb = Kp + b * k_bs + h * W4_HD;   // (advanced to the first key of a split range below)
   const bf16_t* Vb = Vp + b * v_bs + h * W4_HD;
@@ -234,9 +257,25 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   for (int qb = 0; qb < 2; ++qb) {
     qrow[qb] = qblk * 256 + wave * 64 + qb * 32 + l31;
     const int rc = qrow[qb] < N ? qrow[qb] : N - 1;
+    if (have_pref) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)rc * ldq + s * 16 + hi * 8);
+      for (int s = 0; s < 8; ++s) qf[qb][s] = qn[qb][s];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)rc * ldq + s * 16 + hi * 8);
+    }
   }
+  // the next item's Q rows -> qn (called from this item's last tile)
+  auto load_qn = [&]() __attribute__((always_inline)) {
+    const bf16_t* Qb2 = Q + b2 * q_bs + h2 * W4_HD;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int r2 = qblk2 * 256 + wave * 64 + qb * 32 + l31;
+      const int rc = r2 < N ? r2 : N - 1;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) qn[qb][s] = *reinterpret_cast<const bf16x8*>(Qb2 + (int64_t)rc * ldq + s * 16 + hi * 8);
+    }
+  };
   __builtin_amdgcn_sched_barrier(0);
   auto convert_q = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -250,27 +289,32 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   };
 
   const int nkv = (Nk + W4_KV - 1) / W4_KV;
-  // ---- staging: thread t moves the 16-byte chunks (row t / 16 + 16 i, chunk t % 16), i = 0..3, of a tile's K and V
-  u32x4 kreg[4], vreg[4];
+  // ---- staging (kreg / vreg, declared in front of the item loop)
   // buffer descriptors sized to this head's N valid rows: a request past them (the rows of a ragged last tile, whole tiles
   // requested past the end of the sequence) returns zeros and moves nothing -- the scores of such keys are masked anyway,
   // and their zero V rows meet zero weights.  (The range check covers VGPR + SGPR offset: tools/ubench/buffer_range.hip.)
   const int ldk2 = (int)ldk * 2, ldv2 = (int)ldv * 2;
   const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)((uint32_t)(Nk - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
   const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((uint32_t)(Nk - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
+  // the next item's K / V (persistent form; its first tile is requested by this item's LAST staging step instead of a tile past the end)
+  const auto rsK2 = __builtin_amdgcn_make_buffer_rsrc((void*)(Kp + b2 * k_bs + h2 * W4_HD), 0, (int)((uint32_t)(N - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
+  const auto rsV2 = __builtin_amdgcn_make_buffer_rsrc((void*)(Vp + b2 * v_bs + h2 * W4_HD), 0, (int)((uint32_t)(N - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
   // piece i (rows t / 16 + 16 i) of tile j: global -> registers.  Rows are clamped to the last valid key (a no-op on full
   // tiles), tiles to the last tile (the pipeline requests up to two tiles past the end; nobody reads those buffers)
   // tile j: global -> registers, piece i = rows t / 16 + 16 i.  Full tiles: one per-lane offset (rebuilt per burst: as a loop
   // invariant it would pin two registers) and the piece in the scalar offset; the last tile of a ragged N clamps its rows
   // piece i (rows t / 16 + 16 i) of tile j, K or V side: global -> registers.  ko / vo: per-lane byte offset of (row t / 16,
   // chunk t % 16); the tile and the piece go into the scalar offset
+  // requests go through rsKs / rsVs: this item's descriptors, except in the last tile of the persistent form, whose staging step
+  // requests the NEXT item's first tile (set once per tile: a select per request costs 32 scalar instructions per tile, 3.5 %)
+  auto rsKs = rsK, rsVs = rsV;
   auto load_piece = [&](int j, int ko, int vo, auto Ic, bool k_side) __attribute__((always_inline)) {
     constexpr int i = decltype(Ic)::value;
     if (W4_ABL & 32) j = 0;          // timing ablation: every request hits the same (cache-resident) tile
     if (k_side)
-      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, ko, (j * W4_KV + 16 * i) * ldk2, 0));
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsKs, ko, (j * W4_KV + 16 * i) * ldk2, 0));
     else
-      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, vo, (j * W4_KV + 16 * i) * ldv2, 0));
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsVs, vo, (j * W4_KV + 16 * i) * ldv2, 0));
   };
   auto stage_offsets = [&](int& ko, int& vo) __attribute__((always_inline)) {
     int te = tid;
@@ -344,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   // ---- prologue: tiles 0 and 1 in LDS, tile 2 requested; K fragments of (tile 0, key block 0); S(0)
   // Tiles 0 AND 1 are requested together (tile 1 into the sixteen registers of the K / V fragments, idle until the first
   // fragment read) and the Q conversion runs under their flight: one memory round trip in front of the first MFMA, not three
-  load_tile(0);
+  if (!have_pref) load_tile(0);                   // (persistent form, later items: requested inside the previous item's last tile)
   u32x4 k1[4], v1[4];
   {
     int ko, vo;
@@ -762,17 +806,25 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     }
   };
 
+  const int j_rag = (Nk & (W4_KV - 1)) ? nkv - 1 : -1;          // the tile whose key blocks reach past N
+  const int j_last = has_next ? nkv - 1 : -1;                  // persistent form: the tiles that carry the next item's requests
+  const int j_qn = has_next ? (nkv > 1 ? nkv - 2 : 0) : -1;
   // one 64-key tile j out of ring buffer B (compile-time: every fragment address is a per-lane base plus an immediate)
   auto tile = [&](int j, auto Bc, auto FIRSTc) __attribute__((always_inline)) {
     constexpr int B = decltype(Bc)::value, NB = (B + 1) % 3, WB = (B + 2) % 3;
     constexpr int FIRST = decltype(FIRSTc)::value;
-    const bool rag = (j == nkv - 1) && (Nk & (W4_KV - 1));
+    // (one scalar compare each against tile indices fixed in front of the loop: with one wave per SIMD every scalar instruction of
+    // the tile loop is issue time)
+    const bool rag = j == j_rag;
+    const bool last = j == j_last;                  // persistent form: this tile's staging step requests the NEXT item's first tile
+    if (__builtin_expect_with_probability(j == j_qn, 0, 1.0)) load_qn();   // ... and the tile before, its Q rows
     // (kb0, q0): S(kb0, q1);  pending (tile j-1: kb1, q1);  reload kf <- K(j) kb1, vf <- V(j) kb0
     step(IC<0>{}, IC<!FIRST>{}, IC<FIRST>{}, IC<B * W4_KT + 32 * W4_KROW>{}, IC<B * W4_VT>{}, IC<0>{}, 0, rag, j * W4_KV);
     // (kb0, q1): S(kb1, q0);  pending (kb0, q0);  + staging: tile j + 2 (requested one tile ago) goes into the buffer tile j - 1
     // left before the last barrier, and each register is refilled with its piece of tile j + 3 right behind its write -- four
     // steps (> 1 us) before it is needed: with one wave per SIMD nothing else runs while a wave waits for memory
-    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<1 + 4 * WB>{}, j + 3, rag, j * W4_KV);
+    if (__builtin_expect_with_probability(last, 0, 1.0)) { rsKs = rsK2; rsVs = rsV2; }
+    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<1 + 4 * WB>{}, last ? 0 : j + 3, rag, j * W4_KV);
     // (kb1, q0): S(kb1, q1);  pending (kb0, q1);  reload kf <- K(j+1) kb0, vf <- V(j) kb1
     step(IC<0>{}, IC<1>{}, IC<0>{}, IC<NB * W4_KT>{}, IC<B * W4_VT + 2 * 16 * 256>{}, IC<0>{}, 0, rag, j * W4_KV + 32);
     // (kb1, q1): S(tile j+1: kb0, q0);  pending (kb1, q0)
@@ -857,6 +909,11 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OROW + ch * 16);
     if (row0 + row < N) *reinterpret_cast<u32x4*>(Ob + (int64_t)(row0 + row) * ldo + ch * 8) = v;
   }
+  if (!has_next) break;
+  item = item2; b = b2; h = h2; qblk = qblk2;
+  have_pref = true;
+  __syncthreads();                                // every wave has read its output tile out of LDS: the ring buffers are free for the next item
+  }
 }
 
 // Finishes the q-tiles of a tail split: O = sum_r o_r 2^(m_r - m) / sum_r l_r 2^(m_r - m), m = max_r m_r (exp2 domain, the
@@ -925,6 +982,19 @@ int attention_w4_prepare(hipStream_t st) {
   return w4_scratch(st, true) ? 0 : fail("attention: cannot allocate the tail-split scratch");
 }
 
+static int g_w4_persist = 1;     // tfx_set_option attention_persistent: 0 = one workgroup per (b, h, q-tile) item (round 3)
+void set_attention_persistent(int v) { g_w4_persist = v; }
+static int g_w4_grid() {         // workgroups of the persistent form: one per CU, a whole number per XCD
+  static int grid = 0;
+  if (!grid) {
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    grid = cus & ~7;
+  }
+  return grid;
+}
+
 template <int MODE>
 static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, int nfull, int nparts, int nsplit, int xsplit, float* part) {
   static bool attr_set = false;
@@ -941,9 +1011,15 @@ static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, 
       return fail("attention: cannot raise dynamic LDS limit to %d bytes", ATT_LDS_W4);
     attr_set = true;
   }
+  // persistent form: one workgroup per CU over all (b, h, q-tile) items, when there are more items than CUs and no tail split
+  int T_items = 0;
+  if (g_w4_persist && nsplit == 1 && (int)grid > g_w4_grid()) {
+    T_items = (int)grid;
+    grid = (unsigned)g_w4_grid();
+  }
   attn_w4_kernel<MODE><<<grid, 256, ATT_LDS_W4, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
                                                        a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
-                                                       a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, part);
+                                                       a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, part, T_items);
   return 0;
 }
 

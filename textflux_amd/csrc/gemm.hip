@@ -790,12 +790,25 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   const int per_batch = p.tm * p.tn;
   const int T1 = p.batch * per_batch;               // tiles
   const int T = SPLIT ? p.u_full + p.batch * p.tail_r * p.sk : T1;             // work units
-  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
-  const int q8 = T >> 3, r8 = T & 7;
-  const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int xcnt = q8 + (xcd < r8 ? 1 : 0);
-  int it = blockIdx.x >> 3;
-  if (it >= xcnt) return;
+  // Whole tiles and (tile, slice) units cost differently, so the two kinds are dealt out separately: XCD x owns a contiguous range
+  // of EACH, its blocks stride through the whole tiles first and through the slice units after (every block ends up with its
+  // share of both: 588 tiles = 512 whole + 76 x 3 slices gives each block 2 whole tiles and most of them one short unit).
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, bi = blockIdx.x >> 3;
+  const int len0 = SPLIT ? p.u_full : T, len1 = T - len0;
+  auto xrange = [&](int len, int& start, int& cnt) {
+    const int q8 = len >> 3, r8 = len & 7;
+    start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    cnt = q8 + (xcd < r8 ? 1 : 0);
+  };
+  int start0, cnt0, start1 = 0, cnt1 = 0;
+  xrange(len0, start0, cnt0);
+  if (SPLIT) xrange(len1, start1, cnt1);
+  const int n0u = bi < cnt0 ? (cnt0 - bi + per_xcd - 1) / per_xcd : 0;
+  const int n1u = (SPLIT && bi < cnt1) ? (cnt1 - bi + per_xcd - 1) / per_xcd : 0;
+  const int nunits = n0u + n1u;
+  if (nunits == 0) return;
+  auto unit_id = [&](int k) { return k < n0u ? start0 + bi + k * per_xcd : len0 + start1 + bi + (k - n0u) * per_xcd; };
+  int it = 0;        // index into this block's unit list
 
   struct Tile { int b, m0, n0, unit, nt; bool second; uint32_t xoff, woff; };   // unit: -1 = whole tile, else index of the (tile, slice) unit
   auto coords = [&](int id) {
@@ -893,7 +906,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     fw[s] = LDS_W + wc * 64 * 128 + o;
   }
 
-  Tile cur = coords(xstart + it);
+  Tile cur = coords(unit_id(0));
   // ---- prologue (first tile of the block only): K-tiles 0 and 1 complete
 #pragma unroll
   for (int q = 0; q < 4; ++q) stage(q, cur.xoff, cur.woff, 0, 0);
@@ -957,11 +970,11 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #endif
   for (;;) {
     TFX_STAMP(3);
-    const int nit = it + per_xcd;
-    const bool has_next = nit < xcnt;
+    const int nit = it + 1;
+    const bool has_next = nit < nunits;
     // the last tile of the block re-requests its own first K-tiles: harmless (nobody reads them) and keeps the
     // load counts of the waits uniform
-    const Tile nxt = coords(xstart + (has_next ? nit : it));
+    const Tile nxt = coords(unit_id(has_next ? nit : it));
     const uint32_t cx = cur.xoff, cw = cur.woff, nx = nxt.xoff, nw = nxt.woff;
     // Everything K-tiles 0 and 1 read was waited for before this tile started (prologue / the epilogue's vmcnt(0)), and
     // the first requests of THIS tile have their deadline at L3 of K-tile 1: the earlier counted waits could only stall
