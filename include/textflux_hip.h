@@ -250,6 +250,14 @@ int tfx_graph_destroy(tfx_graph graph);
 int tfx_conv3x3_nhwc(const void* x, int32_t B, int32_t inH, int32_t inW, int32_t Cin, const void* w, const void* bias,
                      void* out, int32_t H, int32_t W, int32_t Cout, int32_t stride, int32_t up, int32_t pad_lo,
                      const void* res, const void* zero_page, int variant, tfx_stream stream);
+/* The same convolution (stride 1, pad 1, no upsample) in PIXEL-PAIR form, for layers with few output channels: one GEMM row is two
+ * horizontally adjacent output pixels (W even), N = 2 * Cout -- their channels are neighbours in NHWC, so `out` / `res` are the
+ * ordinary [B, H, W, Cout] tensors -- and K runs over the 3 x 4 input taps the pair touches: w_pair [2 * Cout][3][4][Cin] holds,
+ * for pixel o of the pair, the kernel's column dx at position dx + o and zeros elsewhere; bias_pair [2 * Cout] = the bias twice.
+ * 4/3 of the FLOPs, but a 128-channel layer then fills the MFMA kernel's 256-column tile instead of half of it (VAE: the
+ * full-resolution blocks of D/models/autoencoders/vae.py:60-360; same result up to fp32 summation order). */
+int tfx_conv3x3_pair_nhwc(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w_pair, const void* bias_pair,
+                          void* out, int32_t Cout, const void* res, const void* zero_page, tfx_stream stream);
 /* GroupNorm(groups, eps, affine) followed by SiLU when silu != 0, x/out [B, HW, C] NHWC.  workspace: fp32
  * [B * (ceil(HW/1024) + 1) * groups * 2]. */
 int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* workspace, int32_t B,

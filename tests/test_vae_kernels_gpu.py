@@ -52,6 +52,33 @@ def test_conv3x3_nhwc(ops, variant, B, H, W, Cin, Cout, stride, up, pad_lo, with
     close(got.permute(0, 3, 1, 2), ref.to(BF))
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,with_res", [(2, 12, 20, 64, 128, False), (1, 9, 14, 128, 128, True), (1, 40, 36, 256, 128, True),
+                                                     (2, 7, 6, 64, 72, False)])
+def test_conv3x3_pixel_pair_form(ops, B, H, W, Cin, Cout, with_res):
+    """Round 4: layers with <= 128 output channels as one GEMM row per PAIR of horizontally adjacent pixels (N = 2 Cout fills the
+    256-column tile; K over the 3 x 4 taps the pair touches, zero weights where a pixel does not use a column) -- against fp32
+    F.conv2d, and bit for bit against the one-pixel-per-row form."""
+    x = rnd((B, Cin, H, W), 11).to(BF)
+    w = rnd((Cout, Cin, 3, 3), 12, 0.05).to(BF)
+    b = rnd((Cout,), 13).to(BF)
+    ref = F.conv2d(x.float(), w.float(), b.float(), stride=1, padding=1)
+    res = rnd(ref.shape, 14).to(BF) if with_res else None
+    if with_res:
+        ref = res.float() + ref.to(BF).float()
+    xn, wk = x.permute(0, 2, 3, 1).contiguous().cuda(), w.permute(0, 2, 3, 1).contiguous().cuda()
+    rn = res.permute(0, 2, 3, 1).contiguous().cuda() if with_res else None
+    wp, bp = ops.pair_conv_weights(wk, b.cuda())
+    assert wp.shape == (2 * Cout, 3, 4, Cin) and bp.shape == (2 * Cout,)
+    got = ops.conv3x3_pair_nhwc(xn, wp, bp, res=rn)
+    assert got.shape == (B, H, W, Cout)
+    close(got.permute(0, 3, 1, 2), ref.to(BF))
+    # the pair form visits the same (tap, channel) products in the same order -- the extra taps are exact zeros -- so it is
+    # bit-identical to the one-pixel-per-row form, not merely close
+    assert torch.equal(got, ops.conv3x3_nhwc(xn, wk, b.cuda(), res=rn))
+    with pytest.raises(RuntimeError, match="W must be even"):
+        ops.conv3x3_pair_nhwc(xn[:, :, :W - 1].contiguous(), wp, bp)
+
+
 @pytest.mark.parametrize("C,groups,HW,silu", [(128, 32, 48 * 40, True), (256, 32, 1500, True), (512, 32, 33 * 31, False),
                                                (64, 4, 2100, True)])
 def test_groupnorm_silu_nhwc(ops, C, groups, HW, silu):

@@ -122,6 +122,7 @@ SIGNATURES = {
     "tfx_graph_destroy": (c_int, [c_void_p]),
     "tfx_conv3x3_nhwc": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                  c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int, c_void_p]),
+    "tfx_conv3x3_pair_nhwc": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "tfx_groupnorm_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                    c_float, c_int32, c_void_p]),
     "tfx_any_negative": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),

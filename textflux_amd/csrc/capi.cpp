@@ -443,7 +443,25 @@ int tfx_conv3x3_nhwc(const void* x, int32_t B, int32_t inH, int32_t inW, int32_t
   a.res = res; a.ldr = Cout;
   a.conv_cin = Cin; a.conv_inH = inH; a.conv_inW = inW; a.conv_H = H; a.conv_W = W;
   a.conv_stride = stride; a.conv_up_shift = up == 2 ? 1 : 0; a.conv_pad_lo = pad_lo; a.zero_page = zero_page;
+  a.conv_kw = 3; a.conv_stride_x = 0; a.qkn_eps = 1e-6f;
   return variant < 0 ? gemm_bf16(a, S(stream)) : gemm_bf16_variant(a, variant, S(stream));
+}
+
+int tfx_conv3x3_pair_nhwc(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w_pair, const void* bias_pair,
+                          void* out, int32_t Cout, const void* res, const void* zero_page, tfx_stream stream) {
+  if (!x || !w_pair || !out || !zero_page) return fail("tfx_conv3x3_pair_nhwc: null pointer");
+  if (W % 2 || Cin % 64 || Cout % 4) return fail("tfx_conv3x3_pair_nhwc: W must be even, Cin a multiple of 64, Cout of 4");
+  GemmArgs a;
+  std::memset(&a, 0, sizeof(a));
+  const int K = 12 * Cin;
+  a.A = x; a.lda = Cin; a.W = w_pair; a.ldw = K; a.bias = bias_pair;
+  a.C = out; a.ldc = 2 * Cout; a.M = B * H * (W / 2); a.N = 2 * Cout; a.K = K; a.batch = 1;
+  a.epilogue = res ? EPI_BIAS_RES : EPI_BIAS;
+  a.res = res; a.ldr = 2 * Cout;
+  a.conv_cin = Cin; a.conv_inH = H; a.conv_inW = W; a.conv_H = H; a.conv_W = W / 2;
+  a.conv_stride = 1; a.conv_up_shift = 0; a.conv_pad_lo = 1; a.zero_page = zero_page;
+  a.conv_kw = 4; a.conv_stride_x = 2;
+  return gemm_bf16(a, S(stream));
 }
 
 int tfx_groupnorm_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* workspace, int32_t B,

@@ -57,6 +57,7 @@ struct GemmParams {
   const bf16_t* gate; int64_t gate_bs;
   const bf16_t* res; int64_t ldr, r_bs;
   int cin, inH, inW, oH, oW, cstride, cup, cpad;   // implicit 3x3 convolution (cin > 0), see GemmArgs
+  int ckw, cstride_x;                               // taps per kernel row (3; 4 = the pixel-pair form) and the x stride (= cstride; 2 = pixel-pair form)
   int csh;                                          // log2(cin) when cin < 64 (narrow-input mode), else 0
   const bf16_t* zero;
   const float* a_scale; int64_t as_bs; const float* w_scale;   // fp8 kernel only
@@ -96,10 +97,10 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
       float av = 0.f;
       if (m < p.M && k < p.K) {
         if (p.cin > 0) {
-          const int tap = k / p.cin, ci = k - tap * p.cin, dy = tap / 3, dx = tap - 3 * dy;
+          const int tap = k / p.cin, ci = k - tap * p.cin, dy = tap / p.ckw, dx = tap - p.ckw * dy;
           const int pix = m % (p.oH * p.oW), bb = m / (p.oH * p.oW), y = pix / p.oW, x = pix - y * p.oW;
-          const int yy = y * p.cstride - p.cpad + dy, xx = x * p.cstride - p.cpad + dx;
-          if (tap < 9 && yy >= 0 && xx >= 0 && yy < (p.inH << p.cup) && xx < (p.inW << p.cup))
+          const int yy = y * p.cstride - p.cpad + dy, xx = x * p.cstride_x - p.cpad + dx;
+          if (tap < 3 * p.ckw && yy >= 0 && xx >= 0 && yy < (p.inH << p.cup) && xx < (p.inW << p.cup))
             av = bf2f(A[((int64_t)(bb * p.inH + (yy >> p.cup)) * p.inW + (xx >> p.cup)) * p.cin + ci]);
         } else {
           av = bf2f(A[(int64_t)m * p.lda + k]);
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
           const int m = m0 + grow, hw = p.oH * p.oW;
           const int bb = m / hw, pix = m - bb * hw, y = pix / p.oW, x = pix - y * p.oW;
           cpix[q][j] = bb * p.inH * p.inW;
-          cyx[q][j] = ((y * p.cstride - p.cpad + 1) << 16) | (x * p.cstride - p.cpad + 1);
+          cyx[q][j] = ((y * p.cstride - p.cpad + 1) << 16) | (x * p.cstride_x - p.cpad + 1);
           goff[q][j] = clog * 8;
         } else {
           goff[q][j] = grow * (int)p.lda + clog * 8;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
         return;
       }
       // K index -> (tap, channel block): a 64-wide K-tile never straddles a tap because Cin % 64 == 0
-      const int k0 = kt * 64, tap = k0 / p.cin, ci0 = k0 - tap * p.cin, dy = tap / 3, dx = tap - 3 * dy;
+      const int k0 = kt * 64, tap = k0 / p.cin, ci0 = k0 - tap * p.cin, dy = tap / p.ckw, dx = tap - p.ckw * dy;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int yy = (cyx[q][j] >> 16) - 1 + dy, xx = (cyx[q][j] & 0xffff) - 1 + dx;
@@ -1164,6 +1165,7 @@ static GemmParams make_params(const GemmArgs& a) {
   p.res = (const bf16_t*)a.res; p.ldr = a.ldr; p.r_bs = a.r_bstride;
   p.cin = a.conv_cin; p.inH = a.conv_inH; p.inW = a.conv_inW; p.oH = a.conv_H; p.oW = a.conv_W;
   p.cstride = a.conv_stride; p.cup = a.conv_up_shift; p.cpad = a.conv_pad_lo; p.zero = (const bf16_t*)a.zero_page;
+  p.ckw = a.conv_kw; p.cstride_x = a.conv_stride_x > 0 ? a.conv_stride_x : a.conv_stride;
   p.csh = a.conv_cin == 8 ? 3 : a.conv_cin == 16 ? 4 : a.conv_cin == 32 ? 5 : 0;
   p.a_scale = a.a_scale; p.as_bs = a.a_scale_bstride; p.w_scale = a.w_scale;
   p.ws = nullptr; p.sk = 1; p.u_full = 0; p.tail_r = 0; p.ws_ld = 0; p.ws_bs = 0;
@@ -1176,8 +1178,8 @@ static GemmParams make_params(const GemmArgs& a) {
 }
 
 static bool conv_ok(const GemmArgs& a) {
-  const bool wide = a.conv_cin % 64 == 0 && a.K == 9 * a.conv_cin;
-  const bool narrow = (a.conv_cin == 8 || a.conv_cin == 16 || a.conv_cin == 32) && a.K == (9 * a.conv_cin + 63) / 64 * 64;
+  const bool wide = a.conv_cin % 64 == 0 && (a.conv_kw == 3 || a.conv_kw == 4) && a.K == 3 * a.conv_kw * a.conv_cin;
+  const bool narrow = a.conv_kw == 3 && (a.conv_cin == 8 || a.conv_cin == 16 || a.conv_cin == 32) && a.K == (9 * a.conv_cin + 63) / 64 * 64;
   return (wide || narrow) && a.batch == 1 && a.zero_page && (uintptr_t)a.zero_page % 16 == 0 &&
          a.conv_H > 0 && a.conv_W > 0 && (a.conv_inH << a.conv_up_shift) < 32768 && (a.conv_inW << a.conv_up_shift) < 32768 &&
          (int64_t)a.M * 1 == (int64_t)a.conv_H * a.conv_W * (a.M / (a.conv_H * a.conv_W)) && a.M % (a.conv_H * a.conv_W) == 0;

@@ -45,6 +45,10 @@ struct GemmArgs {
   // (x*stride - pad_lo + dx) >> up_shift) -- up_shift = 1 folds a nearest 2x upsample into the gather -- and taps that
   // fall outside the (upsampled) input read `zero_page` (>= 128 B of zeros) instead.
   int conv_cin = 0, conv_inH = 0, conv_inW = 0, conv_H = 0, conv_W = 0, conv_stride = 1, conv_up_shift = 0, conv_pad_lo = 1;
+  // pixel-pair form (conv_kw = 4, conv_stride_x = 2): one GEMM row = TWO horizontally adjacent output pixels, N = 2 * Cout (their
+  // channels are neighbours in NHWC), K = 3 x 4 taps x Cin over the 4 input columns the pair touches, weights [2 Cout][3][4][Cin]
+  // with zeros where a pixel does not use a column.  A third more FLOPs, but a 128-channel layer fills the 256-column tile.
+  int conv_kw = 3, conv_stride_x = 0;
   const void* zero_page = nullptr;
   // fp8 (e4m3) operands, gemm_fp8 only: A and W hold one byte per element, C = (A.W^T) * a_scale[b][m] * w_scale[n] + bias
   const float* a_scale = nullptr; int64_t a_scale_bstride = 0;   // per activation row

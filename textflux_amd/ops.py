@@ -328,6 +328,29 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+def pair_conv_weights(w: torch.Tensor, bias: Optional[torch.Tensor]):
+    """[Cout, 3, 3, Cin] (KRSC), [Cout] -> the pixel-pair form of tfx_conv3x3_pair_nhwc: [2 Cout, 3, 4, Cin], [2 Cout]."""
+    Cout, _, _, Cin = w.shape
+    wp = torch.zeros(2, Cout, 3, 4, Cin, dtype=w.dtype, device=w.device)
+    wp[0, :, :, 0:3] = w
+    wp[1, :, :, 1:4] = w
+    return wp.view(2 * Cout, 3, 4, Cin).contiguous(), (torch.cat([bias, bias]).contiguous() if bias is not None else None)
+
+
+def conv3x3_pair_nhwc(x: torch.Tensor, w_pair: torch.Tensor, bias_pair: Optional[torch.Tensor], res: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3 x 3 convolution, stride 1, pad 1, in pixel-pair form (pair_conv_weights): x [B, H, W, Cin], W even -> [B, H, W, Cout]."""
+    _chk_dev(x, w_pair, bias_pair, res, out)
+    assert x.is_contiguous() and w_pair.is_contiguous() and x.dtype == BF16
+    B, H, W, Cin = x.shape
+    Cout = w_pair.shape[0] // 2
+    if out is None:
+        out = torch.empty(B, H, W, Cout, dtype=BF16, device=x.device)
+    L.check(L.lib().tfx_conv3x3_pair_nhwc(x.data_ptr(), B, H, W, Cin, w_pair.data_ptr(), _p(bias_pair), out.data_ptr(), Cout, _p(res),
+                                          zero_page(x.device).data_ptr(), _stream()), "conv3x3_pair_nhwc")
+    return out
+
+
 def groupnorm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, silu: bool = True,
                    eps: float = 1e-6, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [B, ..., C] NHWC bf16 -> GroupNorm(+SiLU)."""

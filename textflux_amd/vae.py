@@ -72,6 +72,7 @@ class AutoencoderKL:
         if bad or in_channels > 8 or out_channels > 8 or latent_channels % 8 or latent_channels > 32:
             raise ValueError(f"AutoencoderKL config outside the gfx950 kernels' range: block widths {bad or '-'} must be "
                              "multiples of 64 with (width / groups) % 4 == 0; in/out channels <= 8; latent channels 8/16/24/32")
+        self.pair_convs = True     # 3 x 3 layers with <= 128 output channels in pixel-pair form (tfx_conv3x3_pair_nhwc); A/B knob: set before load
         self.sd: Dict[str, torch.Tensor] = {}
         self.hw: Dict[str, torch.Tensor] = {}
         self.dtype, self.device = torch.bfloat16, torch.device("cpu")
@@ -147,9 +148,15 @@ class AutoencoderKL:
                 b = self.sd[name + ".bias"]
                 self.hw[name + ".bias"] = torch.cat([b, torch.zeros(pad, dtype=b.dtype, device=b.device)], 0)
             self.hw[k] = w.contiguous()
+            # few output channels (the full-resolution blocks: 128): the pixel-pair form fills the MFMA kernel's 256-column tile
+            if self.pair_convs and cin % 64 == 0 and cout % 8 == 0 and cout <= 128:
+                self.hw[name + ".pair"] = ops.pair_conv_weights(w.contiguous(), self.sd[name + ".bias"])
 
     # ---- building blocks ----------------------------------------------------------------------------------------
     def _conv(self, x, name, **kw):
+        pair = self.hw.get(name + ".pair")
+        if pair is not None and x.shape[2] % 2 == 0 and kw.get("stride", 1) == 1 and kw.get("up", 1) == 1 and kw.get("pad_lo", 1) == 1:
+            return ops.conv3x3_pair_nhwc(x, pair[0], pair[1], res=kw.get("res"))
         return ops.conv3x3_nhwc(x, self.hw[name + ".weight"], self.hw.get(name + ".bias", self.sd[name + ".bias"]), **kw)
 
     def _gn(self, x, name, silu=True):
