@@ -170,6 +170,28 @@ def test_gemm_tail_split_matches_unsplit(ops, B, M, N, K):
                 ops.set_option("gemm_splitk", 2)
 
 
+@pytest.mark.parametrize("B,M,N,K", [(1, 4096, 3072, 256), (3, 5120, 9216, 384), (2, 1000, 3136, 512), (1, 36864, 3072, 3072)])
+def test_gemm_one_wave_per_simd_kernel_is_bit_identical(ops, B, M, N, K):
+    """Round 4: gemm4w_kernel -- 4 waves of 128 x 128, 32-deep K sub-tiles in a 4-set LDS ring, the whole
+    head of a q / k norm tile inside one wave -- accumulates every output element in the same order as the other two MFMA kernels:
+    bit-identical for every epilogue, ragged edges and batch strides included.  (It measures 11-14 % slower than the ping-pong
+    kernel, profiles/r04_gemm4w_ab.json, and is selectable only: tfx_set_option gemm_waves 4.)"""
+    a, w = rnd((B, M, K), 71).to(BF).cuda(), rnd((N, K), 72, 0.05).to(BF).cuda()
+    bias, gate, res = rnd((N,), 73).to(BF).cuda(), rnd((B, N), 74).to(BF).cuda(), rnd((B, M, N), 75).to(BF).cuda()
+    cases = [(ops.EPI_BIAS, {}), (ops.EPI_BIAS_GELU, dict(gelu_from_col=max(0, (N // 256 - 1) * 256))),
+             (ops.EPI_BIAS_GATE_RES, dict(gate=gate, res=res)), (ops.EPI_BIAS_RES, dict(res=res))]
+    try:
+        for epi, kw in cases:
+            ops.set_option("gemm_waves", 8)
+            ref = ops.gemm(a, w, bias, epilogue=epi, variant=3, **kw)
+            ops.set_option("gemm_waves", 4)
+            got = torch.full((B, M, N), 5.0, dtype=BF, device="cuda")
+            ops.gemm(a, w, bias, out=got, epilogue=epi, variant=3, **kw)
+            assert torch.equal(ref, got), (epi, (ref.float() - got.float()).abs().max().item())
+    finally:
+        ops.set_option("gemm_waves", 8)
+
+
 def test_gemm_persistent_rejects_odd_k_tiles(ops):
     a, w = rnd((512, 192), 1).to(BF).cuda(), rnd((256, 192), 2).to(BF).cuda()
     with pytest.raises(RuntimeError, match="persistent"):

@@ -566,6 +566,7 @@ int tfx_set_option(const char* name, int value) {
   if (!std::strcmp(name, "attention_use_bound")) { set_attention_use_bound(value); return 0; }
   if (!std::strcmp(name, "attention_persistent")) { set_attention_persistent(value); return 0; }
   if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
+  if (!std::strcmp(name, "gemm_waves")) { set_gemm_waves(value); return 0; }
   if (!std::strcmp(name, "gemm_group_streams")) { g_group_streams = value; return 0; }
   if (!std::strcmp(name, "gemm_splitk")) { set_gemm_splitk(value); return 0; }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only

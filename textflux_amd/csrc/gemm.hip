@@ -1063,6 +1063,324 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #undef PP_TILE_W
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the ONE-WAVE-PER-SIMD form of the persistent kernel (tfx_set_option gemm_waves 4).  Same
+// 256 x 256 block tile, same tile order, same accumulation order per output element (bit-identical to the other two MFMA kernels),
+// but 4 waves of 128 x 128 (8 x 8 accumulators of 16 x 16 = 256 accumulator registers in the AccVGPRs, the whole 512-register file
+// per wave): a third fewer LDS fragment reads per MFMA (16 b128 reads feed 64 MFMAs, against 24 for 64 in the 8-wave kernel) and
+// no ping-pong -- each wave hides its own reads and requests behind its own MFMAs.
+//   * K is walked in 32-deep SUB-tiles (one v_mfma_f32_16x16x32_bf16 k-step): 64-byte rows, 4 LDS sets of 32 KiB (X 256 rows |
+//     W 256 rows), one barrier per sub-tile (64 MFMAs per wave).  In iteration t a wave waits for its requests of sub-tile t + 1
+//     (vmcnt(16): the two youngest sub-tiles may still be in flight), for its fragment reads of sub-tile t, and meets the others;
+//     then it reads the 16 fragments of sub-tile t + 1 into the other fragment set, requests sub-tile t + 4 into the LDS set the
+//     fragments of t just left, and issues the 64 MFMAs of t -- every request has three iterations (~3 k cycles) in flight.
+//   * requests: one wave instruction = 16 rows x 64 B; the 16-byte chunks of a row are XOR-swizzled with (row >> 2) & 3 on the
+//     SOURCE address (the LDS image stays lane-linear, as LDS-DMA requires): conflict-free ds_read_b128 of 16 rows x one chunk.
+//   * the requests of a tile's last four sub-tiles fetch the first four of the block's next tile.
+//   * epilogue (not yet hidden under the next tile's MFMAs in this version): four 32-row blocks through an 8 KiB wave-private
+//     staging tile (256-byte rows, chunks XOR-swizzled with row & 15), whole 256-byte row segments stored by 16 lanes each.  A
+//     128-column head lies inside ONE wave: the fused q / k RMSNorm needs neither the partner exchange nor its two barriers.
+constexpr int W4G_SET = 32768, W4G_WOFF = 16384, W4G_STG = 131072, W4G_STG_WAVE = 8192, W4G_LDS_TOTAL = W4G_STG + 4 * W4G_STG_WAVE;
+
+template <int EPI, bool QKN>
+__global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wcn = wave & 1;          // rows wr * 128 .. + 128, columns wcn * 128 .. + 128 of the block tile
+  const int nsub = p.K >> 5;                          // 32-deep sub-tiles (a multiple of 4: K % 128 == 0)
+
+  // ---- this block's tiles (as gemm8pp_kernel without K-sliced units)
+  const int per_batch = p.tm * p.tn;
+  const int T = p.batch * per_batch;
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, bi = blockIdx.x >> 3;
+  const int q8 = T >> 3, r8 = T & 7;
+  const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int xcnt = q8 + (xcd < r8 ? 1 : 0);
+  if (bi >= xcnt) return;
+  struct Tile { int b, m0, n0; bool second; uint32_t xoff, woff; };
+  auto coords = [&](int id) {
+    Tile t;
+    t.b = id / per_batch;
+    int idx = id - t.b * per_batch;
+    const int GM = p.gm;
+    const int grp = idx / (GM * p.tn);
+    const int first_m = grp * GM;
+    const int gsz = min(GM, p.tm - first_m);
+    idx -= grp * GM * p.tn;
+    t.m0 = (first_m + idx % gsz) * 256;
+    t.n0 = (idx / gsz) * 256;
+    t.second = t.m0 < p.split_row;
+    t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * 2);
+    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * 2) + (t.second ? p.w2_off : 0u);
+    return t;
+  };
+
+  // ---- requests: wave w stages rows [64 w, 64 w + 64) of X and of W, four 16-row pieces each
+  const int lr = lane >> 2, cphys = lane & 3;
+  const int clog = cphys ^ ((lr >> 2) & 3);
+  const int vx = lr * (int)p.lda * 2 + clog * 16, vw = lr * (int)p.ldw * 2 + clog * 16;
+  const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.A, 0, (int)(uint32_t)((((int64_t)(p.batch - 1) * p.a_bs + (int64_t)(p.M - 1) * p.lda + p.K) * 2)), 0x00020000);
+  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.W, 0, (int)((uint32_t)((((int64_t)(p.N - 1) * p.ldw + p.K) * 2)) + (p.split_row > 0 ? p.w2_off : 0u)), 0x00020000);
+  const int rowx = wave * 64 * (int)p.lda * 2, roww = wave * 64 * (int)p.ldw * 2;       // byte offset of the wave's first row
+  const int px = 16 * (int)p.lda * 2, pw = 16 * (int)p.ldw * 2;                          // ... of a piece
+  // piece pc (0..3 X, 4..7 W) of sub-tile `sub` of the tile with origins (xo, wo) into LDS set `set`
+  auto request = [&](int pc, uint32_t xo, uint32_t wo, int sub, int set) __attribute__((always_inline)) {
+    const bool x_item = pc < 4;
+    const int k = pc & 3;
+    const uint32_t dst = set * W4G_SET + (x_item ? 0 : W4G_WOFF) + (wave * 64 + k * 16) * 64;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_item ? rsrcX : rsrcW, (lds_void*)(smem + dst), 16,
+                                             x_item ? vx + rowx + k * px : vw + roww + k * pw, (x_item ? xo : wo) + (uint32_t)sub * 64u, 0,
+                                             GLDS_AUX);
+  };
+
+  // ---- fragment reads: lane l = row l & 15 of a 16-row block, logical chunk l >> 4 (its 8 k values of the 32-deep step)
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const uint32_t fl = r16 * 64 + ((q4 ^ ((r16 >> 2) & 3)) << 4);
+  const uint32_t fa = wr * 128 * 64 + fl, fb = W4G_WOFF + wcn * 128 * 64 + fl;
+#define LDS_FRAG(off) (*reinterpret_cast<const bf16x8*>(smem + (off)))
+
+  f32x4 acc[8][8];
+  bf16x8 FA[2][8], FB[2][8];
+  char* stg = smem + W4G_STG + wave * W4G_STG_WAVE;
+
+  int it = bi;
+  Tile cur = coords(xstart + it);
+  // ---- prologue: sub-tiles 0 .. 3 of the first tile
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) request(pc, cur.xoff, cur.woff, q, q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TFX_BARRIER();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { FA[0][i] = LDS_FRAG(fa + i * 1024); FB[0][i] = LDS_FRAG(fb + i * 1024); }
+
+  // one sub-tile out of LDS set Q (fragments in F[Q & 1]); meanwhile the fragments of the next sub-tile (set Q + 1) are read and sub-tile
+  // (RT, origins RX / RW) is requested into set Q.  WAIT: the counted wait (not in a tile's first three sub-tiles: what they read was
+  // waited for by the previous epilogue / the prologue, and a counted wait there would only stall on the epilogue's stores).  Z: the
+  // tile's first sub-tile starts its accumulators from a zero C operand.
+#define W4G_SUB(Q, RX, RW, RT, WAIT, Z)                                                                                     \
+  do {                                                                                                                      \
+    if (WAIT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                      \
+    TFX_BARRIER();                                                                                                          \
+    constexpr int cur_ = (Q) & 1, nxt_ = cur_ ^ 1;                                                                          \
+    constexpr uint32_t nset_ = (((Q) + 1) & 3) * W4G_SET;                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                         \
+      /* per row block: two fragment reads of the next sub-tile and one request in front of its eight MFMAs.  (Measured alternative: */ \
+      /* the MFMAs first, the sixteen reads bunched into the first four row blocks and the requests into the last four -- 5 % slower: */ \
+      /* what one wave can hide behind a 16-cycle MFMA is one short instruction, a burst of four reads or two requests is not hidden)  */ \
+      FA[nxt_][i] = LDS_FRAG(fa + nset_ + i * 1024);                                                                        \
+      FB[nxt_][i] = LDS_FRAG(fb + nset_ + i * 1024);                                                                        \
+      request(i, RX, RW, RT, Q);                                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                         \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[cur_][j], FA[cur_][i], (Z) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    }                                                                                                                       \
+  } while (0)
+
+  for (;;) {
+    const int nit = it + per_xcd;
+    const bool has_next = nit < xcnt;
+    const Tile nxt = coords(xstart + (has_next ? nit : it));
+    const uint32_t cx = cur.xoff, cw = cur.woff, nx = nxt.xoff, nw = nxt.woff;
+    W4G_SUB(0, cx, cw, 4, false, true);
+    W4G_SUB(1, cx, cw, 5, false, false);
+    W4G_SUB(2, cx, cw, 6, false, false);
+    W4G_SUB(3, cx, cw, 7, true, false);
+    for (int t = 4; t < nsub - 4; t += 4) {
+      W4G_SUB(0, cx, cw, t + 4, true, false);
+      W4G_SUB(1, cx, cw, t + 5, true, false);
+      W4G_SUB(2, cx, cw, t + 6, true, false);
+      W4G_SUB(3, cx, cw, t + 7, true, false);
+    }
+    W4G_SUB(0, nx, nw, 0, true, false);     // the last four sub-tiles request the first four of the next tile
+    W4G_SUB(1, nx, nw, 1, true, false);
+    W4G_SUB(2, nx, nw, 2, true, false);
+    W4G_SUB(3, nx, nw, 3, true, false);
+
+    // ---- epilogue
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int q_e = lane_e >> 4, r_e = lane_e & 15;
+      const int m0w = cur.m0 + wr * 128, n0w = cur.n0 + wcn * 128;
+      const bf16_t* const p_bias = cur.second ? p.bias2 : p.bias;
+      const bf16_t* const p_gate = cur.second ? p.gate2 : p.gate;
+      constexpr bool HAS_RES = (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES);
+      const bool do_gelu = (EPI == EPI_BIAS_GELU) && (cur.n0 >= p.gelu_from);
+      const bool in_q = QKN && cur.n0 >= p.nq0 && cur.n0 < p.nq1;
+      const bool norm_tile = QKN && (in_q || (cur.n0 >= p.nk0 && cur.n0 < p.nk1));
+      const int rows_ok = min(max(p.M - m0w, 0), 128);
+      constexpr uint32_t OOR = 0x80000000u;
+      auto uniform_rsrc = [](const void* base, int bytes) {
+        const uint64_t a = (uint64_t)base;
+        const uint64_t u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+      };
+      const auto rsrcC = uniform_rsrc(p.C + cur.b * p.c_bs + (int64_t)m0w * p.ldc, rows_ok ? (int)(((int64_t)(rows_ok - 1) * p.ldc + p.N) * 2) : 0);
+      const auto rsrcR = uniform_rsrc(HAS_RES ? p.res + cur.b * p.r_bs + (int64_t)m0w * p.ldr : p.C,
+                                      HAS_RES && rows_ok ? (int)(((int64_t)(rows_ok - 1) * p.ldr + p.N) * 2) : 0);
+      const auto rsrcB = uniform_rsrc(p_bias ? p_bias : p.C, p_bias ? p.N * 2 : 0);
+      const auto rsrcG = uniform_rsrc(EPI == EPI_BIAS_GATE_RES ? p_gate + cur.b * p.gate_bs : p.C, EPI == EPI_BIAS_GATE_RES ? p.N * 2 : 0);
+      const int ncol = n0w + q_e * 4;                          // + j * 16: the lane's 4 accumulator columns of column block j
+      const int crow = lane_e >> 4, cchunk = lane_e & 15;      // read-back: row crow + 4 it of the 32-row block, 16-byte chunk cchunk
+      const int nst = n0w + cchunk * 8;
+      const uint32_t col_off = nst < p.N ? (uint32_t)nst * 2u : OOR;
+      u32x2 bsr[8], gtr[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bsr[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcB, (ncol + j * 16) * 2, 0, 0);
+        if (EPI == EPI_BIAS_GATE_RES) gtr[j] = __builtin_amdgcn_raw_buffer_load_b64(rsrcG, (ncol + j * 16) * 2, 0, 0);
+      }
+      u32x4 rr[8];
+      auto load_res = [&](int blk) {
+#pragma unroll
+        for (int itr = 0; itr < 8; ++itr)
+          rr[itr] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)((uint32_t)(blk * 32 + itr * 4 + crow) * (uint32_t)(p.ldr * 2) + col_off), 0, 0);
+      };
+      if (HAS_RES) load_res(0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): bias / gate / residual, and every operand request up to the next tile's first four sub-tiles
+      __builtin_amdgcn_sched_barrier(0);
+      float rinv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      u32x4 nw8 = u32x4{0u, 0u, 0u, 0u};
+      if (norm_tile) {
+        nw8 = *reinterpret_cast<const u32x4*>((in_q ? (cur.second ? p.nq_w2 : p.nq_w) : (cur.second ? p.nk_w2 : p.nk_w)) + cchunk * 8);
+        // Linear output in bf16 (what the reference's RMSNorm sees), in place; sum of squares of the lane's 32 columns, then of the
+        // row's 128 columns: the four lanes l, l ^ 16, l ^ 32, l ^ 48 hold one row of this wave's head
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float ss = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const u32x2 br = bsr[j];
+            const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
+                                 __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              float x0 = acc[i][j][e] + bs[e], x1 = acc[i][j][e + 1] + bs[e + 1];
+              round_bf2(x0, x1);
+              acc[i][j][e] = x0;
+              acc[i][j][e + 1] = x1;
+              ss += x0 * x0;
+              ss += x1 * x1;
+            }
+          }
+          ss += __shfl_xor(ss, 16, 64);
+          ss += __shfl_xor(ss, 32, 64);
+          rinv[i] = rsqrtf(ss * (1.0f / 128.0f) + p.n_eps);
+        }
+      }
+      auto store_blocks = [&](auto NORM_T, auto GELU_T) __attribute__((always_inline)) {
+        constexpr bool NORM = decltype(NORM_T)::value;
+        constexpr bool GELU = decltype(GELU_T)::value;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int i = blk * 2 + h;
+            const int R = h * 16 + r_e;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const u32x2 br = bsr[j];
+              const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
+                                   __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = NORM ? acc[i][j][e] : acc[i][j][e] + bs[e];
+              if (GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+              }
+              if (EPI == EPI_BIAS_GATE_RES) {
+                const u32x2 gr = gtr[j];
+                const float gt[4] = {__uint_as_float(gr[0] << 16), __uint_as_float(gr[0] & 0xffff0000u),
+                                     __uint_as_float(gr[1] << 16), __uint_as_float(gr[1] & 0xffff0000u)};
+                round_bf2(v[0], v[1]);
+                round_bf2(v[2], v[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gt[e] * v[e];
+              }
+              u32x2 o;
+              o[0] = pack_bf2(v[0], v[1]);
+              o[1] = pack_bf2(v[2], v[3]);
+              // columns j * 16 + q * 4 .. + 4 of row R = 8-byte half (q & 1) of 16-byte chunk j * 2 + (q >> 1), stored at chunk ^ (R & 15)
+              *reinterpret_cast<u32x2*>(stg + R * 256 + (((j * 2 + (q_e >> 1)) ^ (R & 15)) << 4) + ((q_e & 1) << 3)) = o;
+            }
+          }
+          u32x4 vals[8];
+          f32x4 csr[2];
+#pragma unroll
+          for (int itr = 0; itr < 8; ++itr) {
+            const int row = itr * 4 + crow;
+            u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 256 + ((cchunk ^ (row & 15)) << 4));
+            if (NORM) {
+              const int mrow = min(m0w + blk * 32 + row, p.M - 1);
+              const float* cs = p.rope_cs + (int64_t)(p.rope_pos0 + mrow) * 128 + cchunk * 8;
+              csr[0] = *reinterpret_cast<const f32x4*>(cs);
+              csr[1] = *reinterpret_cast<const f32x4*>(cs + 4);
+              const float rr_row = __shfl(rinv[blk * 2 + (itr >> 2)], row & 15, 64);
+              float x[8], wv[8], y[8], o8[8];
+              unpack8(val, x);
+              unpack8(nw8, wv);
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                float a0 = x[e] * rr_row, a1 = x[e + 1] * rr_row;
+                round_bf2(a0, a1);
+                a0 *= wv[e];
+                a1 *= wv[e + 1];
+                round_bf2(a0, a1);
+                y[e] = a0;
+                y[e + 1] = a1;
+              }
+              const f32x4 c0 = csr[0], c1 = csr[1];
+              o8[0] = y[0] * c0[0] + (-y[1]) * c0[1];  o8[1] = y[1] * c0[0] + y[0] * c0[1];
+              o8[2] = y[2] * c0[2] + (-y[3]) * c0[3];  o8[3] = y[3] * c0[2] + y[2] * c0[3];
+              o8[4] = y[4] * c1[0] + (-y[5]) * c1[1];  o8[5] = y[5] * c1[0] + y[4] * c1[1];
+              o8[6] = y[6] * c1[2] + (-y[7]) * c1[3];  o8[7] = y[7] * c1[2] + y[6] * c1[3];
+              val = pack8(o8);
+            }
+            if (HAS_RES) {
+              float fv[8], fr[8];
+              unpack8(val, fv);
+              unpack8(rr[itr], fr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+              val = pack8(fv);
+            }
+            vals[itr] = val;
+          }
+          if (HAS_RES && blk + 1 < 4) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_res(blk + 1);          // requested before this block's stores (vmcnt retires in issue order)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int itr = 0; itr < 8; ++itr)
+            __builtin_amdgcn_raw_buffer_store_b128(vals[itr], rsrcC,
+                                                   (int)((uint32_t)(blk * 32 + itr * 4 + crow) * (uint32_t)(p.ldc * 2) + col_off), 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (QKN && norm_tile) store_blocks(std::true_type{}, std::false_type{});
+      else if (EPI == EPI_BIAS_GELU && do_gelu) store_blocks(std::false_type{}, std::true_type{});
+      else store_blocks(std::false_type{}, std::false_type{});
+    }
+    if (!has_next) break;
+    cur = nxt;
+    it = nit;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the closing requests must not land in a successor's LDS
+#undef LDS_FRAG
+#undef W4G_SUB
+}
+
 // Second pass of the K-sliced units: C = epi(sum_s P[s] + bias) over the tail tiles, 8 columns per thread, slices summed in order.
 // Thread i -> (tail tile i / 8192, row (i / 32) % 256, columns 8 (i % 32) .. + 8) of ws [slice][tail tile][256][256].
 template <int EPI, bool FP8 = false>
@@ -1137,6 +1455,8 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 static int g_gemm_splitk = 2;     // K-sliced work units: 0 never (A/B knob), 1 only GEMMs with fewer tiles than CUs (round 3), 2 also the last round of small GEMMs
 void set_gemm_splitk(int v) { g_gemm_splitk = v; }
+static int g_gemm_waves = 8;      // 8: the ping-pong kernel (gemm8pp_kernel); 4: the one-wave-per-SIMD kernel (gemm4w_kernel) where eligible
+void set_gemm_waves(int v) { g_gemm_waves = v == 4 ? 4 : 8; }
 static int g_gemm_place = 2;      // request placement of the persistent kernel (bench knob, see gemm8pp_kernel)
 void set_gemm_place(int v) { g_gemm_place = v; }
 #ifdef TFX_BENCH
@@ -1284,7 +1604,22 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
     const int nt = p.K >> 6;
     const SlicePlan pl = variant == 1 ? plan_slices(p, grid, nt, ws, ws_bytes) : SlicePlan{1, 0, 0};
     const int sk = pl.sk;
-    if (p.rope_cs) {   // fused q / k RMSNorm + RoPE epilogue: EPI_BIAS_GELU instantiation only (plain bias = gelu_from >= N)
+    if (g_gemm_waves == 4 && sk == 1 && p.K >= 256) {   // one wave per SIMD (tfx_set_option gemm_waves 4): every unsliced bf16 launch
+      if (p.rope_cs && EPI != EPI_BIAS_GELU) return fail("gemm: the q/k norm + RoPE epilogue rides on the bias(+GELU) epilogue");
+      static bool attr4[2] = {false, false};
+      const int qi = p.rope_cs ? 1 : 0;
+      const void* fn = qi ? (const void*)gemm4w_kernel<EPI_BIAS_GELU, true> : (const void*)gemm4w_kernel<EPI, false>;
+      if (!attr4[qi]) {
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, fn);
+        (void)hipGetLastError();
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, W4G_LDS_TOTAL) != hipSuccess)
+          return fail("gemm: cannot raise dynamic LDS limit for the 4-wave kernel");
+        attr4[qi] = true;
+      }
+      if (qi) gemm4w_kernel<EPI_BIAS_GELU, true><<<grid, 256, W4G_LDS_TOTAL, st>>>(p);
+      else gemm4w_kernel<EPI, false><<<grid, 256, W4G_LDS_TOTAL, st>>>(p);
+    } else if (p.rope_cs) {   // fused q / k RMSNorm + RoPE epilogue: EPI_BIAS_GELU instantiation only (plain bias = gelu_from >= N)
       if (sk > 1) return fail("gemm: the q/k norm + RoPE epilogue cannot ride on a K-sliced launch (gemm_qkn_ok)");
       if (EPI != EPI_BIAS_GELU) return fail("gemm: the q/k norm + RoPE epilogue rides on the bias(+GELU) epilogue");
       static bool attrq = false;

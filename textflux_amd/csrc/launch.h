@@ -70,6 +70,7 @@ struct GemmArgs {
 bool gemm_rowsplit_ok(const GemmArgs& a);                       // can this (split_row > 0) GEMM run as one launch?
 void set_gemm_group_m(int gm);
 void set_gemm_place(int v);
+void set_gemm_waves(int v);      // 8 (default): gemm8pp_kernel; 4: gemm4w_kernel (one wave per SIMD) for unsliced bf16 launches
 void set_gemm_splitk(int v);
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
 bool gemm_qkn_ok(const GemmArgs& a);                          // can this GEMM carry the fused q/k norm + RoPE epilogue?
