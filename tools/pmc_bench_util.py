@@ -26,7 +26,7 @@ tot = {"launches": 0, "mfma_busy": 0.0, "gui_active": 0.0}
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["gui_active"]):
     share = a["gui_active"]
     is_dit = k.startswith("tfx::") and any(n in k for n in ("gemm8pp_kernel", "attn_w4_kernel", "attn_w16_kernel", "attn_mx_kernel", "attn_kernel", "ln_modulate_kernel",
-                                                             "rmsnorm_rope_kernel", "sched_step_kernel", "splitk_reduce_kernel", "quant_rows_fp8"))
+                                                             "rmsnorm_rope_kernel", "sched_step_kernel", "splitk_reduce_kernel", "tail_reduce_kernel", "quant_rows_fp8"))
     for t in (tot,) + ((dit,) if is_dit else ()):
         for f in ("launches", "mfma_busy", "gui_active"):
             t[f] += a[f]
