@@ -73,7 +73,7 @@ constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
 
 #define W4_GAP() __builtin_amdgcn_sched_barrier(0)
 #ifndef W4_ABL
-#define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier, 64 no staging writes (requests kept), 128 no staging requests (writes kept)
+#define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier, 64 no staging writes (requests kept), 128 no staging requests (writes kept), 256 requests as LDS-DMA into a scratch region (use with 64)
 #endif
 // wait until every issued MFMA has written its result (there is no counter for the matrix pipe): 24 x 16 idle issue slots,
 // used twice per workgroup (before the first softmax, before the output)
@@ -311,6 +311,12 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   auto load_piece = [&](int j, int ko, int vo, auto Ic, bool k_side) __attribute__((always_inline)) {
     constexpr int i = decltype(Ic)::value;
     if (W4_ABL & 32) j = 0;          // timing ablation: every request hits the same (cache-resident) tile
+    if constexpr (W4_ABL & 256) {    // timing ablation: the request as LDS-DMA into a scratch region behind the ring (what would a DMA-staged kernel pay?)
+      typedef __attribute__((address_space(3))) void lds_void_;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_side ? rsKs : rsVs, (lds_void_*)(smem + ATT_LDS_W4 + (tid >> 6) * 1024), 16, k_side ? ko : vo,
+                                               (j * W4_KV + 16 * i) * (k_side ? ldk2 : ldv2), 0, 0);
+      return;
+    }
     if (k_side)
       kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsKs, ko, (j * W4_KV + 16 * i) * ldk2, 0));
     else
@@ -425,9 +431,13 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
 #pragma unroll
     for (int s = 0; s < 8; ++s) w4_mfma_s(sc[0], kf[s], qf[0][s]);
   }
-  // the only place a score is read right after its chain's last MFMA.  MFMAs are issued ahead of their execution (a
-  // dependent chain queues up), so the wait covers the whole chain: 9 x 32 cycles
+  // The first read of these scores is the first step's W4_TOUCH (compiler-visible), in front of which hipcc pads for the chain's last
+  // MFMA; dependent MFMAs are interlocked among themselves.  Rounds 2-3 put 24 x `s_nop 15` here and before the output (from the time
+  // when every read was inline asm with no visible one in front): dead time twice per item, removed in round 4 (-DW4_KEEP_DRAINS restores
+  // them; tools/check_mfma_hazard.py and the determinism tests are the net).
+#ifdef W4_KEEP_DRAINS
   W4_DRAIN_MFMA();
+#endif
   W4_GAP();
 
   // One pipeline step = unit u of q-block QB (u & 1).
@@ -855,7 +865,9 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) ltot[qb] = lsum[qb] + __shfl_xor(lsum[qb], 32, 64);
   }
+#ifdef W4_KEEP_DRAINS
   W4_DRAIN_MFMA();                               // the last MFMA results before the VALU reads them
+#endif
   if constexpr (!LV) {
     ltot[0] = ol[0][0];                          // every row of the ones-block holds the full row sum
     ltot[1] = ol[1][0];
@@ -1007,7 +1019,7 @@ static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, 
     if (fa.localSizeBytes != 0)
       return fail("attention: attn_w4_kernel<%d> spills %zu bytes per lane -- attention_w4.hip must be compiled with "
                   "-mllvm -amdgpu-mfma-vgpr-form", MODE, (size_t)fa.localSizeBytes);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_W4) != hipSuccess)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_W4 + ((W4_ABL & 256) ? 4096 : 0)) != hipSuccess)
       return fail("attention: cannot raise dynamic LDS limit to %d bytes", ATT_LDS_W4);
     attr_set = true;
   }
@@ -1017,7 +1029,7 @@ static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, 
     T_items = (int)grid;
     grid = (unsigned)g_w4_grid();
   }
-  attn_w4_kernel<MODE><<<grid, 256, ATT_LDS_W4, st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
+  attn_w4_kernel<MODE><<<grid, 256, ATT_LDS_W4 + ((W4_ABL & 256) ? 4096 : 0), st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
                                                        a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
                                                        a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, part, T_items);
   return 0;
