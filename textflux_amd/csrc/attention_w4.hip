@@ -140,15 +140,6 @@ __device__ __forceinline__ uint32_t w4_cvt_pk(float lo, float hi) {
   asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
-// the same behind one idle issue slot: for schedules in which hipcc is free to sink the (compiler-visible) v_exp_f32 of the region
-// before to that region's end, i.e. right in front of this (invisible) reader of its result -- a transcendental result needs one
-// instruction in between (tools/check_mfma_hazard.py found exactly that in MODE 4's first, P.V-less step)
-__device__ __forceinline__ uint32_t w4_cvt_pk_gap(float lo, float hi) {
-  uint32_t r;
-  asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
 // MODE 0: the round-2 bookkeeping (row sums and the reference offset on the matrix pipe: 76 MFMAs per 64-key tile, 64 of them
 // Q.K^T / P.V).  MODE 1: the row sums leave the matrix pipe -- with the swapped Q.K^T a query row is lane-local, so l += sum p is
 // eight v_dot2c_f32_bf16 (p0 * 1 + p1 * 1 + l: exactly the bf16 weights P.V multiplies) per unit, issued one step later in the
@@ -517,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       constexpr bool is_c = FT ? (k >= 22 || (k >= 3 && k <= 18 && k % 3 == 0)) : ((k == 23) || (k >= 3 && k < 22 && k % 3 == 0));
       if constexpr (is_c) {
         constexpr int c = FT ? (k >= 22 ? k - 16 : k / 3 - 1) : (k == 23 ? 7 : k / 3 - 1);
-        pf[QB][c >> 2][c & 3] = NOREF ? w4_cvt_pk_gap(cur[2 * c], cur[2 * c + 1]) : w4_cvt_pk(cur[2 * c], cur[2 * c + 1]);
+        pf[QB][c >> 2][c & 3] = w4_cvt_pk(cur[2 * c], cur[2 * c + 1]);
       } else {
         constexpr int e = FT ? (k < 3 ? k : k >= 19 ? k - 6 : k - (k / 3))
                              : (k < 3 ? k : k == 22 ? 15 : k - (k / 3));      // exponentials seen so far = index minus packs before it
@@ -730,47 +721,58 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     W4_GAP();
     } else if constexpr (MODE == 4) {
     // the caller vouches for |score| <= W4_BIG (AttnArgs::score_bound): no reference at all -- no row maximum, no branch, no offset
-    // MFMA; the exponentials start with the step and spread over all 18 regions (one staging piece each in 16 of them)
-    S(IC<1>{}); W4_TOUCH(cur); F(IC<0>{}); G(IC<0>{});
+    // MFMA; the exponentials start with the step and spread over all 18 regions (one staging piece each in 16 of them).  Every pack
+    // reads exponentials that are at least TWO regions old (e0 e1 | e2 | e3 | c0 e4 | e5 | c1 e6 | ...), so whatever order hipcc gives
+    // the instructions inside a region -- it is free to sink the compiler-visible v_exp_f32 behind the region's asm pack, or to hoist
+    // the next region's pack over its MFMA -- an MFMA lies between a transcendental result and its (invisible) reader; the first
+    // version kept one region of distance and needed an s_nop in front of every pack (tools/check_mfma_hazard.py found the P.V-less
+    // first step's violations)
+    auto E = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int e = decltype(Ic)::value;
+      if constexpr (!(W4_ABL & 1)) cur[e] = __builtin_amdgcn_exp2f(cur[e]);
+    };
+    auto C2 = [&](auto Ic) __attribute__((always_inline)) {
+      constexpr int c = decltype(Ic)::value;
+      if constexpr (!(W4_ABL & 1)) pf[QB][c >> 2][c & 3] = w4_cvt_pk(cur[2 * c], cur[2 * c + 1]);
+    };
+    S(IC<1>{}); W4_TOUCH(cur); E(IC<0>{}); E(IC<1>{}); G(IC<0>{});
     W4_GAP();
-    P(IC<0>{}); F(IC<1>{}); G(IC<1>{});
+    P(IC<0>{}); E(IC<2>{}); G(IC<1>{});
     W4_GAP();
-    S(IC<2>{}); F(IC<2>{}); G(IC<2>{});
+    S(IC<2>{}); E(IC<3>{}); G(IC<2>{});
     W4_GAP();
-    P(IC<1>{}); F(IC<3>{}); F(IC<4>{}); G(IC<3>{});
+    P(IC<1>{}); C2(IC<0>{}); E(IC<4>{}); G(IC<3>{});
     W4_GAP();
-    S(IC<3>{}); F(IC<5>{}); G(IC<4>{});
+    S(IC<3>{}); E(IC<5>{}); G(IC<4>{});
     W4_GAP();
-    P(IC<2>{}); F(IC<6>{}); G(IC<5>{});
+    P(IC<2>{}); C2(IC<1>{}); E(IC<6>{}); G(IC<5>{});
     W4_GAP();
-    S(IC<4>{}); F(IC<7>{}); F(IC<8>{}); G(IC<6>{});
+    S(IC<4>{}); E(IC<7>{}); G(IC<6>{});
     W4_GAP();
-    P(IC<3>{}); F(IC<9>{}); G(IC<7>{});
+    P(IC<3>{}); C2(IC<2>{}); E(IC<8>{}); G(IC<7>{});
     W4_GAP();
-    S(IC<5>{}); F(IC<10>{}); G(IC<8>{});
+    S(IC<5>{}); E(IC<9>{}); G(IC<8>{});
     W4_GAP();
-    P(IC<4>{}); F(IC<11>{}); F(IC<12>{}); G(IC<9>{});
+    P(IC<4>{}); C2(IC<3>{}); E(IC<10>{}); G(IC<9>{});
     W4_GAP();
-    S(IC<6>{}); F(IC<13>{}); G(IC<10>{});
+    S(IC<6>{}); E(IC<11>{}); G(IC<10>{});
     W4_GAP();
-    P(IC<5>{}); F(IC<14>{}); G(IC<11>{});
+    P(IC<5>{}); C2(IC<4>{}); E(IC<12>{}); G(IC<11>{});
     W4_GAP();
-    S(IC<7>{}); F(IC<15>{}); F(IC<16>{}); G(IC<12>{});
+    S(IC<7>{}); E(IC<13>{}); G(IC<12>{});
     W4_GAP();
-    P(IC<6>{}); F(IC<17>{}); G(IC<13>{});
+    P(IC<6>{}); C2(IC<5>{}); E(IC<14>{}); G(IC<13>{});
     W4_GAP();
-    S(IC<8>{}); F(IC<18>{}); G(IC<14>{});
+    S(IC<8>{}); E(IC<15>{}); G(IC<14>{});
 #ifdef W4_HAZARD_SELFTEST
     { const float t_ = w4_max(nxt[0], nxt[1]); asm volatile("" ::"v"(t_)); }
 #endif
     W4_GAP();
-    P(IC<7>{}); F(IC<19>{}); G(IC<15>{});
+    P(IC<7>{}); C2(IC<6>{}); G(IC<15>{});
     W4_GAP();
-    P(IC<8>{}); F(IC<20>{}); F(IC<21>{});
+    P(IC<8>{});
     W4_GAP();
-    P(IC<9>{}); F(IC<22>{});
-    W4_GAP();
-    F(IC<23>{});
+    P(IC<9>{}); C2(IC<7>{});
     W4_GAP();
     } else {
     // 16 MFMAs on ordinary data (S(1) starts the chain; the reference offset joins it, out of line, only while a row has one)
