@@ -154,6 +154,13 @@ __device__ __forceinline__ uint32_t w4_cvt_pk(float lo, float hi) {
 // MODE 4: no reference at all (no row maximum, no branch, no offset MFMA) -- only launched when the caller vouches for
 // |score| <= W4_BIG in the exp2 domain (AttnArgs::score_bound; the DiT derives it from the q / k RMSNorm weights: after the
 // norm |q| <= sqrt(128) max|w_q|, RoPE preserves the norm, so |q . k| scale log2 e <= 128 max|w_q| max|w_k| 0.1275).
+#ifdef TFX_BENCH
+// bench library only (tools/attn_item_timers.py): s_memtime sums of wave 0 per workgroup {prologue, tile loop, output, items}
+__device__ unsigned long long* g_w4_timers = nullptr;
+#define W4_STAMP(i) do { if (wave == 0) w4_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W4_STAMP(i) ((void)0)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
                                                          const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq, int64_t ldk,
@@ -221,7 +228,11 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   bf16x8 qn[2][8];               // persistent form: the NEXT item's Q rows (raw), requested inside this item's last tile
   bool have_pref = false;        // ... and whether qn / kreg / vreg hold this item's Q rows / first K, V tile already
   u32x4 kreg[4], vreg[4];        // staging registers: thread t moves the 16-byte chunks (row t / 16 + 16 i, chunk t % 16), i = 0..3, of a tile's K and V
+#ifdef TFX_BENCH
+  unsigned long long w4_stamp[4] = {0, 0, 0, 0}, w4_sum[4] = {0, 0, 0, 0};
+#endif
   for (;;) {                     // one pass per item (exactly one in the non-persistent form)
+  W4_STAMP(0);
   const bool has_next = item + item_step < item_end;      // (false in the non-persistent form: all three are 0)
   const int item2 = item + item_step;
   const int qblk2 = item2 % nqb, h2 = (item2 / nqb) % H, b2 = item2 / (nqb * H);
@@ -846,12 +857,14 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     if (!(W4_ABL & 16)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+  W4_STAMP(1);
   tile(0, IC<0>{}, IC<1>{});
   for (int j = 1; j < nkv; j += 3) {
     tile(j, IC<1>{}, IC<0>{});
     if (j + 1 < nkv) tile(j + 1, IC<2>{}, IC<0>{});
     if (j + 2 < nkv) tile(j + 2, IC<0>{}, IC<0>{});
   }
+  W4_STAMP(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requests past the end of the sequence (zeros) still write their registers
   // ---- drain: the pending P.V of the very last unit (last tile: kb1, q1), V fragments already in registers
 #pragma unroll
@@ -923,6 +936,12 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OROW + ch * 16);
     if (row0 + row < N) *reinterpret_cast<u32x4*>(Ob + (int64_t)(row0 + row) * ldo + ch * 8) = v;
   }
+#ifdef TFX_BENCH
+  W4_STAMP(3);
+  w4_sum[0] += w4_stamp[1] - w4_stamp[0]; w4_sum[1] += w4_stamp[2] - w4_stamp[1]; w4_sum[2] += w4_stamp[3] - w4_stamp[2]; w4_sum[3] += 1;
+  if (!has_next && g_w4_timers && tid == 0)
+    for (int i = 0; i < 4; ++i) atomicAdd(g_w4_timers + i, w4_sum[i]);
+#endif
   if (!has_next) break;
   item = item2; b = b2; h = h2; qblk = qblk2;
   have_pref = true;
@@ -1008,6 +1027,12 @@ static int g_w4_grid() {         // workgroups of the persistent form: one per C
   }
   return grid;
 }
+
+#ifdef TFX_BENCH
+extern "C" void tfx_bench_attn_timers(unsigned long long* dev) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w4_timers), &dev, sizeof(dev));
+}
+#endif
 
 template <int MODE>
 static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, int nfull, int nparts, int nsplit, int xsplit, float* part) {
