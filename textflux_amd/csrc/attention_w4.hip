@@ -182,10 +182,9 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   // re-streams all K / V from HBM at the end, no gain; whole heads -- nfull is no longer a multiple of the CU count, some CUs run
   // three halves in a row, 1.4 % slower than no split.)
   // PERSISTENT form (T_items > 0; round 4): one workgroup per CU walks its XCD's contiguous range of the T_items (b, h, q-tile)
-  // items.  A fresh workgroup costs ~10 us before its first tile and after its last (dispatch, two dependent memory round trips
-  // for Q and the first K / V tiles, the output: tools/attn_fixed_cost.py, 10 % of a 72-tile item); here the next item's Q rows and
-  // its first K / V tile are requested inside the current item's last tile and wait in registers, so that only the output
-  // of an item and the conversion of the next Q stand between two items' MFMA streams.
+  // items.  A fresh workgroup spends 12 k cycles (plus its dispatch) in front of its first tile -- two dependent memory round trips
+  // for Q and the first K / V tiles; here the next item's Q rows and its first K / V tile are requested behind the current item's
+  // tile loop and fly while its output is normalised, staged and stored: 6 k cycles (tools/attn_item_timers.py).
   int kpart = -1, ptile = 0, qblk, h, b;
   int item = 0, item_step = 0, item_end = 0;
   if (T_items > 0) {
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     h = bid % H;
     b = bid / H;
   }
-  bf16x8 qn[2][8];               // persistent form: the NEXT item's Q rows (raw), requested inside this item's last tile
+  bf16x8 qn[2][8];               // persistent form: the NEXT item's Q rows (raw), requested behind this item's tile loop
   bool have_pref = false;        // ... and whether qn / kreg / vreg hold this item's Q rows / first K, V tile already
   u32x4 kreg[4], vreg[4];        // staging registers: thread t moves the 16-byte chunks (row t / 16 + 16 i, chunk t % 16), i = 0..3, of a tile's K and V
 #ifdef TFX_BENCH
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
       for (int s = 0; s < 8; ++s) qf[qb][s] = *reinterpret_cast<const bf16x8*>(Qb + (int64_t)rc * ldq + s * 16 + hi * 8);
     }
   }
-  // the next item's Q rows -> qn (called from this item's last tile)
+  // the next item's Q rows -> qn (requested behind the tile loop)
   auto load_qn = [&]() __attribute__((always_inline)) {
     const bf16_t* Qb2 = Q + b2 * q_bs + h2 * W4_HD;
 #pragma unroll
@@ -830,8 +829,6 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   };
 
   const int j_rag = (Nk & (W4_KV - 1)) ? nkv - 1 : -1;          // the tile whose key blocks reach past N
-  const int j_last = has_next ? nkv - 1 : -1;                  // persistent form: the tiles that carry the next item's requests
-  const int j_qn = has_next ? (nkv > 1 ? nkv - 2 : 0) : -1;
   // one 64-key tile j out of ring buffer B (compile-time: every fragment address is a per-lane base plus an immediate)
   auto tile = [&](int j, auto Bc, auto FIRSTc) __attribute__((always_inline)) {
     constexpr int B = decltype(Bc)::value, NB = (B + 1) % 3, WB = (B + 2) % 3;
@@ -839,15 +836,12 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     // (one scalar compare each against tile indices fixed in front of the loop: with one wave per SIMD every scalar instruction of
     // the tile loop is issue time)
     const bool rag = j == j_rag;
-    const bool last = j == j_last;                  // persistent form: this tile's staging step requests the NEXT item's first tile
-    if (__builtin_expect_with_probability(j == j_qn, 0, 1.0)) load_qn();   // ... and the tile before, its Q rows
     // (kb0, q0): S(kb0, q1);  pending (tile j-1: kb1, q1);  reload kf <- K(j) kb1, vf <- V(j) kb0
     step(IC<0>{}, IC<!FIRST>{}, IC<FIRST>{}, IC<B * W4_KT + 32 * W4_KROW>{}, IC<B * W4_VT>{}, IC<0>{}, 0, rag, j * W4_KV);
     // (kb0, q1): S(kb1, q0);  pending (kb0, q0);  + staging: tile j + 2 (requested one tile ago) goes into the buffer tile j - 1
     // left before the last barrier, and each register is refilled with its piece of tile j + 3 right behind its write -- four
     // steps (> 1 us) before it is needed: with one wave per SIMD nothing else runs while a wave waits for memory
-    if (__builtin_expect_with_probability(last, 0, 1.0)) { rsKs = rsK2; rsVs = rsV2; }
-    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<1 + 4 * WB>{}, last ? 0 : j + 3, rag, j * W4_KV);
+    step(IC<1>{}, IC<1>{}, IC<FIRST>{}, IC<0>{}, IC<0>{}, IC<1 + 4 * WB>{}, j + 3, rag, j * W4_KV);
     // (kb1, q0): S(kb1, q1);  pending (kb0, q1);  reload kf <- K(j+1) kb0, vf <- V(j) kb1
     step(IC<0>{}, IC<1>{}, IC<0>{}, IC<NB * W4_KT>{}, IC<B * W4_VT + 2 * 16 * 256>{}, IC<0>{}, 0, rag, j * W4_KV + 32);
     // (kb1, q1): S(tile j+1: kb0, q0);  pending (kb1, q0)
@@ -866,6 +860,12 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   }
   W4_STAMP(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // requests past the end of the sequence (zeros) still write their registers
+  // persistent form: the NEXT item's Q rows are requested here, behind the tile loop, and fly while this item's output is normalised,
+  // staged and stored; its first K / V tile is requested behind the output's stores and flies under the next prologue's Q conversion.
+  // (Measured on the way, tools/attn_item_timers.py: requests from inside the last tiles cost EVERY tile ~60 cycles -- even a single
+  // compare + branch per tile: the next-Q registers live across the loop --, 4.2 k per item; all 24 requests in one burst here make the
+  // output's stores queue behind them, +4.6 k.)
+  if (has_next) load_qn();
   // ---- drain: the pending P.V of the very last unit (last tile: kb1, q1), V fragments already in registers
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
@@ -943,9 +943,17 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     for (int i = 0; i < 4; ++i) atomicAdd(g_w4_timers + i, w4_sum[i]);
 #endif
   if (!has_next) break;
+  rsKs = rsK2;
+  rsVs = rsV2;
+  load_tile(0);                                   // the next item's first K / V tile (its descriptors; kreg / vreg are idle until the next prologue writes them)
   item = item2; b = b2; h = h2; qblk = qblk2;
   have_pref = true;
-  __syncthreads();                                // every wave has read its output tile out of LDS: the ring buffers are free for the next item
+  // every wave has read its output tile out of LDS: the ring buffers are free for the next item.  A bare barrier behind an LDS-only
+  // wait -- __syncthreads() would also wait for the next item's requests that were just issued (4.6 k cycles per item, measured)
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
   }
 }
 
