@@ -73,7 +73,7 @@ constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
 
 #define W4_GAP() __builtin_amdgcn_sched_barrier(0)
 #ifndef W4_ABL
-#define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier, 64 no staging writes (requests kept), 128 no staging requests (writes kept), 256 requests as LDS-DMA into a scratch region (use with 64)
+#define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier, 64 no staging writes (requests kept), 128 no staging requests (writes kept), 256 requests as LDS-DMA into a scratch region (use with 64), 512 V fragments by one ds_read_b128 (a transposed V tile)
 #endif
 // wait until every issued MFMA has written its result (there is no counter for the matrix pipe): 24 x 16 idle issue slots,
 // used twice per workgroup (before the first softmax, before the output)
@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   };
   auto vread = [&](int voff, int ks, int db) __attribute__((always_inline)) -> bf16x8 {
     const char* va = rV[db] + voff + ks * 16 * 256;
+    if constexpr (W4_ABL & 512) return *reinterpret_cast<const bf16x8*>(rK + voff + ks * 16 * 256 + db * 64);   // timing ablation: what a V^T tile would cost to read (one b128, K's conflict-free pattern)
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va));
     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 8 * 256));
     return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));

@@ -20,7 +20,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         print(json.dumps(dict(lib=os.path.basename(os.environ.get("TFX_LIB", "default")), mode=mode, data="zero" if zero else "random", ms=round(t * 1e3, 4))), flush=True)
 else:
     modes = sys.argv[1:] or ["30", "32"]
-    for abl in ([""] if os.environ.get("W4_NO_ABL") else ["", "1", "2", "4", "64", "320", "128", "8", "16", "6", "31"]):
+    abls = os.environ["W4_ABL_LIST"].split(",") if os.environ.get("W4_ABL_LIST") else ["1", "2", "4", "64", "320", "128", "8", "16", "6", "31", "512"]
+    for abl in ([""] if os.environ.get("W4_NO_ABL") else [""] + abls):
         env = dict(os.environ)
         if abl:
             env["TFX_LIB"] = os.path.join(REPO, "textflux_amd", f"libtextflux_hip_exp_abl{abl}.so")
