@@ -145,7 +145,23 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int GLDS_AUX = 0;        // default cache policy of the operand prefetch
+// Cache-policy bits of the kernel's three global streams (buffer instructions' aux operand: bit 0 sc0, bit 1 nt, bit 4 sc1); the macros exist
+// for A/B builds (tools/run_r04_cachepolicy.sh, profiles/r04_cachepolicy.log).  Round 4: the OUTPUT stores are non-temporal -- a tile's 128 KiB of
+// results are written once and not read by this kernel, and without the hint each round of epilogues (32 CUs x 128 KiB = one XCD's whole 4 MiB L2)
+// pushes the operand panels the next tiles are about to share out of L2: 444.6 -> 439.6 ms per DiT forward on one box, 432.1 -> 429.9 on another.
+// nt on the operand REQUESTS is a disaster (618 ms: the panels ARE the reuse); nt on the residual reads, sc0 / sc1 on the stores: no difference.
+#ifndef TFX_GLDS_AUX
+#define TFX_GLDS_AUX 0
+#endif
+#ifndef TFX_GSTORE_AUX
+#define TFX_GSTORE_AUX 2
+#endif
+constexpr int GLDS_AUX = TFX_GLDS_AUX;      // operand prefetch (LDS-DMA requests)
+constexpr int GSTORE_AUX = TFX_GSTORE_AUX;  // epilogue's output stores
+#ifndef TFX_GRES_AUX
+#define TFX_GRES_AUX 0
+#endif
+constexpr int GRES_AUX = TFX_GRES_AUX;      // epilogue's residual reads (read once)
 constexpr int LDS_X = 0;            // X_g set s at g*32768 + s*16384   (128 rows x 128 B)
 constexpr int LDS_W = 65536;        // W   set s at 65536 + s*32768     (256 rows x 128 B)
 constexpr int LDS_DUMMY = 131072;   // 8 x 1 KiB sink for out-of-range prefetches (keeps vmcnt counts uniform)
@@ -261,7 +277,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
   auto load_res = [&](int blk, u32x4 (&rr)[4]) {
 #pragma unroll
     for (int itr = 0; itr < 4; ++itr)
-      rr[itr] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)((uint32_t)(blk * 32 + itr * 8 + crow) * (uint32_t)(p.ldr * 2) + col_off), 0, 0);
+      rr[itr] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)((uint32_t)(blk * 32 + itr * 8 + crow) * (uint32_t)(p.ldr * 2) + col_off), 0, GRES_AUX);
   };
   if constexpr (FP8) {
     // dequantise in place first (row scale x channel scale): the scale registers are dead before bias / gate / residual are
@@ -456,7 +472,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
 #pragma unroll
       for (int itr = 0; itr < 4; ++itr)
         __builtin_amdgcn_raw_buffer_store_b128(vals[itr], rsrcC,
-                                               (int)((uint32_t)(blk * 32 + itr * 8 + crow) * (uint32_t)(p.ldc * 2) + col_off), 0, 0);
+                                               (int)((uint32_t)(blk * 32 + itr * 8 + crow) * (uint32_t)(p.ldc * 2) + col_off), 0, GSTORE_AUX);
       if (QKN) __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -1243,7 +1259,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
       auto load_res = [&](int blk) {
 #pragma unroll
         for (int itr = 0; itr < 8; ++itr)
-          rr[itr] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)((uint32_t)(blk * 32 + itr * 4 + crow) * (uint32_t)(p.ldr * 2) + col_off), 0, 0);
+          rr[itr] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)((uint32_t)(blk * 32 + itr * 4 + crow) * (uint32_t)(p.ldr * 2) + col_off), 0, GRES_AUX);
       };
       if (HAS_RES) load_res(0);
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): bias / gate / residual, and every operand request up to the next tile's first four sub-tiles
@@ -1364,7 +1380,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
 #pragma unroll
           for (int itr = 0; itr < 8; ++itr)
             __builtin_amdgcn_raw_buffer_store_b128(vals[itr], rsrcC,
-                                                   (int)((uint32_t)(blk * 32 + itr * 4 + crow) * (uint32_t)(p.ldc * 2) + col_off), 0, 0);
+                                                   (int)((uint32_t)(blk * 32 + itr * 4 + crow) * (uint32_t)(p.ldc * 2) + col_off), 0, GSTORE_AUX);
           __builtin_amdgcn_sched_barrier(0);
         }
       };
