@@ -294,6 +294,11 @@ def main():
         t_pt, t_pil = min(timed("pt"), timed("pt")), min(timed("pil"), timed("pil"))
         pil_delta_ms = (t_pil - t_pt) * 1e3
     seen = tdist.ranks_seen(dev)   # ranks that answered an RCCL all-reduce
+    # results travel to rank 0 the way the batch driver collects them (untimed here: `value` is generation throughput): a per-image
+    # checksum of every rank's last call, gathered over RCCL -- rank 0 checks that every rank produced finite images
+    sums = tdist.gather_to_rank0(out.float().mean(dim=(1, 2, 3)).contiguous())
+    if rank == 0:
+        assert len(sums) == world and all(torch.isfinite(x).all() for x in sums), "a rank returned non-finite images"
 
     if rank == 0:
         gemm_ms, gemm_fl, gemm_n = ops.prof_collect(2 if a.fp8 else 0)   # fp8 run: the e4m3 GEMM launches are the dominant kernel
@@ -353,7 +358,7 @@ def main():
                                    + ("" if full else f" [REDUCED MODEL {a.layers} - not a valid headline]")
                                    + (" [fp8 linears: BASELINE config 5 precision, not the bf16 headline]" if a.fp8 else ""),
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards; shared CLIP conditioning broadcast over RCCL, T5 prompts encoded per rank)"},
-            "rccl_ranks_seen": seen,
+            "rccl_ranks_seen": seen, "process_group": tdist.group_info(),
             "elapsed_s": elapsed, "elapsed_per_rank_s": {"min": min(own_all), "max": max(own_all), "ranks": own_all,
                                                          "note": "each rank's own K calls up to its synchronize(), before the closing barrier"},
             "pil_output_delta_ms_per_call": pil_delta_ms,

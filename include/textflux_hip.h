@@ -29,10 +29,11 @@ const char* tfx_version(void);
 const char* tfx_last_error(void);
 /* ABI stamp.  TFX_ABI_VERSION is bumped whenever a struct below grows or the meaning of a field / entry point changes;
  * tfx_abi_info writes {TFX_ABI_VERSION the library was built with, sizeof(tfx_gemm_args), sizeof(tfx_attn_args),
- * sizeof(tfx_dit_desc), sizeof(tfx_step_desc)} (as many as fit in n) and returns how many values there are.  A binding
+ * sizeof(tfx_dit_desc), sizeof(tfx_step_desc), sizeof(tfx_double_block), sizeof(tfx_single_block)} (as many as fit in n; the last
+ * two since ABI 6) and returns how many values there are.  A binding
  * compares them with its own view of this header BEFORE the first call that passes a struct: a library built from an older
  * header would otherwise ignore the tail fields of a grown struct silently (no reference counterpart: the reference has no FFI). */
-#define TFX_ABI_VERSION 5
+#define TFX_ABI_VERSION 6
 int tfx_abi_info(int32_t* out, int n);
 /* Writes the gcnArchName of the current device (e.g. "gfx950:sramecc+:xnack-") into buf.  Needs a GPU. */
 int tfx_query_arch(char* buf, int buflen);
@@ -100,6 +101,21 @@ int tfx_rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int32_t q_off, int3
                      int32_t T, int32_t B, const void* wq_img, const void* wk_img, const void* wq_txt,
                      const void* wk_txt, const float* cos_tab, const float* sin_tab, float eps, tfx_stream stream);
 
+/* the name SURVEY.md §8(b) lists for the same entry point (q AND k of one fused buffer): identical arguments and behaviour */
+int tfx_rmsnorm_rope_qk(void* buf, int64_t ld, int64_t bstride, int32_t q_off, int32_t k_off, int32_t H, int32_t Ntok,
+                        int32_t T, int32_t B, const void* wq_img, const void* wk_img, const void* wq_txt,
+                        const void* wk_txt, const float* cos_tab, const float* sin_tab, float eps, tfx_stream stream);
+
+/* ---- gated residual out[b][r, :] = res[b][r, :] + bf16(gate[b][:] * x[b][r, :])   (transformer_flux.py:733-735, 817-818, 824-826,
+ *      830-831, 837: `hidden_states + gate.unsqueeze(1) * attn_output`; the product is rounded to bf16 before the add, as the
+ *      reference's two bf16 ops do).  Standalone form of tfx_gemm_args.epilogue 2 for a caller that keeps its own Linear (the
+ *      attention-processor plugin level); inside tfx_dit_forward the same arithmetic runs in the producing GEMM's epilogue.
+ *      x, res, out: bf16 [batch][rows_per_batch, D] with row strides ldx / ldr / ldo and batch strides; gate: bf16 [batch][D] with
+ *      batch stride gate_bstride.  D % 8 == 0; out may alias res or x. */
+int tfx_gate_residual(const void* x, int64_t ldx, int64_t x_bstride, const void* gate, int64_t gate_bstride, const void* res,
+                      int64_t ldr, int64_t r_bstride, void* out, int64_t ldo, int64_t o_bstride, int32_t rows_per_batch,
+                      int32_t batch, int32_t D, tfx_stream stream);
+
 /* ---- joint attention softmax(q k^T * scale) v, head_dim 128, no mask (F.scaled_dot_product_attention,
  *      D/models/attention_processor.py:2039-2041).  Element (b, n, h, d) of q is q[b*q_bstride + n*ldq + h*128 + d];
  *      same for k, v, o.  o may alias q. */
@@ -110,10 +126,11 @@ typedef struct tfx_attn_args {
   int32_t B, H, N;
   float scale;
   /* optional promise of the caller: |scale * q . k| <= score_bound for every (query, key) pair, 0 = unknown.  Softmax does not
-   * depend on the reference that is subtracted before the exponential; with a bound of at most 41 (2^+-60 in fp32 / bf16, whose
-   * exponent range holds such weights and their sums over 2^13 keys) the kernel subtracts none: no running row maximum, no
-   * rescaling branch.  tfx_dit_forward derives the bound from the q / k RMSNorm weights (after the norm |q| <= sqrt(128) max|w_q|,
-   * RoPE preserves it).  A wrong promise can overflow to inf / NaN; 0 keeps the kernel's own overflow guard. */
+   * depend on the reference that is subtracted before the exponential; when score_bound * log2(e) + log2(N) + 24 <= 126 (P1024's
+   * N = 4608: score_bound <= 62.2; every weight 2^+-90 at most, and a row's sum over N keys times |v| up to 2^24 stays inside the
+   * exponent range fp32 and bf16 share) the kernel subtracts none: no running row maximum, no rescaling branch.  tfx_dit_forward
+   * takes the bound per block from that block's q / k RMSNorm weights (after the norm |q| <= sqrt(128) max|w_q|, RoPE preserves
+   * it).  A wrong promise can overflow to inf / NaN; 0 (or a bound beyond the limit) keeps the kernel's own overflow guard. */
   float score_bound;
 } tfx_attn_args;
 int tfx_joint_attention(const tfx_attn_args* args, tfx_stream stream);
@@ -156,13 +173,19 @@ int tfx_advance_step(int32_t* step_ptr, tfx_stream stream);
 /* w8 / w8_scale (optional, may be NULL): the same weight as e4m3 bytes [out,in] with one fp32 scale per output channel
  * (tfx_quantize_rows_fp8 of w); used when tfx_dit_desc.flags bit 2 is set and in % 256 == 0, see below. */
 typedef struct tfx_linear { const void* w; const void* b; const void* w8; const float* w8_scale; } tfx_linear;
+/* attn_score_bound (ABI 6, optional): tfx_attn_args.score_bound of THIS block's attention launch, from this block's own q / k
+ * RMSNorm weights -- 128 * max(max|norm_q|, max|norm_added_q|) * max(max|norm_k|, max|norm_added_k|) * 128^-0.5 (+ rounding margin).
+ * 0 = unknown: the launch falls back to tfx_dit_desc.attn_score_bound (0 there too = no promise).  Per block, so that one block
+ * with large norm scales only changes the form of its own attention launch. */
 typedef struct tfx_double_block {
   tfx_linear qkv_img, qkv_txt, out_img, out_txt, ff1_img, ff2_img, ff1_txt, ff2_txt;
   const void *norm_q, *norm_k, *norm_added_q, *norm_added_k;
+  float attn_score_bound;
 } tfx_double_block;
 typedef struct tfx_single_block {
   tfx_linear qkv_mlp, proj_out;
   const void *norm_q, *norm_k;
+  float attn_score_bound;
 } tfx_single_block;
 typedef struct tfx_dit_desc {
   int32_t D, H, in_channels, out_channels, n_double, n_single;
@@ -197,8 +220,9 @@ typedef struct tfx_dit_desc {
    * bit-identical to tfx_euler_step on the stored model output -- i.e. the latent state lives IN the x_embedder input, `out` is
    * not written, and there is neither a scheduler launch nor a copy of the new latents into the next step's input. */
   const void* euler_gate; int64_t euler_gate_bstride;
-  /* optional: tfx_attn_args.score_bound for every attention launch of the forward (0 = unknown).  The caller derives it from the
-   * q / k RMSNorm weights of all blocks: 128 * max|w_q| * max|w_k| * 128^-0.5 (text-stream norms included), see tfx_attn_args. */
+  /* optional: tfx_attn_args.score_bound for the attention launches of blocks whose own attn_score_bound is 0 (0 = unknown).  The
+   * caller derives it from the q / k RMSNorm weights: 128 * max|w_q| * max|w_k| * 128^-0.5 (text-stream norms included), see
+   * tfx_attn_args; since ABI 6 the per-block fields are the ones the engine fills. */
   float attn_score_bound;
 } tfx_dit_desc;
 int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
@@ -374,6 +398,11 @@ int tfx_set_option(const char* name, int value);
  * returns the summed kernel time, FLOPs and launch count (kind 2: fp8 GEMM launches), then clears the records.  Not capturable into a graph. */
 int tfx_prof_enable(int on);
 int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches);
+/* Which form of the attention kernel the launches took (host-side counters, also counted at graph capture, not at replay):
+ * counts[0..7] = launches since the last reset of { 0: kernel 30 with its own overflow guard, 1..3: its option-31..33 variants,
+ * 4: kernel 30 reference-free (score_bound accepted), 5: attention_hp (20), 6: the 16 x 16 kernel (40), 7: any other schedule }.
+ * Copies min(n, 8) counters, then clears them when reset != 0.  Returns the number copied. */
+int tfx_attention_mode_counts(int64_t* counts, int32_t n, int32_t reset);
 /* Phase timing of the attention kernels (tools/attn_timing.py): buf = device uint64 [blocks][8 waves][4 phases] that the
  * instrumented kernel variants fill with cycle counts, NULL switches back to the plain kernels. */
 int tfx_debug_attention_timing(void* buf);

@@ -94,6 +94,7 @@ def denoise(
     sched_cfg: Optional[dict] = None,
     model_fn: Optional[Callable] = None,
     max_steps: Optional[int] = None,   # stop after this many steps of the num_inference_steps schedule (full-size tests)
+    teacher: Optional[Sequence[Tensor]] = None,   # teacher forcing: step i > 0 starts from teacher[i - 1] instead of its own result
 ) -> Tuple[Tensor, List[Tensor]]:
     """Steps 4-7 of FluxFillPipeline.__call__ with `latents=`/`masked_image_latents=`/`prompt_embeds=` injected
     and output_type='latent' (P:2012-2116).  Returns (final latents, per-step latents)."""
@@ -114,6 +115,8 @@ def denoise(
     for i, t in enumerate(timesteps):
         if max_steps is not None and i >= max_steps:
             break
+        if teacher is not None and i > 0:
+            latents = teacher[i - 1].to(dtype).reshape(latents.shape)
         timestep = t.expand(B).to(latents.dtype)
         noise_pred = fwd(
             hidden_states=torch.cat((latents, masked_image_latents.to(latents.dtype)), dim=2),

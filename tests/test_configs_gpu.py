@@ -166,6 +166,37 @@ def test_headline_p1024_1024x1024_batch8_bf16(weights):
     run_config(weights, weights, 1024, 1024, 8, "euler")
 
 
+def test_p1024_one_block_beyond_the_score_bound_falls_back_alone(weights):
+    """the attention fast path is a property of each launch, not of the checkpoint as a whole.  At the headline
+    geometry (P1024, N = 4608) with the q / k RMSNorm weights of ONE block (single block 1) scaled so that max|w_q| max|w_k| exceeds what
+    the reference-free stream admits (score_bound * log2 e + log2 N + 24 <= 126: 5.3 at this N), that block's attention launch -- and
+    only that one -- runs the guarded kernel; the step still matches the bf16-faithful oracle within 1e-3, eager == graph.  Then the
+    norm weight is edited IN PLACE: the next call re-derives the bounds (version counters) instead of keeping a stale promise."""
+    from textflux_amd import ops
+    sd = dict(weights)
+    for n in ("norm_q", "norm_k"):
+        k = f"single_transformer_blocks.1.attn.{n}.weight"
+        sd[k] = (sd[k].float() * 2.5).to(BF)
+    pipe = make_pipe(sd, "euler")
+    tr = pipe.transformer
+    dbl, sgl = tr.attn_score_bounds()
+    lim = (126.0 - 24.0 - torch.log2(torch.tensor(4608.0)).item()) / 1.4426950408889634
+    assert len(dbl) == 1 and len(sgl) == 2 and dbl[0] < lim and sgl[0] < lim and sgl[1] > lim, (dbl, sgl, lim)
+    ops.attention_mode_counts(reset=True)
+    run_config(sd, sd, 1024, 1024, 1, "euler", steps=2, pipe=pipe)
+    c = ops.attention_mode_counts(reset=True)
+    # 2 eager steps with the callback + 30 eager steps + the graph's capture of one step (replays launch nothing host-side)
+    assert c["w4_reference_free"] == 2 * c["w4_guarded"] > 0 and sum(c.values()) == c["w4_reference_free"] + c["w4_guarded"], c
+    # in-place edit of a norm weight (same storage, new version): bounds and session follow
+    old_session = tr._session
+    tr.w["s0.norm_q"].mul_(3.0)
+    _, sgl2 = tr.attn_score_bounds()
+    assert sgl2[0] > 2.9 * sgl[0] and sgl2[1] == sgl[1]
+    S = 4096
+    assert tr.session(1, S, T_TXT) is not old_session
+    tr.w["s0.norm_q"].div_(3.0)
+
+
 def test_c4_sl1024_amo_lora_batch4(weights):
     """LoRA merged at load (rank 128, alpha = rank as TextFlux trains it) + the AMO sampler with injected eps; the oracle
     runs on W + (alpha / r) B A computed in fp32 from the same bf16 factors."""

@@ -596,3 +596,71 @@ def test_small_ops(ops):
     out = torch.zeros(2, 20, 256, dtype=BF, device="cuda")
     ops.copy_rows_(big, out[:, 4:13])
     assert torch.equal(out[:, 4:13], big) and out[:, :4].abs().max().item() == 0
+
+
+# ----------------------------------------------------------------------------- round 5: the boundary's remaining names
+def test_gate_residual_is_the_references_two_bf16_ops_bit_for_bit(ops):
+    """tfx_gate_residual: `hidden_states + gate.unsqueeze(1) * attn_output` (transformer_flux.py:733-735, 817-818) -- two bf16 ops in the
+    reference, reproduced bit for bit (ragged rows, strided views of wider buffers, in place over the residual), and equal to the
+    GEMM's gated-residual epilogue on the same rounded Linear output."""
+    B, R, D = 3, 37, 3072
+    x, g, r = rnd((B, R, D), 60).to(BF), rnd((B, D), 61).to(BF), rnd((B, R, D), 62).to(BF)
+    ref = r + g.unsqueeze(1) * x                                     # torch bf16: product rounded, then the add rounded
+    assert torch.equal(ops.gate_residual(x.cuda(), g.cuda(), r.cuda()).cpu(), ref)
+    wide = torch.zeros(B, R + 3, 2 * D, dtype=BF, device="cuda")     # x as a column slice, the result written in place over res
+    wide[:, 2:2 + R, D:] = x.cuda()
+    res = r.cuda().clone()
+    out = ops.gate_residual(wide[:, 2:2 + R, D:], g.cuda(), res, out=res)
+    assert out.data_ptr() == res.data_ptr() and torch.equal(res.cpu(), ref)
+    a, w, bias = rnd((B, R, 256), 63).to(BF), rnd((D, 256), 64, 0.05).to(BF), rnd((D,), 65).to(BF)
+    y = ops.gemm(a.cuda(), w.cuda(), bias.cuda())                    # the Linear's bf16 output, then the standalone op ...
+    fused = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), epilogue=2, gate=g.cuda(), res=r.cuda())      # ... == the fused epilogue
+    assert torch.equal(ops.gate_residual(y, g.cuda(), r.cuda()), fused)
+
+
+def test_rmsnorm_rope_qk_is_the_same_entry_point_under_survey_8b_name(ops, golden):
+    from textflux_amd import _lib as L
+    g = golden("g1_ops")
+    B, H, N, T = 2, 3, 29, 5
+    buf = rnd((B, N, 3 * H * 128), 70).to(BF).cuda()
+    w = [(1 + 0.1 * rnd((128,), 71 + i)).to(BF).cuda() for i in range(4)]
+    cos, sin = g["rope.cos"].cuda().contiguous(), g["rope.sin"].cuda().contiguous()
+    a, b = buf.clone(), buf.clone()
+    ops.rmsnorm_rope_(a, 2 * H * 128, 0, H, T, *w, cos, sin)
+    L.check(L.lib().tfx_rmsnorm_rope_qk(b.data_ptr(), b.stride(1), b.stride(0), 2 * H * 128, 0, H, N, T, B, w[0].data_ptr(),
+                                        w[1].data_ptr(), w[2].data_ptr(), w[3].data_ptr(), cos.data_ptr(), sin.data_ptr(), 1e-6,
+                                        torch.cuda.current_stream().cuda_stream), "rmsnorm_rope_qk")
+    assert torch.equal(a, b) and not torch.equal(a, buf)
+
+
+def test_attention_reference_free_stream_holds_up_to_the_edge_of_its_admissible_range(ops):
+    """The reference-free stream is admissible while score_bound * log2 e + log2 N + 24 <= 126 (attention.hip): scores of BOTH signs at
+    ~97 % of that bound in the same launch -- rows whose every score is near -b (weights 2^-84, the sum must not underflow), rows with
+    every score near +b (2^+84 summed over N keys), rows that mix both (the small weights vanish, as in exact arithmetic) -- with
+    |v| up to 4096, against fp64 softmax; the counters show which stream ran; one step beyond the bound the guarded kernel takes over."""
+    B, H, N = 1, 2, 2304
+    lim = (126.0 - 24.0 - torch.log2(torch.tensor(float(N))).item()) / 1.4426950408889634          # 62.9 for this N
+    u = torch.nn.functional.normalize(rnd((128,), 80), dim=0)
+    amp = (0.97 * lim / 128 ** -0.5) ** 0.5
+    g = torch.Generator().manual_seed(81)
+    sq = torch.where(torch.rand(B, N, H, 1, generator=g) < 0.5, -1.0, 1.0)       # sign of every query / key along u
+    sk = torch.where(torch.rand(B, N, H, 1, generator=g) < 0.5, -1.0, 1.0)
+    sk[:, :, 1] = 1.0                                                            # head 1: every key +u -> whole rows at +b or at -b
+    q = (sq * amp * u + 0.05 * torch.randn(B, N, H, 128, generator=g)).reshape(B, N, H * 128).to(BF)
+    k = (sk * amp * u + 0.05 * torch.randn(B, N, H, 128, generator=g)).reshape(B, N, H * 128).to(BF)
+    v = (torch.randn(B, N, H * 128, generator=g) * 1024).clamp(-4096, 4096).to(BF)
+    qh, kh, vh = (t.double().view(B, N, H, 128).transpose(1, 2) for t in (q, k, v))
+    sc = (qh @ kh.transpose(-1, -2)) * 128 ** -0.5
+    bound = sc.abs().max().item() * 1.001
+    assert 0.9 * lim < bound < lim and sc.min().item() < -0.9 * lim and sc.max().item() > 0.9 * lim
+    ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B, N, H * 128)
+    ops.attention_mode_counts(reset=True)
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), score_bound=bound)
+    assert ops.attention_mode_counts()["w4_reference_free"] == 1
+    close(got, ref.to(BF), max_rel=2e-2, mae_rel=6e-3)
+    guarded = ops.attention(q.cuda(), k.cuda(), v.cuda())
+    close(guarded, ref.to(BF), max_rel=2e-2, mae_rel=6e-3)
+    ops.attention_mode_counts(reset=True)
+    assert torch.equal(ops.attention(q.cuda(), k.cuda(), v.cuda(), score_bound=lim * 1.02), guarded)     # beyond the range: the guard stays
+    c = ops.attention_mode_counts(reset=True)
+    assert c["w4_guarded"] == 1 and c["w4_reference_free"] == 0

@@ -18,6 +18,11 @@ CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_int32, c_int64, c_float, c_char_p = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_char_p
 
+# TFX_ABI_VERSION of the include/textflux_hip.h the ctypes mirrors below were written against (tests/test_capi_symbols.py asserts
+# that it equals the header's): the library's stamp is compared with THIS constant, so a binding copied without include/ still
+# loads, and a ctypes mirror edited without the header (or the other way round) fails a test instead of passing the check.
+ABI_VERSION = 6
+
 
 class GemmArgs(C.Structure):
     _fields_ = [
@@ -49,11 +54,11 @@ class Linear(C.Structure):
 class DoubleBlock(C.Structure):
     _fields_ = [(n, Linear) for n in ("qkv_img", "qkv_txt", "out_img", "out_txt", "ff1_img", "ff2_img", "ff1_txt",
                                       "ff2_txt")] + [(n, c_void_p) for n in ("norm_q", "norm_k", "norm_added_q",
-                                                                             "norm_added_k")]
+                                                                             "norm_added_k")] + [("attn_score_bound", c_float)]
 
 
 class SingleBlock(C.Structure):
-    _fields_ = [("qkv_mlp", Linear), ("proj_out", Linear), ("norm_q", c_void_p), ("norm_k", c_void_p)]
+    _fields_ = [("qkv_mlp", Linear), ("proj_out", Linear), ("norm_q", c_void_p), ("norm_k", c_void_p), ("attn_score_bound", c_float)]
 
 
 class DitDesc(C.Structure):
@@ -100,6 +105,10 @@ SIGNATURES = {
     "tfx_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "tfx_rmsnorm_rope": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "tfx_rmsnorm_rope_qk": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "tfx_gate_residual": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                  c_int32, c_int32, c_int32, c_void_p]),
     "tfx_joint_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "tfx_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int32,
                                c_void_p]),
@@ -150,6 +159,7 @@ SIGNATURES = {
     "tfx_set_option": (c_int, [c_char_p, c_int]),
     "tfx_prof_enable": (c_int, [c_int]),
     "tfx_prof_collect": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
+    "tfx_attention_mode_counts": (c_int, [C.POINTER(c_int64), c_int32, c_int32]),
     "tfx_debug_attention_timing": (c_int, [c_void_p]),
 }
 
@@ -172,10 +182,17 @@ def _src_hash() -> str:
 
 
 def header_abi_version() -> int:
-    """TFX_ABI_VERSION of the include/textflux_hip.h this binding mirrors."""
+    """TFX_ABI_VERSION of include/textflux_hip.h (tests compare it with ABI_VERSION; lib() does not need the header)."""
     import re
-    with open(os.path.join(os.path.dirname(_HERE), "include", "textflux_hip.h")) as f:
-        return int(re.search(r"#define\s+TFX_ABI_VERSION\s+(\d+)", f.read()).group(1))
+    path = os.path.join(os.path.dirname(_HERE), "include", "textflux_hip.h")
+    try:
+        with open(path) as f:
+            m = re.search(r"#define\s+TFX_ABI_VERSION\s+(\d+)", f.read())
+    except OSError as e:
+        raise RuntimeError(f"cannot read {path} ({e}): the header ships with the package sources") from e
+    if m is None:
+        raise RuntimeError(f"{path} does not define TFX_ABI_VERSION")
+    return int(m.group(1))
 
 
 def _check_abi(l: C.CDLL) -> None:
@@ -186,12 +203,13 @@ def _check_abi(l: C.CDLL) -> None:
     except AttributeError:
         raise RuntimeError(f"{LIB_PATH} predates the ABI stamp (no tfx_abi_info): rebuild it (`make -C textflux_amd/csrc -B`)") from None
     fn.restype, fn.argtypes = c_int, [C.POINTER(c_int32), c_int]
-    got = (c_int32 * 5)()
-    n = fn(got, 5)
-    want = [header_abi_version(), C.sizeof(GemmArgs), C.sizeof(AttnArgs), C.sizeof(DitDesc), C.sizeof(StepDesc)]
-    if n != 5 or list(got) != want:
+    got = (c_int32 * 7)()
+    n = fn(got, 7)
+    want = [ABI_VERSION, C.sizeof(GemmArgs), C.sizeof(AttnArgs), C.sizeof(DitDesc), C.sizeof(StepDesc), C.sizeof(DoubleBlock),
+            C.sizeof(SingleBlock)]
+    if n != 7 or list(got) != want:
         raise RuntimeError(f"{LIB_PATH} was built from another include/textflux_hip.h: ABI stamp {list(got)[:n]} != the binding's "
-                           f"{want} (version, sizeof gemm_args / attn_args / dit_desc / step_desc); rebuild it")
+                           f"{want} (version, sizeof gemm_args / attn_args / dit_desc / step_desc / double_block / single_block); rebuild it")
 
 
 def is_stale() -> bool:

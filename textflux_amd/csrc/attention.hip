@@ -772,6 +772,23 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
 
 static int g_attn_bound = 1;   // 0: ignore AttnArgs::score_bound (A/B knob, tfx_set_option attention_use_bound)
 void set_attention_use_bound(int v) { g_attn_bound = v; }
+// which kernel form the launches took (tfx_attention_mode_counts): host counters, bumped at launch (and at graph capture)
+static int64_t g_attn_mode_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int attention_mode_counts(int64_t* counts, int n, int reset) {
+  n = n < 0 ? 0 : n > 8 ? 8 : n;
+  for (int i = 0; i < n; ++i) counts[i] = g_attn_mode_count[i];
+  if (reset) for (int i = 0; i < 8; ++i) g_attn_mode_count[i] = 0;
+  return n;
+}
+// The reference-free stream (attn_w4_kernel<4>) is admissible when nothing can leave the exponent range fp32 and bf16 share without any
+// reference subtracted: scores s in +-b (exp2 domain, b = score_bound * log2 e), weights 2^s in [2^-b, 2^b] (no underflow while b <= 126:
+// a row's sum is never 0), row sums <= N 2^b, un-normalised outputs <= N 2^b max|v|.  With |v| <= 2^24 granted (bf16 activations of a
+// network; the guarded kernels make the same kind of assumption about N max|v| alone) the condition is b + log2 N + 24 <= 126.
+// P1024 (N = 4608): score_bound <= 62.2, i.e. max|w_q| max|w_k| <= 5.3 of a block's q / k RMSNorm weights; round 4 used a flat
+// 41 (3.55) out of caution -- the bound is the kernel's property, not the bench weights'.
+static bool attn_bound_admissible(float score_bound, int N) {
+  return score_bound > 0.f && score_bound * 1.4426950408889634f + log2f((float)N) + 24.0f <= 126.0f;
+}
 static int g_attn_waves = 30;  // 30 (default) one wave per SIMD, 64 rows per wave, 32x32x16 MFMA (attention_w4.hip); 10 matrix-pipe softmax, 8 waves x 32 rows; 8 exact-online-max lock-step kernel; 4 / 12 = 4-wave workgroups of 8 / 10; 9 = 128 keys per barrier; 16 = ping-pong
 static unsigned long long* g_attn_dbg = nullptr;  // bench-only phase timing buffer
 void set_attention_debug(void* p) {
@@ -801,6 +818,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
     const int rc = joint_attention_hp(a, st);
     if (prof) prof_end(1, st);
+    ++g_attn_mode_count[5];
     return rc ? rc : check_launch("joint_attention");
   }
   // option 30: whole-row 16-byte output stores; its K / V buffer descriptors cover one head's rows with a 32-bit byte count,
@@ -818,18 +836,20 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
     const int rc = joint_attention_w16(a, st);
     if (prof) prof_end(1, st);
+    ++g_attn_mode_count[6];
     return rc ? rc : check_launch("joint_attention");
   }
   if (((g_attn_waves >= 30 && g_attn_waves <= 34) || g_attn_waves == 40) && w4_ok) {
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
-    // 30 (the default) takes the reference-free stream (34) when the caller's score bound allows it: 41 natural-log units = 59 in the
-    // exp2 domain, inside W4_BIG with room for the bf16 rounding of the pre-scaled q; an explicit 31 .. 33 runs as named
-    const bool bounded = a.score_bound > 0.f && a.score_bound <= 41.0f;
+    // 30 (the default) takes the reference-free stream (34) when the caller's score bound allows it (attn_bound_admissible above);
+    // an explicit 31 .. 33 runs as named
+    const bool bounded = attn_bound_admissible(a.score_bound, a.N);
     const int mode = g_attn_waves == 34 ? (bounded ? 4 : 3) : g_attn_waves == 30 ? (bounded && g_attn_bound ? 4 : 0)
                    : g_attn_waves >= 31 && g_attn_waves <= 33 ? g_attn_waves - 30 : 0;
     const int rc = joint_attention_w4(a, st, mode);
     if (prof) prof_end(1, st);
+    ++g_attn_mode_count[mode];
     return rc ? rc : check_launch("joint_attention");
   }
 #ifndef TFX_BENCH

@@ -120,12 +120,12 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
     return rmsnorm_rope(y + (int64_t)row0 * D7, D7, y_bs, 2 * D, 0, H, rows, 0, B, nq, nk, nq, nk, d.cos_tab + (int64_t)row0 * 128,
                         d.sin_tab + (int64_t)row0 * 128, eps, st);
   };
-  auto attention = [&]() -> int {
+  auto attention = [&](float block_bound) -> int {   // the block's own score bound (ABI 6), else the forward-wide one
     AttnArgs a;
     a.q = y + 2 * D; a.k = y; a.v = y + D; a.o = y + 2 * D;
     a.ldq = a.ldk = a.ldv = a.ldo = D7;
     a.q_bstride = a.k_bstride = a.v_bstride = a.o_bstride = y_bs;
-    a.B = B; a.H = H; a.N = N; a.scale = att_scale; a.score_bound = d.attn_score_bound;
+    a.B = B; a.H = H; a.N = N; a.scale = att_scale; a.score_bound = block_bound > 0.f ? block_bound : d.attn_score_bound;
     return joint_attention(a, st);
   };
 
@@ -178,7 +178,7 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
         TRY(jq.run(st));
         if (!fj)
           TRY(rmsnorm_rope(y, D7, y_bs, 2 * D, 0, H, N, T, B, w.norm_q, w.norm_k, w.norm_added_q, w.norm_added_k, d.cos_tab, d.sin_tab, eps, st));
-        TRY(attention());
+        TRY(attention(w.attn_score_bound));
         TRY(jo.run(st));                                                      // hidden += gate_msa * to_out(attn), both streams
         TRY(ln_modulate(hid_img, xn_img, mi + 3 * D, mi + 4 * D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
         TRY(ln_modulate(hid, xn, mt + 3 * D, mt + 4 * D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
@@ -200,7 +200,7 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
           if (!ft) TRY(norm_rope_rows(0, T, w.norm_added_q, w.norm_added_k));
         }
       }
-      TRY(attention());
+      TRY(attention(w.attn_score_bound));
       // hidden += gate_msa * to_out(attn)   (:817-818, 830-831)
       TRY(Gemm(y_img + 2 * D, D7, y_bs, w.out_img, D, hid_img, D, hid_bs, Sn, D, D, B)
               .gate_res(mi + 2 * D, mbs, hid_img, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
@@ -229,7 +229,7 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
         TRY(norm_gemm(hid, 0, N, ms, ms + D, gs));
         if (!fs) TRY(norm_rope_rows(0, N, w.norm_q, w.norm_k));
       }
-      TRY(attention());
+      TRY(attention(w.attn_score_bound));
       TRY(Gemm(y + 2 * D, D7, y_bs, w.proj_out, 5 * D, hid, D, hid_bs, N, D, 5 * D, B)
               .gate_res(ms + 2 * D, mbs, hid, D, hid_bs).scratch(d.gemm_workspace, d.gemm_workspace_bytes).run(st, q8, q8s));
     }
@@ -261,10 +261,10 @@ extern "C" {
 const char* tfx_version(void) { return "textflux_hip 0.1 (gfx950)"; }
 const char* tfx_last_error(void) { return last_error(); }
 int tfx_abi_info(int32_t* out, int n) {
-  const int32_t v[5] = {TFX_ABI_VERSION, (int32_t)sizeof(tfx_gemm_args), (int32_t)sizeof(tfx_attn_args), (int32_t)sizeof(tfx_dit_desc),
-                        (int32_t)sizeof(tfx_step_desc)};
-  for (int i = 0; i < 5 && i < n; ++i) out[i] = v[i];
-  return 5;
+  const int32_t v[7] = {TFX_ABI_VERSION, (int32_t)sizeof(tfx_gemm_args), (int32_t)sizeof(tfx_attn_args), (int32_t)sizeof(tfx_dit_desc),
+                        (int32_t)sizeof(tfx_step_desc), (int32_t)sizeof(tfx_double_block), (int32_t)sizeof(tfx_single_block)};
+  for (int i = 0; i < 7 && i < n; ++i) out[i] = v[i];
+  return 7;
 }
 
 int tfx_query_arch(char* buf, int buflen) {
@@ -375,6 +375,28 @@ int tfx_rmsnorm_rope(void* buf, int64_t ld, int64_t bstride, int32_t q_off, int3
   if (ld % 8 || bstride % 8 || q_off % 8 || k_off % 8) return fail("tfx_rmsnorm_rope: offsets/strides must be multiples of 8");
   return rmsnorm_rope(buf, ld, bstride, q_off, k_off, H, Ntok, T, B, wq_img, wk_img, wq_txt, wk_txt, cos_tab, sin_tab,
                       eps, S(stream));
+}
+
+int tfx_rmsnorm_rope_qk(void* buf, int64_t ld, int64_t bstride, int32_t q_off, int32_t k_off, int32_t H, int32_t Ntok,
+                        int32_t T, int32_t B, const void* wq_img, const void* wk_img, const void* wq_txt,
+                        const void* wk_txt, const float* cos_tab, const float* sin_tab, float eps, tfx_stream stream) {
+  return tfx_rmsnorm_rope(buf, ld, bstride, q_off, k_off, H, Ntok, T, B, wq_img, wk_img, wq_txt, wk_txt, cos_tab, sin_tab, eps, stream);
+}
+
+int tfx_gate_residual(const void* x, int64_t ldx, int64_t x_bstride, const void* gate, int64_t gate_bstride, const void* res,
+                      int64_t ldr, int64_t r_bstride, void* out, int64_t ldo, int64_t o_bstride, int32_t rows_per_batch,
+                      int32_t batch, int32_t D, tfx_stream stream) {
+  if (!x || !gate || !res || !out) return fail("tfx_gate_residual: null pointer");
+  if (D <= 0 || D % 8 || (ldx | x_bstride | ldr | r_bstride | ldo | o_bstride | gate_bstride) % 8)
+    return fail("tfx_gate_residual: D and every stride must be multiples of 8 elements");
+  if (((uintptr_t)x | (uintptr_t)gate | (uintptr_t)res | (uintptr_t)out) % 16) return fail("tfx_gate_residual: pointers must be 16-byte aligned");
+  if (rows_per_batch < 0 || batch < 0) return fail("tfx_gate_residual: negative extent");
+  return gate_residual(x, ldx, x_bstride, gate, gate_bstride, res, ldr, r_bstride, out, ldo, o_bstride, rows_per_batch, batch, D, S(stream));
+}
+
+int tfx_attention_mode_counts(int64_t* counts, int32_t n, int32_t reset) {
+  if (!counts && n > 0) return fail("tfx_attention_mode_counts: null pointer");
+  return attention_mode_counts(counts, n, reset);
 }
 
 int tfx_joint_attention(const tfx_attn_args* g, tfx_stream stream) {

@@ -282,6 +282,34 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
       *reinterpret_cast<const u32x4*>(src + b * sbs + (int64_t)r * sld + c * 8);
 }
 
+// out[b][r, :] = res[b][r, :] + bf16(gate[b][:] * x[b][r, :])  (tfx_gate_residual: `hidden + gate.unsqueeze(1) * attn_output`,
+// transformer_flux.py:733-735, 817-818, 824-826; two bf16 ops in the reference, so the product is rounded before the add -- the
+// arithmetic of the GEMM's EPI_BIAS_GATE_RES epilogue on an already rounded Linear output).  HBM-bound: 16 bytes per lane and
+// stream, 3 * rows * D * 2 bytes of traffic (the gate row stays in L2).
+__global__ __launch_bounds__(256) void gate_residual_kernel(const bf16_t* x, int64_t ldx, int64_t xbs,
+                                                            const bf16_t* __restrict__ gate, int64_t gbs, const bf16_t* res, int64_t ldr,
+                                                            int64_t rbs, bf16_t* out, int64_t ldo, int64_t obs, int rows, int cpr,
+                                                            int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cpr);
+  const int64_t rr = i / cpr;
+  const int r = (int)(rr % rows);
+  const int b = (int)(rr / rows);
+  const u32x4 xv = *reinterpret_cast<const u32x4*>(x + b * xbs + (int64_t)r * ldx + c * 8);
+  const u32x4 gv = *reinterpret_cast<const u32x4*>(gate + b * gbs + c * 8);
+  const u32x4 rv = *reinterpret_cast<const u32x4*>(res + b * rbs + (int64_t)r * ldr + c * 8);
+  u32x4 ov;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t xw = xv[k], gw = gv[k], rw = rv[k];
+    const float lo = bf2f((bf16_t)(rw & 0xffff)) + round_bf(bf2f((bf16_t)(gw & 0xffff)) * bf2f((bf16_t)(xw & 0xffff)));
+    const float hi = bf2f((bf16_t)(rw >> 16)) + round_bf(bf2f((bf16_t)(gw >> 16)) * bf2f((bf16_t)(xw >> 16)));
+    ov[k] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  }
+  *reinterpret_cast<u32x4*>(out + b * obs + (int64_t)r * ldo + c * 8) = ov;
+}
+
 // ---------------------------------------------------------------------------------------------
 // GroupNorm(groups, eps, affine) [+ SiLU] on NHWC activations x [B, HW, C] (VAE blocks: ResnetBlock2D norm1/norm2,
 // D/models/resnet.py:327-366; conv_norm_out, D/models/autoencoders/vae.py:191-193, 352-354; mid-block attention
@@ -470,6 +498,15 @@ int copy_rows(const void* src, int64_t sld, int64_t sbs, void* dst, int64_t dld,
   copy_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>((const bf16_t*)src, sld, sbs, (bf16_t*)dst, dld,
                                                                           dbs, rows, cols / 8, total);
   return check_launch("copy_rows");
+}
+int gate_residual(const void* x, int64_t ldx, int64_t x_bs, const void* gate, int64_t gate_bs, const void* res, int64_t ldr, int64_t r_bs,
+                  void* out, int64_t ldo, int64_t o_bs, int rows, int batch, int D, hipStream_t st) {
+  const int64_t total = (int64_t)batch * rows * (D / 8);
+  if (total == 0) return 0;
+  gate_residual_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>((const bf16_t*)x, ldx, x_bs, (const bf16_t*)gate, gate_bs,
+                                                                             (const bf16_t*)res, ldr, r_bs, (bf16_t*)out, ldo, o_bs, rows,
+                                                                             D / 8, total);
+  return check_launch("gate_residual");
 }
 int groupnorm_silu_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* ws, int B, int64_t HW,
                         int C, int groups, float eps, bool silu, hipStream_t st) {

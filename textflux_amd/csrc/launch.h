@@ -101,7 +101,10 @@ int attention_w4_prepare(hipStream_t st);                      // allocates the 
 void set_attention_tail_split(int v);                          // 0 = never split the last round's q-tiles by keys (bench knob)
 int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode);   // one wave per SIMD, 64 query rows per wave (attention_w4.hip); mode: 0 bookkeeping on the matrix pipe, 1 row sums on the VALU, 2 + lazy reference offset
 void set_attention_ablation(int a);
-void set_attention_use_bound(int v);   // 0: ignore AttnArgs::score_bound
+void set_attention_use_bound(int v);
+int attention_mode_counts(int64_t* counts, int n, int reset);   // tfx_attention_mode_counts
+int gate_residual(const void* x, int64_t ldx, int64_t x_bs, const void* gate, int64_t gate_bs, const void* res, int64_t ldr, int64_t r_bs,
+                  void* out, int64_t ldo, int64_t o_bs, int rows, int batch, int D, hipStream_t st);   // 0: ignore AttnArgs::score_bound
 void set_attention_persistent(int v);  // 0: one workgroup per (b, h, q-tile) item instead of one per CU
 void set_attention_debug(void* p);
 void set_attention_waves(int nw);  // 8 (one 512-thread workgroup per CU) or 4 (two independent 256-thread workgroups)

@@ -47,12 +47,30 @@ def respawn_under_torchrun(n_gpus: Optional[int], script: str, argv: Sequence[st
     os.execv(sys.executable, cmd)
 
 
+# Collectives actually EXECUTED on the default group by this process, by kind (bench.py prints them: a record that says
+# "rccl_ranks_seen: 1" must be able to show whether an all-reduce ran or the no-group branch answered).  Every helper below runs
+# its collective whenever a group exists -- also at world size 1 under a launcher -- so that the RCCL code path of a 1-GPU
+# `torch.distributed.run` job is the same code the 8-GPU job runs.
+COLLECTIVES = {"all_reduce": 0, "broadcast": 0, "all_gather": 0, "gather": 0, "barrier": 0}
+
+
+def _ran(kind: str) -> None:
+    COLLECTIVES[kind] += 1
+
+
+def group_info() -> dict:
+    on = dist.is_available() and dist.is_initialized()
+    return {"initialized": on, "backend": dist.get_backend() if on else None, "world_size": dist.get_world_size() if on else 1,
+            "collectives_executed": dict(COLLECTIVES)}
+
+
 def ranks_seen(device) -> int:
     """Number of ranks that take part in a collective on the default group (1 without a group): sum of ones."""
     if not dist.is_initialized():
         return 1
     t = torch.ones(1, dtype=torch.int32, device=device)
     dist.all_reduce(t)
+    _ran("all_reduce")
     return int(t.item())
 
 
@@ -72,64 +90,69 @@ def broadcast_conditioning(prompt_embeds: Optional[torch.Tensor], pooled: Option
                            dtype, device, src: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """Rank `src` passes the tensors, the others pass None and receive.  Payload: 4 MiB per distinct prompt
     ([1,512,4096] bf16) + 1.5 KiB pooled -- one direct xGMI hop per peer, negligible next to >= 1 s of denoising."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if rank != src:
         prompt_embeds = torch.empty(shape_pe, dtype=dtype, device=device)
         pooled = torch.empty(shape_pooled, dtype=dtype, device=device)
     else:
         prompt_embeds, pooled = prompt_embeds.to(device, dtype).contiguous(), pooled.to(device, dtype).contiguous()
-    if world > 1:
+    if dist.is_initialized():
         dist.broadcast(prompt_embeds, src=src)
         dist.broadcast(pooled, src=src)
+        _ran("broadcast"), _ran("broadcast")
     return prompt_embeds, pooled
 
 
 def broadcast_tensor(t: Optional[torch.Tensor], shape, dtype, device, src: int = 0) -> torch.Tensor:
     """One tensor from rank `src` to everybody (the others pass None)."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     t = torch.empty(shape, dtype=dtype, device=device) if rank != src else t.to(device, dtype).contiguous()
-    if world > 1:
+    if dist.is_initialized():
         dist.broadcast(t, src=src)
+        _ran("broadcast")
     return t
 
 
 def gather_to_rank0(t: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
     """Equal-shape gather of per-rank results (final latents / images) on rank `dst`."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return [t]
     world, rank = dist.get_world_size(), dist.get_rank()
     if dist.get_backend() == "nccl":
         outs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(outs, t.contiguous())   # RCCL has no rooted gather primitive cheaper than this at these sizes
+        _ran("all_gather")
         return outs if rank == dst else None
     outs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
     dist.gather(t.contiguous(), outs, dst=dst)
+    _ran("gather")
     return outs
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _ran("all_reduce")
     return float(t.item())
 
 
 def all_ranks(value: float, device) -> List[float]:
     """The value of every rank, in rank order (diagnostics: which rank was the straggler)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return [value]
     t = torch.tensor([value], dtype=torch.float64, device=device)
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, t)
+    _ran("all_gather")
     return [float(o.item()) for o in outs]
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         if dist.get_backend() == "nccl":      # name the device: RCCL would otherwise guess it from the rank
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
             dist.barrier()
+        _ran("barrier")

@@ -183,6 +183,22 @@ def rmsnorm_rope_(buf: torch.Tensor, q_off: int, k_off: int, H: int, T: int, wq_
     return buf
 
 
+def gate_residual(x: torch.Tensor, gate: torch.Tensor, res: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """res + bf16(gate[:, None, :] * x): x, res [B,R,D] (row / batch strides allowed), gate [B,D] -> out [B,R,D] (tfx_gate_residual;
+    `hidden_states + gate.unsqueeze(1) * attn_output`, transformer_flux.py:733-735, 817-818)."""
+    _chk_dev(x, gate, res, out)
+    assert x.dim() == 3 and x.dtype == res.dtype == gate.dtype == BF16 and res.shape == x.shape
+    B, R, D = x.shape
+    assert gate.shape == (B, D) and x.stride(2) == res.stride(2) == gate.stride(1) == 1
+    if out is None:
+        out = torch.empty(B, R, D, dtype=BF16, device=x.device)
+    assert out.shape == x.shape and out.dtype == BF16 and out.stride(2) == 1
+    L.check(L.lib().tfx_gate_residual(x.data_ptr(), x.stride(1), x.stride(0), gate.data_ptr(), gate.stride(0), res.data_ptr(),
+                                      res.stride(1), res.stride(0), out.data_ptr(), out.stride(1), out.stride(0), R, B, D,
+                                      _stream()), "gate_residual")
+    return out
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: Optional[torch.Tensor] = None,
               scale: Optional[float] = None, score_bound: float = 0.0) -> torch.Tensor:
     """q,k,v: [B,N,H*128] (views with row/batch strides allowed) -> out [B,N,H*128].  score_bound: the caller's promise
@@ -291,6 +307,16 @@ def prof_collect(kind: int):
     ms, fl, n = C.c_double(), C.c_double(), C.c_int()
     L.check(L.lib().tfx_prof_collect(kind, C.byref(ms), C.byref(fl), C.byref(n)), "prof_collect")
     return ms.value, fl.value, n.value
+
+
+ATTENTION_MODES = ("w4_guarded", "w4_valu_rowsum", "w4_lazy_valu", "w4_lazy", "w4_reference_free", "hp", "w16", "other")
+
+
+def attention_mode_counts(reset: bool = False) -> dict:
+    """Attention launches since the last reset by kernel form (tfx_attention_mode_counts): which stream the score bound selected."""
+    c = (C.c_int64 * 8)()
+    L.lib().tfx_attention_mode_counts(c, 8, 1 if reset else 0)
+    return {name: int(c[i]) for i, name in enumerate(ATTENTION_MODES)}
 
 
 def set_option(name: str, value: int) -> None:

@@ -327,21 +327,48 @@ class FluxTransformer2DModel:
         return self._lin(ops.silu(temb), "mod")
 
     # ------------------------------------------------------------------ sessions / forward
-    def attn_score_bound(self) -> float:
-        """tfx_dit_desc.attn_score_bound: an upper bound of |q . k| * 128^-0.5 over every attention launch of the forward, from the
+    # 3 % on top of the bound: the normalised q and k each pass three bf16 roundings (x * rsqrt -> bf16, * weight -> bf16, RoPE ->
+    # bf16) and q one more when the kernel pre-scales it: (1 + 2^-8)^7 = 1.028 in the worst case.
+    SCORE_BOUND_MARGIN = 1.03
+
+    def attn_score_bounds(self):
+        """Per block (doubles, then singles): an upper bound of |q . k| * 128^-0.5 of THAT block's attention launch, from its own
         q / k RMSNorm weights (attention_processor.py:2001-2004, 2023-2037: after RMSNorm |q|^2 = sum_i (x_i / rms)^2 w_i^2 <=
-        128 max w^2, RoPE is a rotation) -- lets the attention kernel drop its running-maximum bookkeeping when the bound shows that
-        exp2 cannot overflow.  Joint attention mixes the image and text streams: the larger of the two norms on each side.
-        2 % on top for the bf16 roundings of the normalised values."""
-        c, w, m = self.config, self.w, 0.0
-        amax = lambda n: float(w[n].float().abs().max().item())
+        128 max w^2, RoPE is a rotation) -- tfx_double_block / tfx_single_block.attn_score_bound.  It lets the attention kernel drop
+        its running-maximum bookkeeping where the bound shows that exp2 cannot leave the exponent range; a block with large norm
+        scales falls back alone.  Joint attention mixes the image and text streams: the larger of the two norms on each side.
+        One device reduction + one copy for all 57 blocks.  Cached with the weights' version counters: an in-place edit of a norm
+        weight re-derives the bounds (and drops the session that baked the old ones) on the next forward."""
+        c, w = self.config, self.w
+        names = []
         for i in range(c.num_layers):
-            m = max(m, max(amax(f"d{i}.norm_q"), amax(f"d{i}.norm_added_q")) * max(amax(f"d{i}.norm_k"), amax(f"d{i}.norm_added_k")))
+            names += [f"d{i}.norm_q", f"d{i}.norm_added_q", f"d{i}.norm_k", f"d{i}.norm_added_k"]
         for j in range(c.num_single_layers):
-            m = max(m, amax(f"s{j}.norm_q") * amax(f"s{j}.norm_k"))
-        return 1.02 * 128.0 * m * 128 ** -0.5
+            names += [f"s{j}.norm_q", f"s{j}.norm_k"]
+        key = tuple((w[n].data_ptr(), w[n]._version) for n in names)
+        cached = getattr(self, "_bounds_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if not names:
+            self._bounds_cache = (key, ([], []))
+            return [], []
+        am = torch.stack([w[n].float().abs().max() for n in names]).cpu().tolist()
+        f = self.SCORE_BOUND_MARGIN * 128.0 * 128 ** -0.5
+        nd = c.num_layers
+        dbl = [f * max(am[4 * i], am[4 * i + 1]) * max(am[4 * i + 2], am[4 * i + 3]) for i in range(nd)]
+        sgl = [f * am[4 * nd + 2 * j] * am[4 * nd + 2 * j + 1] for j in range(c.num_single_layers)]
+        if cached is not None:
+            self._session = None        # a session bakes the bounds into its descriptor (and its captured graphs)
+        self._bounds_cache = (key, (dbl, sgl))
+        return dbl, sgl
+
+    def attn_score_bound(self) -> float:
+        """The largest per-block bound (tfx_dit_desc.attn_score_bound, the forward-wide fallback field)."""
+        dbl, sgl = self.attn_score_bounds()
+        return max(dbl + sgl, default=0.0)
 
     def session(self, B: int, S: int, T: int) -> "DitSession":
+        self.attn_score_bounds()        # norm weights edited in place since the last call: new bounds, new session
         s = self._session
         if s is None or (s.B, s.S, s.T) != (B, S, T):
             s = self._session = DitSession(self, B, S, T)
@@ -425,6 +452,7 @@ class DitSession:
             return L.Linear(w[name + ".w"].data_ptr(), w[name + ".b"].data_ptr(), q[0].data_ptr() if q else None,
                             q[1].data_ptr() if q else None)
 
+        bounds_d, bounds_s = model.attn_score_bounds()
         self._dbl = (L.DoubleBlock * max(1, c.num_layers))()
         for i in range(c.num_layers):
             b = self._dbl[i]
@@ -432,11 +460,13 @@ class DitSession:
                 setattr(b, n, lin(f"d{i}.{n}"))
             for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
                 setattr(b, n, w[f"d{i}.{n}"].data_ptr())
+            b.attn_score_bound = bounds_d[i]
         self._sgl = (L.SingleBlock * max(1, c.num_single_layers))()
         for j in range(c.num_single_layers):
             b = self._sgl[j]
             b.qkv_mlp, b.proj_out = lin(f"s{j}.qkv_mlp"), lin(f"s{j}.proj_out")
             b.norm_q, b.norm_k = w[f"s{j}.norm_q"].data_ptr(), w[f"s{j}.norm_k"].data_ptr()
+            b.attn_score_bound = bounds_s[j]
         d = self.desc = L.DitDesc()
         d.D, d.H, d.in_channels, d.out_channels = D, c.num_attention_heads, c.in_channels, model.out_channels
         d.n_double, d.n_single = c.num_layers, c.num_single_layers
@@ -448,7 +478,7 @@ class DitSession:
         d.first_block, d.last_block, d.flags = 0, -1, 0
         d.cos_tab, d.sin_tab = self.cos.data_ptr(), self.sin.data_ptr()
         d.rope_cs = self.rope_cs.data_ptr() if model.fuse_qk_norm_rope else None
-        d.attn_score_bound = model.attn_score_bound()
+        d.attn_score_bound = 0.0        # every block carries its own (ABI 6); no forward-wide promise on top
         if self.fp8:
             d.q8, d.q8_scale = self.q8.data_ptr(), self.q8_scale.data_ptr()
         # scratch for the split-K path of few-tile GEMMs (text stream, small batch x resolution): fp32 partials of at most

@@ -23,29 +23,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-BF = torch.bfloat16
-H, W, N_SCHED, SEED = 576, 512, 30, 2024
-S = (H // 16) * (W // 16)
-FIXTURE = os.path.join(REPO, "tests", "golden", "g11_fulldepth_c2_oracle.safetensors")
-
-
-def seeded_weights():
-    from oracle import flux_oracle as fo
-    cfg = fo.FluxConfig()
-    g = torch.Generator().manual_seed(SEED)
-    sd = {}
-    for k, shape in fo.state_dict_shapes(cfg).items():
-        r = torch.randn(shape, generator=g)
-        sd[k] = ((1.0 + 0.1 * r) if (".norm_" in k and len(shape) == 1) else 0.02 * r).to(BF)
-    return cfg, sd
-
-
-def inputs():
-    gi = torch.Generator().manual_seed(7)
-    lat = torch.randn(1, S, 64, generator=gi)
-    mil = torch.cat([torch.randn(1, S, 64, generator=gi), (torch.randn(1, S, 256, generator=gi) > 0).float()], -1)
-    pe, pooled = torch.randn(1, 512, 4096, generator=gi) * 0.1, torch.randn(1, 768, generator=gi)
-    return [t.to(BF) for t in (lat, mil, pe, pooled)]
+from tests.helpers.fulldepth import BF, FIXTURE, H, W, N_SCHED, S, SEED, inputs, seeded_weights   # noqa: E402,F401
 
 
 class AsF32(dict):
