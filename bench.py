@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--layers", type=int, nargs=2, default=[19, 38], help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pil-delta", action="store_true", help="skip the untimed output_type='pil' vs 'pt' comparison")
+    ap.add_argument("--no-attention-ab", action="store_true", help="skip the untimed call with the attention score bound ignored (attention_use_bound=0)")
     ap.add_argument("--cpu-baseline-c1", action="store_true", help="only run BASELINE config 1 on the host cores (minutes, ~50 GB RAM) and print it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of per-step hipGraph replay")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help=argparse.SUPPRESS)  # tuning knobs (tfx_set_option)
@@ -274,10 +275,27 @@ def main():
     pipe.enable_hip_graph(False)
     if rank == 0:
         ops.prof_enable(True)
+    ops.attention_mode_counts(reset=True)
     one_call()
     torch.cuda.synchronize()
     ops.prof_enable(False)
+    attn_modes = {k: v for k, v in ops.attention_mode_counts(reset=True).items() if v}     # which attention stream every launch of a call took
     pipe.enable_hip_graph(not a.no_graph)
+    # the reference-free attention stream is selected per launch from the block's q / k RMSNorm weights (tfx_*_block.attn_score_bound);
+    # what a checkpoint whose norm scales do NOT admit it would see: one untimed call (after one warm-up call that re-captures the step
+    # graph) with the bound ignored -- every launch on the guarded kernel
+    unbounded_s = None
+    if rank == 0 and world == 1 and not a.no_attention_ab:
+        ops.set_option("attention_use_bound", 0)
+        tr._session = None                       # the captured step graphs hold the kernels chosen at capture
+        one_call()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one_call()
+        torch.cuda.synchronize()
+        unbounded_s = time.perf_counter() - t1
+        ops.set_option("attention_use_bound", 1)
+        tr._session = None
     # what the timed calls leave out of a17: output_type="pt" keeps the decoded images on the device; one untimed call with
     # output_type="pil" (device -> host copy + uint8 / PIL conversion of the batch) gives the difference
     pil_delta_ms = None
@@ -371,7 +389,13 @@ def main():
                          "sample": "HIP events around every GEMM launch of one extra, untimed, eager call after the timed region (graph-replayed launches are not individually timed)",
                          "flops_per_launch": gemm_fl / max(gemm_n, 1),
                          "attention": {"achieved": att_fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0,
-                                       "launches": att_n, "avg_launch_ms": att_ms / max(att_n, 1)}},
+                                       "launches": att_n, "avg_launch_ms": att_ms / max(att_n, 1),
+                                       "modes": attn_modes,
+                                       "modes_note": "launches of the eager sample call by kernel form; w4_reference_free needs the block's score bound "
+                                                     "(128 max|w_q| max|w_k| 128^-0.5 * 1.03) to satisfy bound*log2(e) + log2(N) + 24 <= 126, i.e. "
+                                                     "max|w_q| max|w_k| <= 5.3 at N = 4608; init_random_ draws the norm weights as 1 + 0.1 randn",
+                                       "call_s_with_bound": elapsed / a.steps,
+                                       "call_s_bound_ignored": unbounded_s}},
         }
         peak = MFMA_PEAK_TFLOPS * (2 if a.fp8 else 1)
         rec["roofline"]["attention"]["frac"] = rec["roofline"]["attention"]["achieved"] / MFMA_PEAK_TFLOPS     # attention is bf16 in both modes

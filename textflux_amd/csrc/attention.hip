@@ -928,6 +928,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     attn_kernel<8><<<grid, 512, ATT_LDS, st>>>(ATT_ARGS);
 #undef ATT_ARGS
   if (prof) prof_end(1, st);
+  ++g_attn_mode_count[7];
   return check_launch("joint_attention");
 }
 

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
       if (n >= p.N) continue;
       if (p.ws) { p.ws[b * p.ws_bs + (int64_t)m * p.ws_ld + n] = acc[i][j]; continue; }   // fp32-output mode (raw accumulators)
       float v = acc[i][j] + (p.bias ? bf2f(p.bias[n]) : 0.f);
-      if (EPI == EPI_BIAS_GELU) { if (n >= p.gelu_from) v = gelu_tanh(v); }
+      if (EPI == EPI_BIAS_GELU) { if (n >= p.gelu_from) v = gelu_tanh(round_bf(v)); }   // the Linear's bf16 output is what nn.GELU sees (attention.py:1209-1212)
       if (EPI == EPI_BIAS_GATE_RES) {
         const float g = bf2f(p.gate[b * p.gate_bs + n]);
         const float r = bf2f(p.res[b * p.r_bs + (int64_t)m * p.ldr + n]);
@@ -400,7 +400,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][e] + bs[e];
           }
-          if (GELU) {
+          if (GELU) {   // nn.GELU acts on the Linear's bf16 OUTPUT (activations.py:85-88 after the bf16 nn.Linear): round first
+            round_bf2(v[0], v[1]);
+            round_bf2(v[2], v[3]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
           }
@@ -1310,7 +1312,9 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
               float v[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = NORM ? acc[i][j][e] : acc[i][j][e] + bs[e];
-              if (GELU) {
+              if (GELU) {   // nn.GELU acts on the Linear's bf16 OUTPUT: the reference's rounding point (round 5; it was skipped before)
+                round_bf2(v[0], v[1]);
+                round_bf2(v[2], v[3]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
               }
@@ -1448,7 +1452,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams p) {
   }
   if (EPI == EPI_BIAS_GELU && n >= p.gelu_from) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(round_bf(v[e]));
   }
   if (EPI == EPI_BIAS_GATE_RES) {
     float gt[8];
