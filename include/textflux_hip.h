@@ -391,6 +391,11 @@ int tfx_mul_act(const void* a, int64_t lda, const void* b, int64_t ldb, void* ou
  *      "gemm_place": slot assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip).
  *      "gemm_splitk": 0 disables the split-K path of few-tile GEMMs (default 1). */
 int tfx_set_option(const char* name, int value);
+/* The only device memory the library ever allocates itself is behind an opt-in knob: the attention tail-split partials
+ * ("attention_tail_split" 1; 138 MB per (device, stream) that launched with it, at most 8).  tfx_release_scratch synchronises the
+ * device and frees them all; streams seen afterwards allocate afresh.  Graphs captured while the knob was on hold the old pointers
+ * and must be destroyed first (tfx_graph_destroy).  With the defaults this is a no-op.  Returns 0. */
+int tfx_release_scratch(void);
 
 /* ---- measurement hooks (no reference counterpart: the reference has no profiling) --------------------
  * When enabled, every MFMA-GEMM (kind 0) / attention (kind 1) launch is bracketed by hipEvents on its own stream and

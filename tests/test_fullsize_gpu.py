@@ -188,3 +188,50 @@ def test_fused_qk_norm_rope_epilogue_matches_separate_pass():
     print(f"model output rel MAE fused vs separate: {rel:.2e}")
     assert rel < 5e-3
     m.fuse_qk_norm_rope = True
+
+
+def test_row_split_launches_with_k_sliced_text_tiles_match_separate_launches():
+    """the joint [text | image] projections of a double block (row-split weights) COMBINED with K-sliced tiles -- at
+    512 x 512 batch 1 (N = 1536: 6 row tiles, 2 of them text rows) the out / ff2 projections have 72 tiles for 256 CUs, so EVERY tile
+    is K-sliced, the text tiles (second weight set in tail_reduce_kernel) included -- against the two-launch form under the same
+    options: other tile counts, other slice plans, so only fp32 summation order differs (bf16 noise level, like batch 1 vs batch 2
+    above), finite, rerun-deterministic; and identical samples of one batch keep identical bits in both forms (the sliced tile
+    POSITIONS are the same in every sample: the policy stated in INTEGRATION.md section 5)."""
+    from textflux_amd import ops
+    from textflux_amd.transformer import FluxTransformer2DModel
+    m = FluxTransformer2DModel(in_channels=384, out_channels=64, num_layers=2, num_single_layers=2,
+                               guidance_embeds=True).init_random_(seed=9, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(4)
+    S, T = 1024, 512
+    hs = torch.randn(1, S, 384, generator=g, device="cuda").to(BF)
+    pe = (torch.randn(1, T, 4096, generator=g, device="cuda") * 0.1).to(BF)
+    pooled = torch.randn(1, 768, generator=g, device="cuda").to(BF)
+    ids = torch.zeros(S, 3)
+    ids[:, 1] = torch.arange(S) // 32
+    ids[:, 2] = torch.arange(S) % 32
+    kw = dict(img_ids=ids, txt_ids=torch.zeros(T, 3), return_dict=False)
+    t1, g1 = torch.tensor([0.7], device="cuda").to(BF), torch.tensor([30.0], device="cuda")
+    run = lambda b: m(hidden_states=hs.repeat(b, 1, 1), encoder_hidden_states=pe.repeat(b, 1, 1), pooled_projections=pooled.repeat(b, 1),
+                      timestep=t1.repeat(b), guidance=g1.repeat(b), **kw)[0]
+    joint1, joint3 = run(1), run(3)                       # defaults: gemm_splitk 2, gemm_group_streams 1
+    assert torch.equal(joint1, run(1)) and torch.isfinite(joint1.float()).all() and joint1.float().std().item() > 1e-3
+    assert torch.equal(joint3[0], joint3[1]) and torch.equal(joint3[0], joint3[2])
+    ops.set_option("gemm_group_streams", 0)
+    try:
+        sep1, sep3 = run(1), run(3)
+    finally:
+        ops.set_option("gemm_group_streams", 1)
+    assert torch.equal(sep3[0], sep3[1]) and torch.equal(sep3[0], sep3[2])
+    for a, b in ((joint1, sep1), (joint3, sep3), (joint1, joint3[:1])):
+        rel = ((a.float() - b.float()).abs().mean() / b.float().abs().mean()).item()
+        assert rel < 2e-2, rel
+    ops.set_option("gemm_splitk", 0)                      # no K slicing: the joint launch computes the same tiles with the same code
+    try:
+        j0 = run(1)
+        ops.set_option("gemm_group_streams", 0)
+        s0 = run(1)
+        b3 = run(3)
+    finally:
+        ops.set_option("gemm_splitk", 2)
+        ops.set_option("gemm_group_streams", 1)
+    assert torch.equal(j0, s0) and torch.equal(b3[0], s0[0])      # ... and a sample's bits no longer depend on the batch it shares

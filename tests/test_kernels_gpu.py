@@ -491,6 +491,18 @@ def test_attention_tail_split_matches_unsplit_and_reference(ops, B, N):
     d = (split.float() - plain.float()).abs()
     assert d.max().item() <= 2.0 ** -7 * ref.abs().max().item() and d.mean().item() <= 1e-3 * ref.abs().mean().item()
     assert torch.equal(inplace_q, split) and torch.equal(pad_after, pad_before)
+    # the partials are the only device memory the library allocates itself: the release hook frees them (138 MB per stream that used the
+    # knob), the next launch with the knob on allocates afresh and computes the same bits
+    free0 = torch.cuda.mem_get_info()[0]
+    ops.release_scratch()
+    assert torch.cuda.mem_get_info()[0] >= free0 + (100 << 20)
+    try:
+        ops.set_option("attention_tail_split", 1)
+        y2 = (rnd((B, N, 4 * D), 61) * 1.5).to(BF).cuda()          # q was overwritten in place above: the same inputs again
+        assert torch.equal(ops.attention(y2[:, :, 2 * D:3 * D], y2[:, :, :D], y2[:, :, D:2 * D]), split)
+    finally:
+        ops.set_option("attention_tail_split", 0)
+        ops.release_scratch()
 
 
 def test_attention_strided_inplace_over_q(ops):

@@ -157,6 +157,7 @@ SIGNATURES = {
     "tfx_add_into_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "tfx_mul_act": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
     "tfx_set_option": (c_int, [c_char_p, c_int]),
+    "tfx_release_scratch": (c_int, []),
     "tfx_prof_enable": (c_int, [c_int]),
     "tfx_prof_collect": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
     "tfx_attention_mode_counts": (c_int, [C.POINTER(c_int64), c_int32, c_int32]),

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   const int ldk2 = (int)ldk * 2, ldv2 = (int)ldv * 2;
   const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)((uint32_t)(Nk - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
   const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((uint32_t)(Nk - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
-  // the next item's K / V (persistent form; its first tile is requested by this item's LAST staging step instead of a tile past the end)
+  // the next item's K / V (persistent form; its first tile is requested after this item's output stores -- load_tile(0) below -- and flies under the next prologue)
   const auto rsK2 = __builtin_amdgcn_make_buffer_rsrc((void*)(Kp + b2 * k_bs + h2 * W4_HD), 0, (int)((uint32_t)(N - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
   const auto rsV2 = __builtin_amdgcn_make_buffer_rsrc((void*)(Vp + b2 * v_bs + h2 * W4_HD), 0, (int)((uint32_t)(N - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
   // piece i (rows t / 16 + 16 i) of tile j: global -> registers.  Rows are clamped to the last valid key (a no-op on full
@@ -988,8 +988,8 @@ __global__ __launch_bounds__(256) void attn_w4_merge_kernel(const float* part, b
 
 // scratch of the tail split: one per (device, stream) that ever ran a split launch -- two launches in flight on different streams
 // (a graph replay on a side stream next to an eager call) must not share partials.  Allocated on first use outside a stream
-// capture, never freed (captured graphs keep the pointer); a launch on a stream without scratch (first seen during capture, or
-// the table is full) simply runs unsplit.
+// capture, freed only by tfx_release_scratch (captured graphs keep the pointer); a launch on a stream without scratch (first seen
+// during capture, or the table is full) simply runs unsplit.
 static constexpr int W4_PART_TILES = 1024;   // (q-tile, key range) slots: 2 rounds of a 512-CU chip, 138 MB
 static constexpr int W4_PART_SLOTS = 8;
 struct W4Scratch { int dev; hipStream_t st; float* part; int cus; };
@@ -1017,6 +1017,23 @@ static const W4Scratch* w4_scratch(hipStream_t st, bool may_alloc) {
   }
   g_w4_scr[g_w4_nscr] = s;
   return &g_w4_scr[g_w4_nscr++];
+}
+
+int attention_w4_release() {
+  std::lock_guard<std::mutex> lk(g_w4_mu);
+  if (g_w4_nscr == 0) return 0;
+  (void)hipDeviceSynchronize();
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (int i = 0; i < g_w4_nscr; ++i) {
+    (void)hipSetDevice(g_w4_scr[i].dev);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(g_w4_scr[i].part);
+  }
+  (void)hipSetDevice(cur);
+  (void)hipGetLastError();
+  g_w4_nscr = 0;
+  return 0;
 }
 
 int attention_w4_prepare(hipStream_t st) {

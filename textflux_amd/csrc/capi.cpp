@@ -394,6 +394,8 @@ int tfx_gate_residual(const void* x, int64_t ldx, int64_t x_bstride, const void*
   return gate_residual(x, ldx, x_bstride, gate, gate_bstride, res, ldr, r_bstride, out, ldo, o_bstride, rows_per_batch, batch, D, S(stream));
 }
 
+int tfx_release_scratch(void) { return attention_w4_release(); }
+
 int tfx_attention_mode_counts(int64_t* counts, int32_t n, int32_t reset) {
   if (!counts && n > 0) return fail("tfx_attention_mode_counts: null pointer");
   return attention_mode_counts(counts, n, reset);
@@ -579,7 +581,7 @@ int tfx_set_option(const char* name, int value) {
   if (!std::strcmp(name, "attention_waves")) {
     if (value == 0) { set_attention_waves(0); return 0; }     // back to the library default and its size heuristic
     if (value != 4 && value != 8 && value != 9 && value != 10 && value != 12 && value != 16 && value != 20 && !(value >= 30 && value <= 34) && value != 40)
-      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves), 16 (ping-pong), 20 (half-tile pipelined), 30 .. 33 (one wave per SIMD, 32x32x16 MFMA: bookkeeping on the matrix pipe / row sums on the VALU / + lazy reference offset / 30 + lazy reference offset / 33, or no reference at all when the call carries a score bound) or 40 (one wave per SIMD, 16x16x32 MFMA)");
+      return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves), 16 (ping-pong), 20 (half-tile pipelined), 30 .. 34 (one wave per SIMD, 32x32x16 MFMA: 30 bookkeeping on the matrix pipe -- or no reference at all when the call carries an admissible score bound -- / 31 row sums on the VALU / 32 = 31 + lazy reference offset / 33 = 30 + lazy reference offset / 34 = no reference with a score bound, else 33) or 40 (one wave per SIMD, 16x16x32 MFMA)");
     set_attention_waves(value);
     return 0;
   }

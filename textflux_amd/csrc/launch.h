@@ -97,9 +97,10 @@ struct AttnArgs {
 int joint_attention(const AttnArgs& a, hipStream_t st);
 int joint_attention_hp(const AttnArgs& a, hipStream_t st);   // half-tile software-pipelined kernel (attention_hp.hip)
 int joint_attention_w16(const AttnArgs& a, hipStream_t st);  // one wave per SIMD on v_mfma_f32_16x16x32_bf16 (attention_w16.hip)
+int attention_w4_release();                                    // frees every tail-split scratch buffer (tfx_release_scratch)
 int attention_w4_prepare(hipStream_t st);                      // allocates the tail-split scratch of `st` (call outside stream capture)
 void set_attention_tail_split(int v);                          // 0 = never split the last round's q-tiles by keys (bench knob)
-int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode);   // one wave per SIMD, 64 query rows per wave (attention_w4.hip); mode: 0 bookkeeping on the matrix pipe, 1 row sums on the VALU, 2 + lazy reference offset
+int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode);   // one wave per SIMD, 64 query rows per wave (attention_w4.hip); mode (attn_w4_kernel<MODE>): 0 bookkeeping on the matrix pipe, 1 row sums on the VALU, 2 = 1 + lazy reference offset, 3 = 0 + lazy reference offset, 4 no reference at all (only when AttnArgs::score_bound is admissible, attention.hip)
 void set_attention_ablation(int a);
 void set_attention_use_bound(int v);
 int attention_mode_counts(int64_t* counts, int n, int reset);   // tfx_attention_mode_counts

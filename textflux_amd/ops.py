@@ -319,6 +319,12 @@ def attention_mode_counts(reset: bool = False) -> dict:
     return {name: int(c[i]) for i, name in enumerate(ATTENTION_MODES)}
 
 
+def release_scratch() -> None:
+    """Frees what the library allocated behind optional knobs (today: the attention tail-split partials, one buffer per stream that
+    ran with attention_tail_split = 1).  Step graphs captured while the knob was on keep dangling pointers: drop them first."""
+    L.check(L.lib().tfx_release_scratch(), "release_scratch")
+
+
 def set_option(name: str, value: int) -> None:
     L.check(L.lib().tfx_set_option(name.encode(), int(value)), "set_option")
 
@@ -372,6 +378,10 @@ def conv3x3_pair_nhwc(x: torch.Tensor, w_pair: torch.Tensor, bias_pair: Optional
     Cout = w_pair.shape[0] // 2
     if out is None:
         out = torch.empty(B, H, W, Cout, dtype=BF16, device=x.device)
+    # the kernel addresses res and out as dense [B, H, W, Cout] (no strides in tfx_conv3x3_pair_nhwc)
+    assert out.shape == (B, H, W, Cout) and out.dtype == BF16 and out.is_contiguous()
+    assert res is None or (res.shape == (B, H, W, Cout) and res.dtype == BF16 and res.is_contiguous())
+    assert W % 2 == 0
     L.check(L.lib().tfx_conv3x3_pair_nhwc(x.data_ptr(), B, H, W, Cin, w_pair.data_ptr(), _p(bias_pair), out.data_ptr(), Cout, _p(res),
                                           zero_page(x.device).data_ptr(), _stream()), "conv3x3_pair_nhwc")
     return out
