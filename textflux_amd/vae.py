@@ -170,25 +170,35 @@ class AutoencoderKL:
             x = ops.gemm(x.view(B * H * W, C), self.hw[p + ".conv_shortcut.weight"], self.sd[p + ".conv_shortcut.bias"]).view(B, H, W, -1)
         return self._conv(h, p + ".conv2", res=x)
 
+    # query rows per score chunk of the mid-block attention: the fp32 scores + bf16 weights of ONE chunk are the whole scratch
+    # (<= ATTEND_CHUNK_BYTES whatever the image size: 1024 x 1024 -> N = 16384 keys, 2048 rows per chunk, 8 chunks per image)
+    ATTEND_CHUNK_BYTES = 192 << 20
+
     def _attend(self, q, k, v):
         """softmax(q k^T / sqrt(C)) v for ONE head of dim C, q / k / v [B, N, C] bf16 (AttnProcessor2_0,
         D/models/attention_processor.py:2799-2881).  Scores stay fp32 between the two GEMMs (a flash kernel would keep them
         in registers); token counts are padded to a multiple of 64 with zero weights / zero v^T columns so that the P v
-        product takes the MFMA kernel for any h * w; one image at a time through reused [N, Np] score / weight buffers."""
+        product takes the MFMA kernel for any h * w.  Query rows are independent, so the score matrix is never materialised as a
+        whole: one image at a time, `rows` query rows at a time through ONE reused [rows, Np] score / weight buffer pair whose size
+        does not grow with the image (round 4 held the full [N, N]: 1.5 GiB at 1024 x 1024, 6 GiB at 2048 x 1024) -- same
+        arithmetic per row, bit-identical to the unchunked form (tests/test_vae_kernels_gpu.py)."""
         B, N, C = q.shape
         Np = (N + 63) // 64 * 64
         vt = torch.zeros(B, C, Np, dtype=torch.bfloat16, device=q.device) if Np != N else torch.empty(B, C, N, dtype=torch.bfloat16, device=q.device)
         ops.transpose(v, out=vt[:, :, :N])
-        if self._scores is None or self._scores[0].shape != (N, Np):
+        rows = max(256, min(N, self.ATTEND_CHUNK_BYTES // (Np * 6) // 256 * 256))
+        if self._scores is None or self._scores[0].shape != (rows, Np):
             self._scores = None                                          # release before re-allocating
-            self._scores = (torch.empty(N, Np, dtype=torch.float32, device=q.device),
-                            torch.zeros(N, Np, dtype=torch.bfloat16, device=q.device))
+            self._scores = (torch.empty(rows, Np, dtype=torch.float32, device=q.device),
+                            torch.zeros(rows, Np, dtype=torch.bfloat16, device=q.device))
         s, pw = self._scores
         o = torch.empty(B, N, C, dtype=torch.bfloat16, device=q.device)
         for b in range(B):
-            ops.gemm_f32(q[b], k[b], out=s[:, :N])
-            ops.row_softmax(s[:, :N], C ** -0.5, pw)
-            ops.gemm(pw, vt[b], None, out=o[b])
+            for r0 in range(0, N, rows):
+                n = min(rows, N - r0)
+                ops.gemm_f32(q[b, r0:r0 + n], k[b], out=s[:n, :N])
+                ops.row_softmax(s[:n, :N], C ** -0.5, pw[:n])
+                ops.gemm(pw[:n], vt[b], None, out=o[b, r0:r0 + n])
         return o
 
     def _mid(self, x, p):

@@ -15,7 +15,11 @@ library's own A/B switches -- product kernels only, nothing here is a test-only 
 
 Compared with profiles/r05_oracle_self_noise.json: the oracle against ITSELF when only the fp32 summation order of its nn.Linear changes.
 
-    python tools/drift_budget.py [--steps 3]      # GPU box, ~2 min -> gpurun_out/r05_drift_budget.json
+  torch_rocm_reference     NOT the engine: the oracle's plain-torch op chain (= the reference's op chain, tests/test_oracle_golden.py)
+                           executed by PyTorch-ROCm on this GPU (hipBLASLt GEMMs, torch's SDPA, ATen elementwise kernels) -- what the
+                           reference's OWN software stack, moved to an MI355X, gets against its CPU run.  All 30 steps.
+
+    python tools/drift_budget.py [--steps 3]      # GPU box, ~3 min -> gpurun_out/r05_drift_budget.json
 """
 import argparse
 import json
@@ -79,6 +83,28 @@ def main():
             if sw:
                 sw(False)
         print(name, ["%.3e" % e for e in rec["rows"][name]], flush=True)
+    # engine, all 30 steps (what tests/test_fulldepth_trajectory_gpu.py asserts)
+    a.steps = fd.N_SCHED
+    rec["engine_all_steps"] = run()
+    print("engine_all_steps", ["%.3e" % e for e in rec["engine_all_steps"]], flush=True)
+    # ---- the reference's op chain on PyTorch-ROCm (checker code on the GPU; nothing of this is product path)
+    del pipe, tr
+    torch.cuda.empty_cache()
+    from oracle import pipeline_oracle as po
+    cfg, sd = fd.seeded_weights()
+    sd = {k: v.cuda() for k, v in sd.items()}
+    lat, mil, pe, pooled = (t.cuda() for t in fd.inputs())
+    from oracle import flux_oracle as fo
+    def on_gpu(**kw):
+        with torch.device("cuda"):                   # factory calls inside the forward (arange, zeros) land on the GPU
+            return fo.transformer_forward(sd, cfg, **{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()})
+
+    with torch.no_grad():                            # scheduler tables stay host tensors, as in the reference's pipeline
+        _, traj = po.denoise(sd, cfg, lat, mil, pe, pooled, fd.H // 16, fd.W // 16, fd.N_SCHED, 30.0, teacher=[r.cuda() for r in ref],
+                             model_fn=on_gpu)
+    rec["torch_rocm_reference_all_steps"] = [mae(traj[i][0], ref[i]) for i in range(fd.N_SCHED)]
+    print("torch_rocm_reference_all_steps", ["%.3e" % e for e in rec["torch_rocm_reference_all_steps"]], flush=True)
+    rec["torch"] = torch.__version__
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(rec, f, indent=1)
