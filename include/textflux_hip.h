@@ -116,6 +116,14 @@ int tfx_gate_residual(const void* x, int64_t ldx, int64_t x_bstride, const void*
                       int64_t ldr, int64_t r_bstride, void* out, int64_t ldo, int64_t o_bstride, int32_t rows_per_batch,
                       int32_t batch, int32_t D, tfx_stream stream);
 
+/* ---- seam blend of the tiled VAE (AutoencoderKL.blend_v / blend_h, D/models/autoencoders/autoencoder_kl.py:334-344), NHWC bf16,
+ *      in place on b: for t in [0, extent), u in [0, len):  b[n][t][u][:] = bf16(bf16(a[n][t][u][:] * (1 - t/extent)) +
+ *      bf16(b[n][t][u][:] * (t/extent)))  (the reference's python-float weights in fp32, its three bf16 roundings).  t walks rows for
+ *      the vertical blend and columns for the horizontal one: *_tstride / *_ustride are the element strides of t and u, `a` points at
+ *      the first of the neighbour tile's last `extent` rows (columns).  C % 8 == 0. */
+int tfx_blend_edge_nhwc(const void* a, int64_t a_bstride, int64_t a_tstride, int64_t a_ustride, void* b, int64_t b_bstride,
+                        int64_t b_tstride, int64_t b_ustride, int32_t batch, int32_t extent, int32_t len, int32_t C, tfx_stream stream);
+
 /* ---- joint attention softmax(q k^T * scale) v, head_dim 128, no mask (F.scaled_dot_product_attention,
  *      D/models/attention_processor.py:2039-2041).  Element (b, n, h, d) of q is q[b*q_bstride + n*ldq + h*128 + d];
  *      same for k, v, o.  o may alias q. */

@@ -106,6 +106,63 @@ def sample_posterior(mean: Tensor, std: Tensor, eps: Tensor) -> Tensor:
     return mean + std * eps
 
 
+# --------------------------------------------------------------------------- tiled encode / decode (enable_tiling)
+def _blend_v(a: Tensor, b: Tensor, extent: int) -> Tensor:
+    """AutoencoderKL.blend_v (autoencoder_kl.py:334-338): the top `extent` rows of b fade in from the bottom rows of a, IN PLACE on b
+    (so a tile that is blended later sees its already-blended neighbours, as in the reference)."""
+    extent = min(a.shape[2], b.shape[2], extent)
+    for y in range(extent):
+        b[:, :, y, :] = a[:, :, -extent + y, :] * (1 - y / extent) + b[:, :, y, :] * (y / extent)
+    return b
+
+
+def _blend_h(a: Tensor, b: Tensor, extent: int) -> Tensor:
+    """AutoencoderKL.blend_h (autoencoder_kl.py:340-344)."""
+    extent = min(a.shape[3], b.shape[3], extent)
+    for x in range(extent):
+        b[:, :, :, x] = a[:, :, :, -extent + x] * (1 - x / extent) + b[:, :, :, x] * (x / extent)
+    return b
+
+
+def _tiled(x: Tensor, fn, tile: int, out_tile: int, overlap_factor: float) -> Tensor:
+    """The common body of _tiled_encode / tiled_decode (autoencoder_kl.py:346-395, 456-503): tiles of `tile` every
+    int(tile * (1 - overlap)) pixels, each through `fn`, blended over int(out_tile * overlap) output pixels with the tile above
+    and the tile to the left, cropped to out_tile - blend and concatenated."""
+    step = int(tile * (1 - overlap_factor))
+    extent = int(out_tile * overlap_factor)
+    limit = out_tile - extent
+    rows = [[fn(x[:, :, i:i + tile, j:j + tile]) for j in range(0, x.shape[3], step)] for i in range(0, x.shape[2], step)]
+    result_rows = []
+    for i, row in enumerate(rows):
+        result_row = []
+        for j, t in enumerate(row):
+            if i > 0:
+                t = _blend_v(rows[i - 1][j], t, extent)
+            if j > 0:
+                t = _blend_h(row[j - 1], t, extent)
+            result_row.append(t[:, :, :limit, :limit])
+        result_rows.append(torch.cat(result_row, dim=3))
+    return torch.cat(result_rows, dim=2)
+
+
+def tile_sizes(cfg: VaeConfig, sample_size: int) -> Tuple[int, int]:
+    """(tile_sample_min_size, tile_latent_min_size) of AutoencoderKL.__init__ (autoencoder_kl.py:131-138)."""
+    return sample_size, int(sample_size / (2 ** (len(cfg.block_out_channels) - 1)))
+
+
+def tiled_encoder(x: Tensor, sd: SD, cfg: VaeConfig, sample_size: int, overlap_factor: float = 0.25) -> Tensor:
+    """AutoencoderKL._tiled_encode (autoencoder_kl.py:346-395; no quant conv in the FLUX VAE): the moments tensor.  _encode takes
+    this path when use_tiling and the image is larger than tile_sample_min_size in either direction (:264-267)."""
+    ts, tl = tile_sizes(cfg, sample_size)
+    return _tiled(x, lambda t: encoder(t, sd, cfg), ts, tl, overlap_factor)
+
+
+def tiled_decoder(z: Tensor, sd: SD, cfg: VaeConfig, sample_size: int, overlap_factor: float = 0.25) -> Tensor:
+    """AutoencoderKL.tiled_decode (autoencoder_kl.py:456-503)."""
+    ts, tl = tile_sizes(cfg, sample_size)
+    return _tiled(z, lambda t: decoder(t, sd, cfg), tl, ts, overlap_factor)
+
+
 def state_dict_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
     out: Dict[str, Tuple[int, ...]] = {}
 

@@ -371,8 +371,40 @@ def g9_vae():
     save("g9_vae", out)
 
 
+# ----------------------------------------------------------------------------- G13 tiled VAE (enable_tiling)
+def g13_vae_tiled():
+    """AutoencoderKL.enable_tiling() (autoencoder_kl.py:145-160, 264-267, 301-303, 346-395, 456-503) on the G9 architecture with
+    sample_size 32 (tiles of 32 px / 4 latent px every 24 / 3, blended over 1 latent px / 8 px): ragged tile grids in both directions,
+    fp32 and bf16 (the blend's rounding points), encode moments and decode output."""
+    from diffusers import AutoencoderKL
+    from oracle import vae_oracle as vo
+    out = {}
+    cfg = vo.VaeConfig(**G9_VAE)
+    sd = vo.seeded_state_dict(cfg, 1300)
+    x = rnd((2, 3, 80, 56), 1301).clamp(-1, 1)
+    z = rnd((2, 16, 10, 7), 1302)
+    out["x"], out["z"] = x, z
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        vae = AutoencoderKL(in_channels=3, out_channels=3, block_out_channels=cfg.block_out_channels,
+                            layers_per_block=cfg.layers_per_block, down_block_types=("DownEncoderBlock2D",) * 4,
+                            up_block_types=("UpDecoderBlock2D",) * 4, latent_channels=16, norm_num_groups=cfg.norm_num_groups,
+                            use_quant_conv=False, use_post_quant_conv=False, shift_factor=0.1159, scaling_factor=0.3611,
+                            sample_size=32)
+        vae.load_state_dict(sd, strict=True)
+        vae.eval().to(dt)
+        vae.enable_tiling()
+        assert (vae.tile_sample_min_size, vae.tile_latent_min_size, vae.tile_overlap_factor) == (32, 4, 0.25)
+        post = vae.encode(x.to(dt)).latent_dist
+        out[f"{name}.enc.mean"], out[f"{name}.enc.std"] = post.mean, post.std
+        out[f"{name}.dec.out"] = vae.decode(z.to(dt), return_dict=False)[0]
+        vae.disable_tiling()
+        out[f"{name}.dec.untiled"] = vae.decode(z.to(dt), return_dict=False)[0]
+    assert not torch.equal(out["f32.dec.out"], out["f32.dec.untiled"])     # tiling changes the result (each tile its own statistics)
+    save("g13_vae_tiled", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g9"]
-    fns = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_sched, g5=g5_pipeline, g6=g6_g7, g9=g9_vae)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g9", "g13"]
+    fns = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_sched, g5=g5_pipeline, g6=g6_g7, g9=g9_vae, g13=g13_vae_tiled)
     for w in which:
         fns[w]()

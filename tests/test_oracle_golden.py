@@ -237,3 +237,26 @@ def test_fill_pipeline_with_vae(golden):
     assert maxdiff(lat, g["pipe.out_latent"]) <= 1e-4
     img = po.fill_pipeline(sd, G3_CFG, vsd, vcfg, output_type="np", **kw)
     assert img.shape == g["pipe.out_np"].shape and maxdiff(img, g["pipe.out_np"]) <= 1e-4
+
+
+def test_vae_tiled_encode_decode(golden):
+    """AutoencoderKL.enable_tiling (autoencoder_kl.py:346-395, 456-503): the oracle's tiled encoder / decoder against the reference's
+    on ragged tile grids -- fp32 to summation order, bf16 BIT-EXACT (the in-place blends' rounding points and the order in which tiles
+    see their already-blended neighbours)."""
+    from oracle import vae_oracle as vo
+    g = golden("g13_vae_tiled")
+    cfg = vo.VaeConfig(**G9_VAE)
+    sd = vo.seeded_state_dict(cfg, 1300)
+    assert vo.tile_sizes(cfg, 32) == (32, 4)
+    mom = vo.tiled_encoder(g["x"], sd, cfg, 32)
+    mean, logvar = torch.chunk(mom, 2, dim=1)
+    assert maxdiff(mean, g["f32.enc.mean"]) <= 2e-5
+    assert maxdiff(torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)), g["f32.enc.std"]) <= 2e-5
+    dec = vo.tiled_decoder(g["z"], sd, cfg, 32)
+    assert dec.shape == g["f32.dec.out"].shape == (2, 3, 80, 56) and maxdiff(dec, g["f32.dec.out"]) <= 5e-5
+    assert maxdiff(vo.decoder(g["z"], sd, cfg), g["f32.dec.untiled"]) <= 5e-5 and maxdiff(dec, g["f32.dec.untiled"]) > 1e-3
+    bf = torch.bfloat16
+    sdb = {k: v.to(bf) for k, v in sd.items()}
+    momb = vo.tiled_encoder(g["x"].to(bf), sdb, cfg, 32)
+    assert torch.equal(torch.chunk(momb, 2, dim=1)[0], g["bf16.enc.mean"])
+    assert torch.equal(vo.tiled_decoder(g["z"].to(bf), sdb, cfg, 32), g["bf16.dec.out"])

@@ -166,8 +166,56 @@ def test_vae_slicing_is_bit_identical_to_the_batched_path():
     assert vae.use_slicing
     pipe.disable_vae_slicing()
     assert not vae.use_slicing
-    with pytest.warns(UserWarning, match="enable_vae_tiling"):
-        pipe.enable_vae_tiling()
+    pipe.enable_vae_tiling()
+    assert vae.use_tiling
+    pipe.disable_vae_tiling()
+    assert not vae.use_tiling
+
+
+G9_VAE = dict(block_out_channels=(64, 64, 128, 128), layers_per_block=1, latent_channels=16, norm_num_groups=16)
+
+
+def test_vae_tiling_matches_the_references_tiled_encode_decode(golden):
+    """enable_tiling() (reference: autoencoder_kl.py:145-160, 264-267, 301-303, 346-395, 456-503) against fixtures generated by the
+    IMPORTED reference with tiling on (tests/golden/g13_vae_tiled.safetensors: sample_size 32 -> tiles of 32 px / 4 latent px every
+    24 / 3, seams blended over 1 latent px / 8 px; 80 x 56 image = a ragged 4 x 3 tile grid with 8-px edge tiles, 10 x 7 latents): the
+    HIP VAE runs every tile through the whole encoder / decoder, blends in the reference's order and rounding, crops and
+    concatenates.  Compared with the reference's bf16 run at the bf16 level and with its fp32 run at the level the untiled path is;
+    and the seam blend itself (tfx_blend_edge_nhwc) bit for bit against the reference's two bf16 tensor ops."""
+    from oracle import vae_oracle as vo
+    from textflux_amd import ops as o
+    from textflux_amd.vae import AutoencoderKL
+    g = golden("g13_vae_tiled")
+    cfg = vo.VaeConfig(**G9_VAE)
+    sd = vo.seeded_state_dict(cfg, 1300)
+    vae = AutoencoderKL(sample_size=32, **G9_VAE).load_state_dict(sd, device="cuda")
+    assert (vae.tile_sample_min_size, vae.tile_latent_min_size, vae.tile_overlap_factor) == (32, 4, 0.25)
+    x, z = g["x"].to(BF).cuda(), g["z"].to(BF).cuda()
+    untiled = vae.decode(z, return_dict=False)[0]
+    close(untiled, g["f32.dec.untiled"], max_rel=5e-2, mae_rel=1.5e-2)
+    vae.enable_tiling()
+    try:
+        post = vae.encode(x).latent_dist
+        dec = vae.decode(z, return_dict=False)[0]
+    finally:
+        vae.disable_tiling()
+    assert dec.shape == (2, 3, 80, 56) and post.mean.shape == (2, 16, 10, 7)
+    close(post.mean, g["f32.enc.mean"], max_rel=5e-2, mae_rel=1.5e-2)
+    close(post.std, g["f32.enc.std"], max_rel=5e-2, mae_rel=1.5e-2)
+    close(dec, g["f32.dec.out"], max_rel=5e-2, mae_rel=1.5e-2)
+    # two bf16 runs of one fp32 function: as close to each other as either is to fp32
+    close(dec, g["bf16.dec.out"], max_rel=5e-2, mae_rel=1.5e-2)
+    assert not torch.equal(dec, untiled)
+    d_tiling = (g["f32.dec.out"] - g["f32.dec.untiled"]).abs().mean().item()
+    assert (dec.float().cpu() - g["f32.dec.out"]).abs().mean().item() < 0.5 * d_tiling      # the tiled image, not the untiled one
+    # the seam blend alone, bit-exact: a, b bf16 NHWC tiles, vertical and horizontal, extent clamped by a short tile
+    a4, b4 = rnd((2, 9, 12, 16), 70).to(BF), rnd((2, 5, 12, 16), 71).to(BF)
+    for axis, ext in ((1, 8), (1, 3), (2, 8), (2, 1)):
+        aa, bb = (a4, b4) if axis == 1 else (a4.transpose(1, 2).contiguous(), b4.transpose(1, 2).contiguous())
+        ref = bb.permute(0, 3, 1, 2).clone()
+        (vo._blend_v if axis == 1 else vo._blend_h)(aa.permute(0, 3, 1, 2), ref, ext)
+        got = o.blend_edge_nhwc_(aa.cuda(), bb.cuda().clone(), ext, axis)
+        assert torch.equal(got.cpu().permute(0, 3, 1, 2), ref), (axis, ext)
 
 
 def test_vae_rejects_configs_the_kernels_do_not_cover():

@@ -109,6 +109,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "tfx_gate_residual": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int32, c_int32, c_int32, c_void_p]),
+    "tfx_blend_edge_nhwc": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p]),
     "tfx_joint_attention": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "tfx_euler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_void_p, c_int32,
                                c_void_p]),

@@ -394,6 +394,16 @@ int tfx_gate_residual(const void* x, int64_t ldx, int64_t x_bstride, const void*
   return gate_residual(x, ldx, x_bstride, gate, gate_bstride, res, ldr, r_bstride, out, ldo, o_bstride, rows_per_batch, batch, D, S(stream));
 }
 
+int tfx_blend_edge_nhwc(const void* a, int64_t a_bstride, int64_t a_tstride, int64_t a_ustride, void* b, int64_t b_bstride,
+                        int64_t b_tstride, int64_t b_ustride, int32_t batch, int32_t extent, int32_t len, int32_t C, tfx_stream stream) {
+  if (!a || !b) return fail("tfx_blend_edge_nhwc: null pointer");
+  if (C <= 0 || C % 8 || (a_bstride | a_tstride | a_ustride | b_bstride | b_tstride | b_ustride) % 8)
+    return fail("tfx_blend_edge_nhwc: C and every stride must be multiples of 8 elements");
+  if (((uintptr_t)a | (uintptr_t)b) % 16) return fail("tfx_blend_edge_nhwc: pointers must be 16-byte aligned");
+  if (batch < 0 || extent < 0 || len < 0) return fail("tfx_blend_edge_nhwc: negative extent");
+  return blend_edge(a, a_bstride, a_tstride, a_ustride, b, b_bstride, b_tstride, b_ustride, batch, extent, len, C, S(stream));
+}
+
 int tfx_release_scratch(void) { return attention_w4_release(); }
 
 int tfx_attention_mode_counts(int64_t* counts, int32_t n, int32_t reset) {

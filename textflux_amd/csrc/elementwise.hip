@@ -310,6 +310,33 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const bf16_t* x, int
   *reinterpret_cast<u32x4*>(out + b * obs + (int64_t)r * ldo + c * 8) = ov;
 }
 
+// Tile seam blend of the tiled VAE (AutoencoderKL.blend_v / blend_h, D/models/autoencoders/autoencoder_kl.py:334-344): for t in
+// [0, extent), u in [0, len):  b[., t, u, :] = a[., t, u, :] * (1 - t / extent) + b[., t, u, :] * (t / extent), IN PLACE on b.  (t, u) =
+// (row, column) for the vertical blend, (column, row) for the horizontal one: the caller passes the strides and points `a` at the
+// first of its last `extent` rows / columns.  Rounding as the reference's bf16 tensor ops: python-float weights in fp32, each
+// product rounded to bf16, the sum rounded.  NHWC, C % 8 == 0, 16 bytes per lane; the seams are a sliver of the image.
+__global__ __launch_bounds__(256) void blend_edge_kernel(const bf16_t* __restrict__ a, int64_t a_bs, int64_t a_ts, int64_t a_us,
+                                                         bf16_t* __restrict__ b, int64_t b_bs, int64_t b_ts, int64_t b_us, int extent,
+                                                         int len, int cpr, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % cpr);
+  int64_t r = i / cpr;
+  const int u = (int)(r % len);
+  r /= len;
+  const int t = (int)(r % extent);
+  const int bi = (int)(r / extent);
+  const float wb = (float)((double)t / (double)extent), wa = (float)(1.0 - (double)t / (double)extent);
+  const bf16_t* ap = a + bi * a_bs + (int64_t)t * a_ts + (int64_t)u * a_us + c * 8;
+  bf16_t* bp = b + bi * b_bs + (int64_t)t * b_ts + (int64_t)u * b_us + c * 8;
+  float fa[8], fb[8], o[8];
+  unpack8(*reinterpret_cast<const u32x4*>(ap), fa);
+  unpack8(*reinterpret_cast<const u32x4*>(bp), fb);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = round_bf(fa[e] * wa) + round_bf(fb[e] * wb);
+  *reinterpret_cast<u32x4*>(bp) = pack8(o);
+}
+
 // ---------------------------------------------------------------------------------------------
 // GroupNorm(groups, eps, affine) [+ SiLU] on NHWC activations x [B, HW, C] (VAE blocks: ResnetBlock2D norm1/norm2,
 // D/models/resnet.py:327-366; conv_norm_out, D/models/autoencoders/vae.py:191-193, 352-354; mid-block attention
@@ -507,6 +534,14 @@ int gate_residual(const void* x, int64_t ldx, int64_t x_bs, const void* gate, in
                                                                              (const bf16_t*)res, ldr, r_bs, (bf16_t*)out, ldo, o_bs, rows,
                                                                              D / 8, total);
   return check_launch("gate_residual");
+}
+int blend_edge(const void* a, int64_t a_bs, int64_t a_ts, int64_t a_us, void* b, int64_t b_bs, int64_t b_ts, int64_t b_us, int batch,
+               int extent, int len, int C, hipStream_t st) {
+  const int64_t total = (int64_t)batch * extent * len * (C / 8);
+  if (total <= 0) return 0;
+  blend_edge_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>((const bf16_t*)a, a_bs, a_ts, a_us, (bf16_t*)b, b_bs, b_ts, b_us,
+                                                                          extent, len, C / 8, total);
+  return check_launch("blend_edge");
 }
 int groupnorm_silu_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* ws, int B, int64_t HW,
                         int C, int groups, float eps, bool silu, hipStream_t st) {

@@ -104,6 +104,8 @@ int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode);   // one wa
 void set_attention_ablation(int a);
 void set_attention_use_bound(int v);
 int attention_mode_counts(int64_t* counts, int n, int reset);   // tfx_attention_mode_counts
+int blend_edge(const void* a, int64_t a_bs, int64_t a_ts, int64_t a_us, void* b, int64_t b_bs, int64_t b_ts, int64_t b_us, int batch,
+               int extent, int len, int C, hipStream_t st);
 int gate_residual(const void* x, int64_t ldx, int64_t x_bs, const void* gate, int64_t gate_bs, const void* res, int64_t ldr, int64_t r_bs,
                   void* out, int64_t ldo, int64_t o_bs, int rows, int batch, int D, hipStream_t st);   // 0: ignore AttnArgs::score_bound
 void set_attention_persistent(int v);  // 0: one workgroup per (b, h, q-tile) item instead of one per CU

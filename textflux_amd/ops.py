@@ -387,6 +387,24 @@ def conv3x3_pair_nhwc(x: torch.Tensor, w_pair: torch.Tensor, bias_pair: Optional
     return out
 
 
+def blend_edge_nhwc_(a: torch.Tensor, b: torch.Tensor, extent: int, axis: int) -> torch.Tensor:
+    """Seam blend of two VAE tiles, in place on b (AutoencoderKL.blend_v: axis 1 = rows, blend_h: axis 2 = columns; a, b NHWC bf16
+    views [B, H, W, C]): the first `extent` rows / columns of b fade in from the LAST `extent` of a; extent is clamped to both tiles'
+    sizes as the reference does, and the weights use the clamped value."""
+    _chk_dev(a, b)
+    assert a.dim() == 4 and b.dim() == 4 and a.dtype == b.dtype == BF16 and a.stride(3) == b.stride(3) == 1 and axis in (1, 2)
+    other = 3 - axis
+    extent = min(a.shape[axis], b.shape[axis], int(extent))
+    assert a.shape[0] == b.shape[0] and a.shape[3] == b.shape[3] and a.shape[other] == b.shape[other], "tiles of one row / column line up"
+    if extent <= 0:
+        return b
+    a0 = a.narrow(axis, a.shape[axis] - extent, extent)
+    L.check(L.lib().tfx_blend_edge_nhwc(a0.data_ptr(), a0.stride(0), a0.stride(axis), a0.stride(other), b.data_ptr(), b.stride(0),
+                                        b.stride(axis), b.stride(other), b.shape[0], extent, b.shape[other], b.shape[3], _stream()),
+            "blend_edge_nhwc")
+    return b
+
+
 def groupnorm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, silu: bool = True,
                    eps: float = 1e-6, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [B, ..., C] NHWC bf16 -> GroupNorm(+SiLU)."""

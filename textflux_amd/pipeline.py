@@ -193,16 +193,13 @@ class FluxFillPipeline:
         self.vae.disable_slicing()
 
     def enable_vae_tiling(self):
-        import warnings
-        if not getattr(self, "_warned_vae_knob", False):
-            self._warned_vae_knob = True
-            warnings.warn("enable_vae_tiling() has no effect here: the VAE runs untiled at every supported geometry (288 GB of HBM "
-                          "per MI355X; 1024 x 1024 at batch 8 is a test) -- the reference's tiled decode blends overlapping tiles, "
-                          "i.e. computes a DIFFERENT image; use enable_vae_slicing() to bound the working set.  The call is "
-                          "accepted for drop-in compatibility", stacklevel=2)
+        """Overlapping VAE tiles blended at the seams (reference: pipeline_flux_fill.py enable_vae_tiling -> AutoencoderKL.enable_tiling,
+        autoencoder_kl.py:145-160).  As in the reference this computes a different image from the untiled path; nothing at the
+        BASELINE geometries needs it on 288 GB of HBM, it exists so that a caller who sets it gets what the reference gives."""
+        self.vae.enable_tiling()
 
     def disable_vae_tiling(self):
-        pass
+        self.vae.disable_tiling()
 
     @property
     def guidance_scale(self):

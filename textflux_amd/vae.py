@@ -62,11 +62,17 @@ def _narrow(cin: int) -> int:
 class AutoencoderKL:
     def __init__(self, in_channels: int = 3, out_channels: int = 3, block_out_channels: Tuple[int, ...] = (128, 256, 512, 512),
                  layers_per_block: int = 2, latent_channels: int = 16, norm_num_groups: int = 32,
-                 scaling_factor: float = 0.3611, shift_factor: float = 0.1159, **_ignored):
+                 scaling_factor: float = 0.3611, shift_factor: float = 0.1159, sample_size: int = 32, **_ignored):
         self.config = _Config(in_channels=in_channels, out_channels=out_channels,
                               block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
                               latent_channels=latent_channels, norm_num_groups=norm_num_groups,
-                              scaling_factor=scaling_factor, shift_factor=shift_factor)
+                              scaling_factor=scaling_factor, shift_factor=shift_factor, sample_size=sample_size)
+        # tiling geometry (D/models/autoencoders/autoencoder_kl.py:127-139; the FLUX VAE's config.json says sample_size 1024)
+        ss = sample_size[0] if isinstance(sample_size, (list, tuple)) else sample_size
+        self.use_tiling = False
+        self.tile_sample_min_size = ss
+        self.tile_latent_min_size = int(ss / (2 ** (len(self.config.block_out_channels) - 1)))
+        self.tile_overlap_factor = 0.25
         bad = [ch for ch in self.config.block_out_channels
                if ch % 64 or (ch // norm_num_groups) % 4 or 256 % (ch // 8) or ch % norm_num_groups]
         if bad or in_channels > 8 or out_channels > 8 or latent_channels % 8 or latent_channels > 32:
@@ -109,7 +115,7 @@ class AutoencoderKL:
         with open(os.path.join(root, "config.json")) as f:
             cfg = json.load(f)
         keys = ("in_channels", "out_channels", "block_out_channels", "layers_per_block", "latent_channels",
-                "norm_num_groups", "scaling_factor", "shift_factor")
+                "norm_num_groups", "scaling_factor", "shift_factor", "sample_size")
         m = cls(**{k: cfg[k] for k in keys if k in cfg})
         sd = load_file(os.path.join(root, "diffusion_pytorch_model.safetensors"))
         missing = [k for k in m._shapes() if k not in sd]
@@ -227,6 +233,41 @@ class AutoencoderKL:
     def disable_slicing(self):
         self.use_slicing = False
 
+    # enable_tiling() / disable_tiling(): the reference's other memory knob (autoencoder_kl.py:145-160): inputs larger than
+    # tile_sample_min_size (tile_latent_min_size for decode) in either direction are cut into overlapping tiles, each tile runs through
+    # the whole encoder / decoder on its own (its own GroupNorm statistics, its own mid-block attention), neighbouring results are
+    # blended over a quarter tile and cropped (:346-395, 456-503).  This computes a DIFFERENT image from the untiled path -- in the
+    # reference too -- and is reproduced here tile for tile, blend for blend (tfx_blend_edge_nhwc), in the reference's order: a tile is
+    # blended IN PLACE with its upper and left neighbours, which have already been blended with theirs.
+    def enable_tiling(self, use_tiling: bool = True):
+        self.use_tiling = use_tiling
+
+    def disable_tiling(self):
+        self.enable_tiling(False)
+
+    def _tiled(self, x: torch.Tensor, fn, tile: int, out_tile: int) -> torch.Tensor:
+        step = int(tile * (1 - self.tile_overlap_factor))
+        extent = int(out_tile * self.tile_overlap_factor)
+        limit = out_tile - extent
+        rows = [[fn(x[:, i:i + tile, j:j + tile].contiguous()) for j in range(0, x.shape[2], step)] for i in range(0, x.shape[1], step)]
+        for i, row in enumerate(rows):
+            for j, t in enumerate(row):
+                if i > 0:
+                    ops.blend_edge_nhwc_(rows[i - 1][j], t, extent, axis=1)
+                if j > 0:
+                    ops.blend_edge_nhwc_(row[j - 1], t, extent, axis=2)
+        hs = [min(r[0].shape[1], limit) for r in rows]
+        ws = [min(t.shape[2], limit) for t in rows[0]]
+        out = torch.empty(x.shape[0], sum(hs), sum(ws), rows[0][0].shape[3], dtype=rows[0][0].dtype, device=x.device)
+        y0 = 0
+        for i, row in enumerate(rows):
+            x0 = 0
+            for j, t in enumerate(row):
+                out[:, y0:y0 + hs[i], x0:x0 + ws[j]].copy_(t[:, :hs[i], :ws[j]])       # crop + concatenate: device copies
+                x0 += ws[j]
+            y0 += hs[i]
+        return out
+
     def _sliced(self, fn, x: torch.Tensor) -> torch.Tensor:
         if not self.use_slicing or x.shape[0] <= 1:
             return fn(x)
@@ -244,6 +285,11 @@ class AutoencoderKL:
         return self._sliced(self._encode_moments_nhwc, x8)
 
     def _encode_moments_nhwc(self, x8: torch.Tensor) -> torch.Tensor:
+        if self.use_tiling and (x8.shape[2] > self.tile_sample_min_size or x8.shape[1] > self.tile_sample_min_size):   # :264-267
+            return self._tiled(x8, self._encode_moments_whole, self.tile_sample_min_size, self.tile_latent_min_size)
+        return self._encode_moments_whole(x8)
+
+    def _encode_moments_whole(self, x8: torch.Tensor) -> torch.Tensor:
         c = self.config
         h = self._conv(x8, "encoder.conv_in")
         n = len(c.block_out_channels)
@@ -261,6 +307,11 @@ class AutoencoderKL:
         return self._sliced(self._decode_nhwc, z)
 
     def _decode_nhwc(self, z: torch.Tensor) -> torch.Tensor:
+        if self.use_tiling and (z.shape[2] > self.tile_latent_min_size or z.shape[1] > self.tile_latent_min_size):       # :301-303
+            return self._tiled(z, self._decode_whole, self.tile_latent_min_size, self.tile_sample_min_size)
+        return self._decode_whole(z)
+
+    def _decode_whole(self, z: torch.Tensor) -> torch.Tensor:
         c = self.config
         if z.shape[-1] != _narrow(c.latent_channels):
             zp = torch.zeros(*z.shape[:-1], _narrow(c.latent_channels), dtype=z.dtype, device=z.device)
