@@ -381,7 +381,6 @@ def conv3x3_pair_nhwc(x: torch.Tensor, w_pair: torch.Tensor, bias_pair: Optional
     # the kernel addresses res and out as dense [B, H, W, Cout] (no strides in tfx_conv3x3_pair_nhwc)
     assert out.shape == (B, H, W, Cout) and out.dtype == BF16 and out.is_contiguous()
     assert res is None or (res.shape == (B, H, W, Cout) and res.dtype == BF16 and res.is_contiguous())
-    assert W % 2 == 0
     L.check(L.lib().tfx_conv3x3_pair_nhwc(x.data_ptr(), B, H, W, Cin, w_pair.data_ptr(), _p(bias_pair), out.data_ptr(), Cout, _p(res),
                                           zero_page(x.device).data_ptr(), _stream()), "conv3x3_pair_nhwc")
     return out
