@@ -176,7 +176,9 @@ def main():
     S = (H // 16) * (W // 16)
     full = a.layers == [19, 38]
 
-    # ---- model: FLUX.1-Fill architecture, random-init on the device (no checkpoints offline; throughput does not depend on values)
+    # ---- model: FLUX.1-Fill architecture, random-init on the device (no checkpoints offline).  Throughput depends on the VALUES in one
+    # place only: the attention stream each block's q / k RMSNorm weights admit (reported as roofline.attention.modes, with the call time
+    # of the other stream beside it); matrix-core power, and with it the clock, also depends on operand entropy -- random data is the worst case
     tr = FluxTransformer2DModel(in_channels=384, out_channels=64, num_layers=a.layers[0], num_single_layers=a.layers[1],
                                 guidance_embeds=True).init_random_(seed=1234 + rank, device=dev)
     vae = AutoencoderKL().init_random_(seed=7, device=dev)
@@ -328,7 +330,7 @@ def main():
         # rocm-smi its own sustained loops): they are READ from the newest committed profile and say so -- "live": false,
         # the file, and the round it was collected in -- so that no future run can pass them off as measured by this run.
         def committed(stem):
-            for rnd in ("r04", "r03", "r02"):
+            for rnd in ("r05", "r04", "r03", "r02"):
                 fn = os.path.join(REPO, "profiles", f"{rnd}_{stem}.json")
                 if os.path.exists(fn):
                     with open(fn) as f:
