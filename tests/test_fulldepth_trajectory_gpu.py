@@ -82,3 +82,36 @@ def test_free_running_trajectory_and_graph_equals_eager(setting):
     graphed = pipe(**fd.call_kwargs()).images[0].float().cpu()
     pipe.enable_hip_graph(False)
     assert torch.equal(graphed, got[-1])
+
+
+def test_headline_geometry_full_depth_steps(setting):
+    """The same 57-block model at the geometry bench.py is quoted on (P1024: 1024 x 1024, S = 4096, N = 4608): the first, the middle and the
+    last step of the 30-step schedule, each one forward + Euler step from seeded latents (fixture g14: the bf16-faithful oracle's results
+    and, as metadata, the oracle's self-noise at the same three points -- tools/fulldepth_p1024.py).  |dsigma| of the last step is 0.098
+    here (0.062 at SL512), so its floor alone exceeds 1e-3; asserted as for SL512: err <= max(1e-3, 1.15 x floor)."""
+    from safetensors import safe_open
+    from safetensors.torch import load_file
+    pipe, _ = setting
+    ref = load_file(fd.P1024_FIXTURE)
+    with safe_open(fd.P1024_FIXTURE, "pt") as f:
+        floor = json.loads(f.metadata()["floor"])
+    pipe.enable_hip_graph(False)
+    for k in fd.P1024_STEPS:
+        lat, mil, pe, pooled = fd.p1024_inputs(k)
+        got = []
+
+        def cb(p, i, t, kw):
+            if i == k:
+                got.append(kw["latents"][0].float().cpu())
+                p._interrupt = True
+            elif i == k - 1:
+                return {"latents": lat.cuda()}
+            return {}
+
+        pipe(prompt_embeds=pe.cuda(), pooled_prompt_embeds=pooled.cuda(), latents=lat.cuda(), masked_image_latents=mil.cuda(),
+             height=fd.P1024_H, width=fd.P1024_W, guidance_scale=30.0, output_type="latent", num_inference_steps=fd.N_SCHED,
+             callback_on_step_end=cb)
+        assert len(got) == 1 and torch.isfinite(got[0]).all()
+        e = mae(got[0], ref[f"oracle.step{k}"])
+        print(f"P1024 full depth, step {k + 1}/30: engine-vs-reference-bf16 latent MAE {e:.3e}; oracle self-noise floor {floor[str(k)]:.3e}")
+        assert e <= max(1e-3, 1.15 * floor[str(k)]), (k, e, floor[str(k)])

@@ -243,10 +243,11 @@ def test_mid_block_attention_matches_fp32_softmax_attention():
     close(out, ref.to(BF), max_rel=1.5e-2, mae_rel=3e-3)
 
 
-def test_mid_block_attention_score_chunks_are_bit_identical_and_bound_the_scratch():
+def test_mid_block_attention_score_chunks_bound_the_scratch():
     """Round 5: the mid-block attention walks the query rows in chunks through one reused score / weight
     buffer pair whose size is capped (AutoencoderKL.ATTEND_CHUNK_BYTES) instead of materialising [N, N]: ragged token count, ragged last
-    chunk, batch 2 -- bit-identical to one chunk per image, and the scratch holds `rows` rows, not N."""
+    chunk, batch 2.  The scratch holds `rows` rows, not N; reruns are bit-identical; against one chunk per image the result differs only
+    by the fp32 summation order of the K-sliced P v product (isolated last-ulp flips); both match fp32 softmax attention."""
     from textflux_amd.vae import AutoencoderKL
     vae = AutoencoderKL.__new__(AutoencoderKL)
     vae._scores = None
@@ -258,9 +259,12 @@ def test_mid_block_attention_score_chunks_are_bit_identical_and_bound_the_scratc
     vae.ATTEND_CHUNK_BYTES = 4 << 20                       # 4 MiB / (2176 * 6 B) -> 256 rows per chunk: 9 chunks, the last one ragged
     parts = vae._attend(q, k, v)
     assert vae._scores[0].shape[0] == 256 and vae._scores[0].numel() * 6 <= 4 << 20
-    assert torch.equal(parts, whole)
-    ref = torch.softmax(q[1].float() @ k[1].float().T * C ** -0.5, -1) @ v[1].float()
-    close(parts[1], ref.to(BF), max_rel=1.5e-2, mae_rel=3e-3)
+    assert torch.equal(parts, vae._attend(q, k, v))
+    d = (parts.float() - whole.float()).abs()
+    assert d.max().item() <= 2 ** -7 * whole.float().abs().max().item() and (d > 0).float().mean().item() < 0.05
+    for got in (parts, whole):
+        ref = torch.softmax(q[1].float() @ k[1].float().T * C ** -0.5, -1) @ v[1].float()
+        close(got[1], ref.to(BF), max_rel=1.5e-2, mae_rel=3e-3)
 
 
 @pytest.mark.parametrize("M,N,K,batch", [(300, 520, 128, 1), (1015, 1015, 256, 2), (256, 264, 64, 1)])

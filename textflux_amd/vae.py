@@ -186,8 +186,9 @@ class AutoencoderKL:
         in registers); token counts are padded to a multiple of 64 with zero weights / zero v^T columns so that the P v
         product takes the MFMA kernel for any h * w.  Query rows are independent, so the score matrix is never materialised as a
         whole: one image at a time, `rows` query rows at a time through ONE reused [rows, Np] score / weight buffer pair whose size
-        does not grow with the image (round 4 held the full [N, N]: 1.5 GiB at 1024 x 1024, 6 GiB at 2048 x 1024) -- same
-        arithmetic per row, bit-identical to the unchunked form (tests/test_vae_kernels_gpu.py)."""
+        does not grow with the image (round 4 held the full [N, N]: 1.5 GiB at 1024 x 1024, 6 GiB at 2048 x 1024).  Scores and
+        softmax weights of a row do not depend on the chunking (bit-identical); the P v sum over the keys is K-sliced according to the
+        chunk's tile count, so two chunk sizes agree to the last bf16 ulp, not bit for bit (tests/test_vae_kernels_gpu.py)."""
         B, N, C = q.shape
         Np = (N + 63) // 64 * 64
         vt = torch.zeros(B, C, Np, dtype=torch.bfloat16, device=q.device) if Np != N else torch.empty(B, C, N, dtype=torch.bfloat16, device=q.device)
@@ -198,13 +199,17 @@ class AutoencoderKL:
             self._scores = (torch.empty(rows, Np, dtype=torch.float32, device=q.device),
                             torch.zeros(rows, Np, dtype=torch.bfloat16, device=q.device))
         s, pw = self._scores
+        # the P v product of one chunk has rows / 256 x C / 256 tiles (16 at rows = 2048, C = 512) for 256 CUs and K = Np: it runs K-sliced
+        # through the GEMM's split-K scratch (fp32 partials, fixed order: deterministic for a given image size)
+        if getattr(self, "_pv_ws", None) is None or self._pv_ws.device != q.device:
+            self._pv_ws = torch.empty(64 << 20, dtype=torch.uint8, device=q.device)
         o = torch.empty(B, N, C, dtype=torch.bfloat16, device=q.device)
         for b in range(B):
             for r0 in range(0, N, rows):
                 n = min(rows, N - r0)
                 ops.gemm_f32(q[b, r0:r0 + n], k[b], out=s[:n, :N])
                 ops.row_softmax(s[:n, :N], C ** -0.5, pw[:n])
-                ops.gemm(pw[:n], vt[b], None, out=o[b, r0:r0 + n])
+                ops.gemm(pw[:n], vt[b], None, out=o[b, r0:r0 + n], workspace=self._pv_ws)
         return o
 
     def _mid(self, x, p):
