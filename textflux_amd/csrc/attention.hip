@@ -11,6 +11,7 @@
 // K and V tiles are staged global -> registers -> LDS (issue early / write late), double buffered, one barrier
 // per tile.  K rows (256 B) have their 16-byte chunks XOR-swizzled with (key & 15); V rows have their 64-byte
 // segments XOR-swizzled with (key & 3); both make the respective LDS reads bank-conflict free.
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -773,11 +774,11 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
 static int g_attn_bound = 1;   // 0: ignore AttnArgs::score_bound (A/B knob, tfx_set_option attention_use_bound)
 void set_attention_use_bound(int v) { g_attn_bound = v; }
 // which kernel form the launches took (tfx_attention_mode_counts): host counters, bumped at launch (and at graph capture)
-static int64_t g_attn_mode_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static std::atomic<int64_t> g_attn_mode_count[8];   // zero-initialised (static storage); launches may come from several host threads
 int attention_mode_counts(int64_t* counts, int n, int reset) {
   n = n < 0 ? 0 : n > 8 ? 8 : n;
-  for (int i = 0; i < n; ++i) counts[i] = g_attn_mode_count[i];
-  if (reset) for (int i = 0; i < 8; ++i) g_attn_mode_count[i] = 0;
+  for (int i = 0; i < n; ++i) counts[i] = g_attn_mode_count[i].load(std::memory_order_relaxed);
+  if (reset) for (int i = 0; i < 8; ++i) g_attn_mode_count[i].store(0, std::memory_order_relaxed);
   return n;
 }
 // The reference-free stream (attn_w4_kernel<4>) is admissible when nothing can leave the exponent range fp32 and bf16 share without any
