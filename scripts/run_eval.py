@@ -167,6 +167,7 @@ def main(argv=None, lora: bool = False, script: str = __file__):
     print(f"[rank {rank}] {len(res['done'])} images written" + (f"; {len(res['all_done'])}/{len(items)} in total, "
           f"{res['batches']} batches in {res['rounds']} rounds, prompts encoded {res['encode']}" if rank == 0 else ""))
     if rank == 0:
+        print("[rank 0] process group: " + json.dumps(tdist.group_info()))
         print("All tasks processed.")
     tdist.shutdown()
 

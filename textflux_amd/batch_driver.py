@@ -215,9 +215,11 @@ def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], bat
             err0, meta = e, [-1, 0, 0, 0]
     else:
         meta = [0, 0, 0, 0]
-    if world > 1:
+    grouped = dist.is_initialized()      # also at world size 1 under a launcher: a 1-GPU torchrun job runs the code of the 8-GPU job
+    if grouped:
         mt = torch.tensor(meta, dtype=torch.int64, device=device)
         dist.broadcast(mt, src=0)
+        tdist._ran("broadcast")
         meta = [int(v) for v in mt.tolist()]
     if meta[0] < 0:
         raise RuntimeError(f"rank 0 could not encode the prompt template: {err0}" if rank == 0 else
@@ -226,8 +228,9 @@ def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], bat
     dtype = {0: torch.bfloat16, 1: torch.float32, 2: torch.float16}[dcode]
     if rank != 0:
         pooled1 = torch.empty(1, P, dtype=dtype, device=device)
-    if world > 1:
+    if grouped:
         dist.broadcast(pooled1, src=0)
+        tdist._ran("broadcast")
     done: List[int] = []
     for r in range(rounds):
         mine = plan[r * world + rank] if r * world + rank < len(plan) else None
@@ -293,11 +296,12 @@ def run_items(items: Sequence[Dict[str, Any]], pipe, out_dir: Optional[str], bat
             print(f"[rank {rank}] batch of {n} at {mine.size} failed: {e}")
     # ---- summary on rank 0
     res: Dict[str, Any] = {"done": done, "failed": failed, "batches": len(plan), "rounds": rounds, "encode": encode}
-    if world > 1:
+    if grouped:
         cnt = torch.zeros(len(items) + 1, dtype=torch.int32, device=device)
         for i in done:
             cnt[i] = 1
         dist.all_reduce(cnt)
+        tdist._ran("all_reduce")
         res["all_done"] = [i for i in range(len(items)) if int(cnt[i]) > 0]
         tdist.barrier()
     else:
