@@ -218,8 +218,9 @@ typedef struct tfx_dit_desc {
   void* gemm_workspace; int64_t gemm_workspace_bytes;   /* optional, passed to every block Linear (tfx_gemm_args.workspace) */
   /* optional: the rotary table as (cos, sin) pairs, fp32 [N, 64, 2] (cos_tab / sin_tab hold every value twice: pair i =
    * columns 2i, 2i + 1).  When set, the q | k | v (| mlp) projections with at least as many 256 x 256 tiles as the device
-   * has CUs apply the per-head RMSNorm + RoPE in their GEMM epilogue (bf16 mode); the others -- and every projection when
-   * this is NULL -- are followed by tfx_rmsnorm_rope as a separate pass.  Same rounding points either way. */
+   * has CUs apply the per-head RMSNorm + RoPE in their GEMM epilogue (bf16 mode, and since round 5 the fp8 mode of flags bit 2);
+   * the others -- and every projection when this is NULL -- are followed by tfx_rmsnorm_rope as a separate pass.  Same rounding
+   * points either way. */
   const float* rope_cs;
   /* optional: the flow-matching Euler update fused into proj_out's epilogue (scheduling_flow_match_euler_discrete.py:319-330:
    * x' = x + (sigma_next - sigma) * v).  euler_gate: bf16 [B][out_channels] rows (row stride euler_gate_bstride elements), every
@@ -397,7 +398,9 @@ int tfx_mul_act(const void* a, int64_t lda, const void* b, int64_t ldb, void* ou
  *      (+ a merge kernel; faster at small batches, but a sample's bits then depend on the batch size: default 0).
  *      "gemm_group_m": row tiles per group of the GEMM tile order (default 0 = by shape: 1 for N <= 3072, else 4).
  *      "gemm_place": slot assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip).
- *      "gemm_splitk": 0 disables the split-K path of few-tile GEMMs (default 1). */
+ *      "gemm_splitk": 0 disables the split-K path of few-tile GEMMs (default 1).
+ *      "fp8_fuse_qkn": 0 = in fp8 mode the q | k | v (| mlp) projections are followed by the separate q / k norm + RoPE pass (default 1:
+ *      fused into the e4m3 GEMM's epilogue like the bf16 mode's). */
 int tfx_set_option(const char* name, int value);
 /* The only device memory the library ever allocates itself is behind an opt-in knob: the attention tail-split partials
  * ("attention_tail_split" 1; 138 MB per (device, stream) that launched with it, at most 8).  tfx_release_scratch synchronises the

@@ -47,11 +47,11 @@ struct Gemm {
     if (a.epilogue == EPI_BIAS) { a.epilogue = EPI_BIAS_GELU; a.gelu_from_col = 1 << 30; }   // bias only: GELU never starts
     return *this;
   }
-  bool qknorm_ok(const void* wq, const void* wk, const float* cs, int pos0, int D, float eps) const {
+  bool qknorm_ok(const void* wq, const void* wk, const float* cs, int pos0, int D, float eps, bool fp8 = false) const {
     Gemm t = *this;
     t.qknorm(wq, wk, cs, pos0, D, eps);
     if (t.a.split_row > 0 && !(t.a.qkn_wq2 && t.a.qkn_wk2)) return false;
-    return gemm_qkn_ok(t.a);
+    return fp8 ? gemm_fp8_qkn_ok(t.a) : gemm_qkn_ok(t.a);
   }
   int run(hipStream_t st) const { return gemm_bf16(a, st); }
   bool fp8_ready() const { return lin->w8 && lin->w8_scale && a.K % 256 == 0; }
@@ -81,6 +81,7 @@ struct Gemm {
     if (int _e = (x)) return _e; \
   } while (0)
 
+static int g_fp8_fuse_qkn = 1;    // tfx_set_option fp8_fuse_qkn: 0 = fp8 projections followed by the separate q / k norm + RoPE pass (round 4; A/B knob)
 static int g_group_streams = 1;   // tfx_set_option gemm_group_streams: 0 = the text and image GEMMs of a double block as separate launches (A/B knob)
 
 int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
@@ -133,12 +134,14 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
   // xn (bf16) then the GEMM.  fp8 mode: the norm writes the e4m3 rows + scales straight into the q8 workspace
   // (layout [B][N][D] bytes / [B][N]) and the GEMM consumes them -- no bf16 round trip, no separate quantisation pass.
   // projection of rows [row0, row0 + rows) into y with q/k norm + RoPE: fused into the GEMM epilogue when the shape allows
-  // (bf16 mode, persistent kernel, enough tiles to fill the chip unsplit), else the GEMM followed by the separate pass
-  const bool may_fuse = d.rope_cs && !q8;
+  // (persistent kernel, enough tiles to fill the chip unsplit; since round 5 in fp8 mode too), else the GEMM followed by the separate pass
+  const bool may_fuse = d.rope_cs != nullptr;
   auto fused_here = [&](const Gemm& gm, int row0, const void* nq, const void* nk) -> bool {
     Gemm t = gm;      // with the scratch the launch will have: a GEMM the auto path K-slices cannot carry the fused epilogue
     t.scratch(d.gemm_workspace, d.gemm_workspace_bytes);
-    return may_fuse && t.qknorm_ok(nq, nk, d.rope_cs, row0, D, eps);
+    const bool f8 = q8 && gm.fp8_ready();
+    if (f8 && !g_fp8_fuse_qkn) return false;
+    return may_fuse && t.qknorm_ok(nq, nk, d.rope_cs, row0, D, eps, f8);
   };
   auto norm_gemm = [&](const uint16_t* src, int row0, int rows, const uint16_t* shift, const uint16_t* scale, Gemm gm) -> int {
     gm.scratch(d.gemm_workspace, d.gemm_workspace_bytes);
@@ -602,6 +605,7 @@ int tfx_set_option(const char* name, int value) {
   if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
   if (!std::strcmp(name, "gemm_waves")) { set_gemm_waves(value); return 0; }
   if (!std::strcmp(name, "gemm_group_streams")) { g_group_streams = value; return 0; }
+  if (!std::strcmp(name, "fp8_fuse_qkn")) { g_fp8_fuse_qkn = value; return 0; }
   if (!std::strcmp(name, "gemm_splitk")) { set_gemm_splitk(value); return 0; }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only
   return fail("tfx_set_option: unknown option '%s'", name);

@@ -1767,6 +1767,19 @@ bool gemm_qkn_ok(const GemmArgs& a) {
   return plan_slices(p, cus & ~7, p.K >> 6, a.workspace, a.workspace_bytes).sk == 1;
 }
 
+// The same question for the e4m3 path (gemm_fp8): it slices K only when the whole GEMM has fewer tiles than CUs, so the fused epilogue
+// is available exactly when it does not (a: the bf16-side description of the Linear, as tfx_dit_forward builds it).
+bool gemm_fp8_qkn_ok(const GemmArgs& a) {
+  if (a.conv_cin > 0 || (a.epilogue != EPI_BIAS_GELU && a.epilogue != EPI_BIAS) || a.split_row > 0) return false;
+  if (a.K <= 0 || a.K % 256 || a.N % 8 || (a.qkn_q0 | a.qkn_q1 | a.qkn_k0 | a.qkn_k1) % 256) return false;
+  if (a.epilogue == EPI_BIAS_GELU && (a.gelu_from_col % 256 || a.gelu_from_col < (a.qkn_q1 > a.qkn_k1 ? a.qkn_q1 : a.qkn_k1))) return false;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  const int64_t T = (int64_t)a.batch * ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  return T >= (cus & ~7);
+}
+
 // ---- fp32 output (raw accumulators, no epilogue): C [batch][M, N] floats with row stride ldc.  The score GEMM of the
 // VAE mid-block attention: q k^T must reach the softmax unrounded.  The persistent kernel in its (tile, slice) form with
 // ONE slice writes exactly that; shapes it does not take (K % 128 != 0) go to the generic kernel.
@@ -1828,7 +1841,23 @@ static int launch_fp8(const GemmParams& p, void* ws, int64_t ws_bytes, hipStream
   if (prof) prof_begin(2, 2.0 * p.M * (double)p.N * p.K * p.batch, st);
   const int T = p.batch * p.tm * p.tn, nt = p.K >> 7;   // 128-byte K-tiles of e4m3
   SlicePlan pl = T < grid ? plan_slices(p, grid, nt, ws, ws_bytes) : SlicePlan{1, 0, 0};   // fp8: whole-GEMM slicing only
-  if (pl.sk > 1) {
+  if (p.rope_cs) {   // fused q / k RMSNorm + RoPE epilogue (round 5: also in fp8 mode; gemm_fp8_qkn_ok)
+    if (pl.sk > 1 || EPI != EPI_BIAS_GELU) {
+      if (prof) prof_end(2, st);
+      return fail("gemm_fp8: the q/k norm + RoPE epilogue needs an unsliced launch with the bias(+GELU) epilogue (gemm_fp8_qkn_ok)");
+    }
+    static bool attrq = false;
+    const void* fn = (const void*)gemm8pp_kernel<EPI_BIAS_GELU, 2, true, false, true>;
+    if (!attrq) {
+      hipFuncAttributes fa;
+      (void)hipFuncGetAttributes(&fa, fn);
+      (void)hipGetLastError();
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess)
+        return fail("gemm_fp8: cannot raise dynamic LDS limit for the q/k-norm kernel");
+      attrq = true;
+    }
+    gemm8pp_kernel<EPI_BIAS_GELU, 2, true, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
+  } else if (pl.sk > 1) {
     GemmParams ps = p;
     ps.ws = (float*)ws; ps.sk = pl.sk; ps.u_full = 0; ps.tail_r = pl.tail_r;
     gemm8pp_kernel<EPI_BIAS, 2, true, true><<<grid, 512, PP_LDS_TOTAL, st>>>(ps);

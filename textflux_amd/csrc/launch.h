@@ -74,6 +74,7 @@ void set_gemm_waves(int v);      // 8 (default): gemm8pp_kernel; 4: gemm4w_kerne
 void set_gemm_splitk(int v);
 int gemm_bf16(const GemmArgs& a, hipStream_t st);            // dispatches fast MFMA kernel or generic fallback
 bool gemm_qkn_ok(const GemmArgs& a);                          // can this GEMM carry the fused q/k norm + RoPE epilogue?
+bool gemm_fp8_qkn_ok(const GemmArgs& a);   // ... for the e4m3 path (gemm_fp8): an unsliced launch, same column conditions
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
 int gemm_bf16_f32out(const GemmArgs& a, hipStream_t st);     // C = fp32 raw accumulators [batch][M, N] (ldc, c_bstride in floats)
 int gemm_fp8(const GemmArgs& a, hipStream_t st);             // persistent MFMA kernel on e4m3 operands (K % 256 == 0)
