@@ -107,42 +107,54 @@ def sample_posterior(mean: Tensor, std: Tensor, eps: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------- tiled encode / decode (enable_tiling)
-def _blend_v(a: Tensor, b: Tensor, extent: int) -> Tensor:
-    """AutoencoderKL.blend_v (autoencoder_kl.py:334-338): the top `extent` rows of b fade in from the bottom rows of a, IN PLACE on b
-    (so a tile that is blended later sees its already-blended neighbours, as in the reference)."""
-    extent = min(a.shape[2], b.shape[2], extent)
-    for y in range(extent):
-        b[:, :, y, :] = a[:, :, -extent + y, :] * (1 - y / extent) + b[:, :, y, :] * (y / extent)
+def _blend(a: Tensor, b: Tensor, extent: int, dim: int) -> Tensor:
+    """AutoencoderKL.blend_v (dim 2) / blend_h (dim 3) (autoencoder_kl.py:334-344): the first `extent` rows / columns of b fade in from
+    the last `extent` of a, IN PLACE on b (a tile that is blended later sees its already-blended neighbours, as in the reference);
+    extent is clamped to both tiles and the weights use the clamped value.  The reference walks the seam line by line with python-float
+    weights t / extent and 1 - t / extent; restated for the whole seam at once with the same arithmetic per element: the weights as
+    fp32 (what a python float becomes beside a tensor), each product rounded to the tensor dtype, then the sum."""
+    extent = min(a.shape[dim], b.shape[dim], extent)
+    if extent <= 0:
+        return b
+    t = torch.arange(extent, dtype=torch.float64) / extent
+    shape = [1, 1, 1, 1]
+    shape[dim] = extent
+    wb, wa = t.to(torch.float32).view(shape), (1.0 - t).to(torch.float32).view(shape)
+    tail, head = a.narrow(dim, a.shape[dim] - extent, extent), b.narrow(dim, 0, extent)
+    mixed = (tail.float() * wa).to(b.dtype).float() + (head.float() * wb).to(b.dtype).float()
+    head.copy_(mixed.to(b.dtype))
     return b
+
+
+def _blend_v(a: Tensor, b: Tensor, extent: int) -> Tensor:
+    return _blend(a, b, extent, 2)
 
 
 def _blend_h(a: Tensor, b: Tensor, extent: int) -> Tensor:
-    """AutoencoderKL.blend_h (autoencoder_kl.py:340-344)."""
-    extent = min(a.shape[3], b.shape[3], extent)
-    for x in range(extent):
-        b[:, :, :, x] = a[:, :, :, -extent + x] * (1 - x / extent) + b[:, :, :, x] * (x / extent)
-    return b
+    return _blend(a, b, extent, 3)
 
 
 def _tiled(x: Tensor, fn, tile: int, out_tile: int, overlap_factor: float) -> Tensor:
     """The common body of _tiled_encode / tiled_decode (autoencoder_kl.py:346-395, 456-503): tiles of `tile` every
-    int(tile * (1 - overlap)) pixels, each through `fn`, blended over int(out_tile * overlap) output pixels with the tile above
-    and the tile to the left, cropped to out_tile - blend and concatenated."""
-    step = int(tile * (1 - overlap_factor))
-    extent = int(out_tile * overlap_factor)
-    limit = out_tile - extent
-    rows = [[fn(x[:, :, i:i + tile, j:j + tile]) for j in range(0, x.shape[3], step)] for i in range(0, x.shape[2], step)]
-    result_rows = []
-    for i, row in enumerate(rows):
-        result_row = []
-        for j, t in enumerate(row):
-            if i > 0:
-                t = _blend_v(rows[i - 1][j], t, extent)
-            if j > 0:
-                t = _blend_h(row[j - 1], t, extent)
-            result_row.append(t[:, :, :limit, :limit])
-        result_rows.append(torch.cat(result_row, dim=3))
-    return torch.cat(result_rows, dim=2)
+    int(tile * (1 - overlap)) pixels, each through `fn`; then, in raster order, every tile is blended over int(out_tile * overlap)
+    output pixels with the tile above and the tile to its left (both already blended), cropped to out_tile - blend; the crops are
+    concatenated."""
+    step, extent = int(tile * (1 - overlap_factor)), int(out_tile * overlap_factor)
+    keep = out_tile - extent
+    ys, xs = range(0, x.shape[2], step), range(0, x.shape[3], step)
+    grid = {(r, c): fn(x[:, :, y0:y0 + tile, x0:x0 + tile]) for r, y0 in enumerate(ys) for c, x0 in enumerate(xs)}
+    bands = []
+    for r in range(len(ys)):
+        band = []
+        for c in range(len(xs)):
+            t = grid[r, c]
+            if r:
+                _blend(grid[r - 1, c], t, extent, 2)
+            if c:
+                _blend(grid[r, c - 1], t, extent, 3)
+            band.append(t[:, :, :keep, :keep])
+        bands.append(torch.cat(band, dim=3))
+    return torch.cat(bands, dim=2)
 
 
 def tile_sizes(cfg: VaeConfig, sample_size: int) -> Tuple[int, int]:
