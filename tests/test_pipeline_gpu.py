@@ -265,3 +265,64 @@ def test_fp8_call_matches_fp8_oracle_trajectory_and_graph_replay(golden):
     pipe.enable_hip_graph(True)
     graphed = pipe(**kw).images
     assert torch.equal(out, graphed)
+
+
+@pytest.mark.parametrize("height,width", [(32, 32), (72, 57), (128, 96)])
+def test_output_shape_follows_the_references_rounding(height, width):
+    """The reference's own behavioural test (diffusers/tests/pipelines/flux/test_pipeline_flux_fill.py:153-165): a requested size that is
+    not a multiple of vae_scale_factor * 2 = 16 is rounded DOWN -- (72, 57) -> (64, 48) -- by the image processor's resize and by
+    prepare_latents alike; the call returns images of that size."""
+    pipe = make_pipe("euler")
+    gi = torch.Generator().manual_seed(6)
+    image = (torch.randn(1, 3, 64, 64, generator=gi) * 0.3 + 0.5).clamp(0, 1)
+    mask = torch.zeros(1, 1, 64, 64)
+    mask[:, :, 16:48, 8:56] = 1.0
+    pe, pooled = torch.randn(1, 16, 64, generator=gi), torch.randn(1, 32, generator=gi)
+    out = pipe(prompt_embeds=pe.to(BF).cuda(), pooled_prompt_embeds=pooled.to(BF).cuda(), image=image, mask_image=mask, height=height,
+               width=width, num_inference_steps=2, guidance_scale=30.0, generator=torch.Generator().manual_seed(1), output_type="np").images
+    assert out.shape == (1, height - height % 16, width - width % 16, 3) and out.min() >= 0 and out.max() <= 1
+
+
+def test_batch_of_identical_inputs_equals_the_single_call():
+    """PipelineTesterMixin.test_inference_batch_single_identical (diffusers/tests/pipelines/test_pipelines_common.py:1057-1166, the
+    reference asserts max difference < 1e-3 ... 1e-4 on np images): three copies of one input in a batch, each with its own generator
+    seeded alike, give the single call's image -- here bit for bit."""
+    pipe = make_pipe("euler")
+    gi = torch.Generator().manual_seed(8)
+    H = W = 64
+    image = (torch.randn(1, 3, H, W, generator=gi) * 0.3 + 0.5).clamp(0, 1)
+    mask = torch.zeros(1, 1, H, W)
+    mask[:, :, 16:48, 8:56] = 1.0
+    pe, pooled = torch.randn(1, 16, 64, generator=gi).to(BF).cuda(), torch.randn(1, 32, generator=gi).to(BF).cuda()
+    kw = dict(height=H, width=W, num_inference_steps=3, guidance_scale=30.0, output_type="np")
+    one = pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, image=image, mask_image=mask,
+               generator=torch.Generator(device="cuda").manual_seed(3), **kw).images
+    three = pipe(prompt_embeds=pe.repeat(3, 1, 1), pooled_prompt_embeds=pooled.repeat(3, 1), image=image.repeat(3, 1, 1, 1),
+                 mask_image=mask.repeat(3, 1, 1, 1), generator=[torch.Generator(device="cuda").manual_seed(3) for _ in range(3)], **kw).images
+    assert three.shape == (3, H, W, 3)
+    for i in range(3):
+        assert (three[i] == one[0]).all()
+
+
+def test_callback_tensor_inputs_are_validated_and_delivered():
+    """PipelineTesterMixin.test_callback_inputs (test_pipelines_common.py:1721-1790): only names in _callback_tensor_inputs are accepted;
+    the callback receives exactly the requested tensors every step and may replace the latents (here: zero them at the last step)."""
+    pipe = make_pipe("euler")
+    gi = torch.Generator().manual_seed(9)
+    lat = torch.randn(1, 16, 64, generator=gi).to(BF).cuda()
+    mil = torch.randn(1, 16, 320, generator=gi).to(BF).cuda()
+    pe, pooled = torch.randn(1, 16, 64, generator=gi).to(BF).cuda(), torch.randn(1, 32, generator=gi).to(BF).cuda()
+    kw = dict(prompt_embeds=pe, pooled_prompt_embeds=pooled, latents=lat, masked_image_latents=mil, height=64, width=64,
+              num_inference_steps=3, guidance_scale=30.0, output_type="latent")
+    with pytest.raises(ValueError, match="callback_on_step_end_tensor_inputs"):
+        pipe(callback_on_step_end=lambda *a: {}, callback_on_step_end_tensor_inputs=["latents", "not_a_tensor_input"], **kw)
+    seen = []
+
+    def cb(p, i, t, k):
+        seen.append(sorted(k))
+        if i == 2:
+            return {"latents": torch.zeros_like(k["latents"])}
+        return {}
+
+    out = pipe(callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents", "prompt_embeds"], **kw).images
+    assert seen == [["latents", "prompt_embeds"]] * 3 and out.abs().sum().item() == 0
