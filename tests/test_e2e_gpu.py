@@ -154,3 +154,23 @@ def test_batch_driver_matches_single_image_calls(env, tmp_path):
         print(f"item {i}: batched vs single-image MAE {d:.3e}")
         assert d < 5e-3
     ri.PIPE = None
+
+
+def test_prompts_matter_and_prompt_embeds_equal_prompts(env):
+    """The reference's two prompt tests (diffusers/tests/pipelines/flux/test_pipeline_flux_fill.py:113-151): a different `prompt_2` gives a
+    different image (max difference > 1e-6), and passing the embeddings of `encode_prompt(prompt, prompt_2)` instead of the strings gives
+    the same image (the reference asserts < 1e-4; here the same code path runs, so bit for bit)."""
+    ri = env["ri"]
+    ri.PIPE = None
+    pipe = ri.load_flux_pipeline()
+    scene, mask = _scene(3, 128, 64)
+    kw = dict(image=scene, mask_image=mask, height=64, width=128, num_inference_steps=2, guidance_scale=30.0, output_type="np",
+              max_sequence_length=512)
+    g = lambda: torch.Generator(device="cuda").manual_seed(0)
+    same = pipe(prompt="a template", prompt_2="the words 'ALPHA'", generator=g(), **kw).images
+    other = pipe(prompt="a template", prompt_2="completely different words 'OMEGA' here", generator=g(), **kw).images
+    assert np.abs(same - other).max() > 1e-6
+    pe, pooled, _ = pipe.encode_prompt(prompt="a template", prompt_2="the words 'ALPHA'", max_sequence_length=512)
+    from_embeds = pipe(prompt_embeds=pe, pooled_prompt_embeds=pooled, generator=g(), **kw).images
+    assert np.abs(same - from_embeds).max() < 1e-4 and (same == from_embeds).all()
+    ri.PIPE = None
