@@ -173,3 +173,21 @@ def test_fp8_full_width_blocks_match_fp8_oracle(golden):
     assert max(e_enc, e_hid, e_sgl) < 3e-2
     assert e_hid < c_hid and e_sgl < c_sgl
     assert max(c_hid, c_sgl) < 6e-2
+
+
+def test_3d_ids_and_return_dict_follow_the_reference(golden):
+    """The reference's model tests (diffusers/tests/models/transformers/test_models_transformer_flux.py:87-113): `txt_ids` / `img_ids` with
+    a leading batch dimension (the deprecated 3-D form, transformer_flux.py:1100-1111 takes sample 0) give the 2-D result; and the
+    dict / tuple equivalence of PipelineTesterMixin (`return_dict=True` -> an object with `.sample`, False -> a 1-tuple)."""
+    g = golden("g3_model")
+    m = build(G3_CFG, 7)
+    inp = {k[3:]: v for k, v in g.items() if k.startswith("in.")}
+    kw = dict(hidden_states=inp["hidden_states"].to(BF).cuda(), encoder_hidden_states=inp["encoder_hidden_states"].to(BF).cuda(),
+              pooled_projections=inp["pooled_projections"].to(BF).cuda(), timestep=inp["timestep"].to(BF).cuda(),
+              guidance=inp["guidance"].cuda())
+    B = inp["hidden_states"].shape[0]
+    two_d = m.forward(img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], return_dict=False, **kw)
+    three_d = m.forward(img_ids=inp["img_ids"][None].repeat(B, 1, 1), txt_ids=inp["txt_ids"][None].repeat(B, 1, 1), return_dict=False, **kw)
+    assert isinstance(two_d, tuple) and len(two_d) == 1 and torch.equal(two_d[0], three_d[0])
+    obj = m.forward(img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], return_dict=True, **kw)
+    assert torch.equal(obj.sample, two_d[0])
