@@ -8,7 +8,9 @@ One "step" = one full pipeline call on one batch: VAE encode of the masked image
 DiT (hand-written HIP: MFMA GEMMs, flash attention, fused norms / scheduler), VAE decode.  Inputs are resident in HBM
 before the timed region.  Rank 0 prints ONE JSON line (contract in the task description), carrying
   roofline     : MFMA roofline of the dominant kernel (gemm8p), measured live with HIP events on its launch stream
-  cpu_baseline : the CPU oracle (plain PyTorch restatement, `oracle/`) timed on this box's host cores, bounded sample
+  cpu_baseline : the CPU oracle (plain PyTorch restatement, `oracle/`) timed LIVE on this box's host cores: BASELINE config 1 in full
+                 (576x512, 4 steps, fp32, 57 blocks: ~2 min in a subprocess that overlaps model init / warm-up and ends before the timed
+                 region) + a bounded block sample at the GPU workload's own token count
 """
 import argparse
 import json
@@ -166,11 +168,23 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5: e4m3 block linears on the fp8 MFMA (NOT the bf16 headline)")
     a = ap.parse_args()
     if a.cpu_baseline_c1:
-        print(json.dumps({"cpu_baseline_c1": cpu_baseline_c1()}), flush=True)
+        # (first the bounded sample of the GPU workload's own geometry -- one double + one single block at P1024's token count,
+        # extrapolated -- while the host memory is still free, then C1 proper)
+        sample = cpu_baseline(a.height, a.width, a.denoise_steps, budget_s=10.0)
+        print(json.dumps({"cpu_baseline_c1": cpu_baseline_c1(), "workload_block_sample": sample}), flush=True)
         return
 
     from textflux_amd import distributed as tdist
     tdist.respawn_under_torchrun(a.gpus, __file__, sys.argv[1:])   # bare `python bench.py --gpus N`: one rank per GPU
+    # cpu_baseline (rank 0 at N = 1 only): BASELINE.md section 3's C1 run, LIVE (round 6) -- its own process on the host cores, started
+    # here so that its ~2 minutes (47.6 GB of fp32 weights, a warm-up forward, 4 steps) overlap the model initialisation and the UNTIMED
+    # warm-up calls of this process; it is waited for BEFORE the timed region starts, so the timed calls have the host to themselves.
+    c1_proc = None
+    if int(os.environ.get("RANK", "0")) == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        import subprocess
+        c1_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-c1"], stdout=subprocess.PIPE,
+                                   stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
+        t_c1_start = time.time()
     from textflux_amd import ops
     from textflux_amd.pipeline import FluxFillPipeline
     from textflux_amd.schedulers import FlowMatchEulerDiscreteScheduler, StochasticRFOvershotDiscreteScheduler
@@ -273,6 +287,16 @@ def main():
     for _ in range(a.warmup):
         one_call()
     torch.cuda.synchronize()
+    c1_rec = None
+    if c1_proc is not None:      # the host-side baseline finishes before anything is timed
+        c1_out, _ = c1_proc.communicate()
+        try:
+            c1_json = json.loads(c1_out.strip().splitlines()[-1])
+            c1_rec = c1_json["cpu_baseline_c1"]
+            c1_rec["workload_block_sample"] = c1_json.get("workload_block_sample")
+            c1_rec["wall_s_incl_weights_and_warmup"] = time.time() - t_c1_start
+        except Exception as e:   # reported, never fatal for the GPU measurement
+            c1_rec = {"error": f"C1 subprocess: rc {c1_proc.returncode}, {type(e).__name__}: {e}"}
     tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -326,6 +350,17 @@ def main():
         timed("pt")
         t_pt, t_pil = min(timed("pt"), timed("pt")), min(timed("pil"), timed("pil"))
         pil_delta_ms = (t_pil - t_pt) * 1e3
+    # the matrix-pipe rate this board sustains at its power cap on random operands (tfx_mfma_peak_probe, LIVE: the product library's own
+    # MFMA-only kernel, ~2.5 s each): the denominator of roofline.frac_of_capped; bf16 and e4m3
+    probe = {}
+    if rank == 0:
+        gp = torch.Generator().manual_seed(5)
+        rb = torch.randn(1 << 20, generator=gp)
+        probe["bf16"] = ops.mfma_peak_probe(rb.to(torch.bfloat16).to(dev), fp8=False, seconds=2.5)
+        try:
+            probe["e4m3"] = ops.mfma_peak_probe(rb.to(torch.float8_e4m3fn).view(torch.uint8).to(dev), fp8=True, seconds=2.5)
+        except Exception as e:
+            probe["e4m3"] = {"error": f"{type(e).__name__}: {e}"}
     seen = tdist.ranks_seen(dev)   # ranks that answered an RCCL all-reduce
     # results travel to rank 0 the way the batch driver collects them (untimed here: `value` is generation throughput): a per-image
     # checksum of every rank's last call, gathered over RCCL -- rank 0 checks that every rank produced finite images
@@ -343,7 +378,7 @@ def main():
         # rocm-smi its own sustained loops): they are READ from the newest committed profile and say so -- "live": false,
         # the file, and the round it was collected in -- so that no future run can pass them off as measured by this run.
         def committed(stem):
-            for rnd in ("r05", "r04", "r03", "r02"):
+            for rnd in ("r06", "r05", "r04", "r03", "r02"):
                 fn = os.path.join(REPO, "profiles", f"{rnd}_{stem}.json")
                 if os.path.exists(fn):
                     with open(fn) as f:
@@ -367,13 +402,14 @@ def main():
                         "file": fn, "formula": mu["formula"]}
         except Exception:
             pass
+        # the rate of a kernel that does nothing but MFMAs on random data at the board's power cap: measured by THIS run (probe above)
+        pk = probe.get("e4m3" if a.fp8 else "bf16", {})
         power_peak = None
-        try:  # the rate of a kernel that does nothing but MFMAs on random bf16 data at the board's power cap (tools/power_profile.py)
-            pw, fn, rnd = committed("power")
-            if pw.get("power_capped_peak_tflops"):
-                power_peak = {"tflops": pw["power_capped_peak_tflops"], "live": False, "collected_in_round": rnd, "file": fn}
-        except Exception:
-            pass
+        if pk.get("tflops"):
+            power_peak = {"tflops": pk["tflops"], "live": True, "kernel": "tfx::mfma_probe_kernel (tfx_mfma_peak_probe): the GEMM kernels' MFMA sections on "
+                          "register-resident random N(0,1) operands, 8 waves per CU, nothing else", "seconds": pk["seconds"],
+                          "tflops_first_launch": pk["tflops_first_launch"], "launches": pk["launches"],
+                          "bf16": probe.get("bf16"), "e4m3": probe.get("e4m3")}
         rec = {
             "metric": "images/sec (whole node), 1024x1024 30-step FLUX-Fill" if (H, W, n) == (1024, 1024, 30) else
                       f"images/sec (whole node), {H}x{W} {n}-step FLUX-Fill",
@@ -399,7 +435,7 @@ def main():
             "dit_algorithmic_tflops_per_gpu": dit_flops(S) * n * B * a.steps / elapsed / 1e12 if full else None,
             "roofline": {"bound": "mfma", "kernel": "tfx::gemm8pp_kernel (persistent MFMA GEMM, all epilogues; + gemm8p_kernel for K % 128 != 0)", "achieved": achieved,
                          "peak": MFMA_PEAK_TFLOPS * (2 if a.fp8 else 1), "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_TFLOPS * (2 if a.fp8 else 1)),
-                         "power_capped_peak": None if a.fp8 else power_peak,
+                         "power_capped_peak": power_peak, "frac_of_capped": (achieved / power_peak["tflops"]) if power_peak else None,
                          "traffic": None if a.fp8 else traffic, "traffic_note": None if a.fp8 else traffic_note, "mfma_busy_pmc": None if a.fp8 else mfma_pmc, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "sample": "HIP events around every GEMM launch of one extra, untimed, eager call after the timed region (graph-replayed launches are not individually timed)",
                          "flops_per_launch": gemm_fl / max(gemm_n, 1),
@@ -418,13 +454,19 @@ def main():
         # region (GEMMs + attention, text encoders / VAE / everything else counted as time but not as FLOPs) over the bf16 dense peak
         rec["roofline"]["dit_achieved"] = rec["dit_algorithmic_tflops_per_gpu"]
         rec["roofline"]["dit_frac"] = rec["dit_algorithmic_tflops_per_gpu"] / MFMA_PEAK_TFLOPS if full and not a.fp8 else None
-        rec["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline(H, W, n)   # rank 0 at N = 1 only
-        if rec["cpu_baseline"] is not None:
-            try:   # the full BASELINE config-1 run (minutes of CPU): measured once per round by `--cpu-baseline-c1`, committed
-                c1, fn, rnd = committed("cpu_baseline_c1")
-                rec["cpu_baseline"]["c1_full_run"] = dict(c1["cpu_baseline_c1"], live=False, collected_in_round=rnd, file=fn)
-            except Exception:
-                pass
+        rec["cpu_baseline"] = None
+        if c1_rec is not None and "error" not in c1_rec:       # rank 0 at N = 1 only
+            rec["cpu_baseline"] = {
+                "value": c1_rec["images_per_sec"], "unit": "images/sec", "cores": c1_rec["threads"], "kind": "port", "live": True,
+                "sample": ("BASELINE.md section 3 / BASELINE.json config 1 (C1), run live by this bench in a host-side subprocess that finished before "
+                           f"the timed region: {c1_rec['config']}; {c1_rec['loop_s']:.1f} s for the 4-step loop ({c1_rec['s_per_step']:.1f} s / step, "
+                           f"{c1_rec['cpu_tflops']:.2f} TFLOP/s) on {c1_rec['threads']} threads (fastest of a sweep; {c1_rec['logical_cpus']} logical CPUs) after a "
+                           f"{c1_rec['warmup_forward_s']:.1f} s warm-up forward; the reference's C1 is a DIFFERENT configuration from the GPU headline "
+                           "(576x512, 4 steps, fp32, batch 1): a reported baseline, not a ratio's denominator"),
+                "c1": {k: v for k, v in c1_rec.items() if k != "workload_block_sample"},
+                "workload_block_sample": c1_rec.get("workload_block_sample")}
+        elif c1_rec is not None:
+            rec["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": None, "kind": "port", "live": True, "sample": c1_rec["error"]}
         print(json.dumps(rec), flush=True)
     tdist.shutdown()
 

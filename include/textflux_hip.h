@@ -33,7 +33,7 @@ const char* tfx_last_error(void);
  * two since ABI 6) and returns how many values there are.  A binding
  * compares them with its own view of this header BEFORE the first call that passes a struct: a library built from an older
  * header would otherwise ignore the tail fields of a grown struct silently (no reference counterpart: the reference has no FFI). */
-#define TFX_ABI_VERSION 6
+#define TFX_ABI_VERSION 7
 int tfx_abi_info(int32_t* out, int n);
 /* Writes the gcnArchName of the current device (e.g. "gfx950:sramecc+:xnack-") into buf.  Needs a GPU. */
 int tfx_query_arch(char* buf, int buflen);
@@ -414,6 +414,14 @@ int tfx_release_scratch(void);
  * returns the summed kernel time, FLOPs and launch count (kind 2: fp8 GEMM launches), then clears the records.  Not capturable into a graph. */
 int tfx_prof_enable(int on);
 int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches);
+/* Round 6 (ABI 7).  The matrix-pipe rate the BOARD sustains at its power cap, as the denominator of a roofline fraction that does not
+ * depend on which box runs the bench: one launch of a kernel that issues nothing but the GEMM kernels' own MFMA sections
+ * (v_mfma_f32_16x16x32_bf16; fp8 != 0: v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales) on fragments read ONCE from `operands`
+ * (operand_bytes >= 16 KiB of the caller's data -- random N(0, 1) values for the worst-case figure; power, and with it the clock,
+ * depends on operand entropy), one 8-wave workgroup per CU, `ktiles` (a multiple of 48) K-tiles of 64 (fp8: 32) MFMAs per wave.
+ * Writes the launch's FLOPs to *flops; the caller times it (events on `stream`) over 2-3 s: shorter runs finish inside the power
+ * controller's averaging window and report the uncapped clock.  No reference counterpart. */
+int tfx_mfma_peak_probe(const void* operands, int64_t operand_bytes, int32_t fp8, int32_t ktiles, double* flops, tfx_stream stream);
 /* Which form of the attention kernel the launches took (host-side counters, also counted at graph capture, not at replay):
  * counts[0..7] = launches since the last reset of { 0: kernel 30 with its own overflow guard, 1..3: its option-31..33 variants,
  * 4: kernel 30 reference-free (score_bound accepted), 5: attention_hp (20), 6: the 16 x 16 kernel (40), 7: any other schedule }.

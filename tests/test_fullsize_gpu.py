@@ -127,15 +127,8 @@ def test_full_model_batch_consistency_and_determinism():
         ops.set_option("gemm_splitk", 2)
         ops.set_option("gemm_group_streams", 1)
     assert torch.equal(s1, n1) and torch.equal(s2, n2)
-    # ... and the one-wave-per-SIMD GEMM kernel (gemm_waves 4: every unsliced launch, the fused q / k norm + RoPE epilogue included, where
-    # a head lies inside one wave instead of two) reproduces the whole forward to bf16 noise (its norm sums 128 squares in another order)
-    ops.set_option("gemm_waves", 4)
-    try:
-        w4 = m(hidden_states=hs, encoder_hidden_states=pe, pooled_projections=pooled, timestep=t1, guidance=g1, **kw)[0]
-    finally:
-        ops.set_option("gemm_waves", 8)
-    rel4 = ((w4.float() - o1.float()).abs().mean() / o1.float().abs().mean()).item()
-    assert torch.isfinite(w4.float()).all() and rel4 < 2e-2, rel4
+    # (round 6: the one-wave-per-SIMD GEMM kernel -- gemm_waves 4 -- lives in the bench library; its whole-forward check moved to
+    # tools/variant_tests/test_kernel_variants.py)
 
 
 def test_fused_qk_norm_rope_epilogue_matches_separate_pass():

@@ -260,3 +260,23 @@ def test_vae_tiled_encode_decode(golden):
     momb = vo.tiled_encoder(g["x"].to(bf), sdb, cfg, 32)
     assert torch.equal(torch.chunk(momb, 2, dim=1)[0], g["bf16.enc.mean"])
     assert torch.equal(vo.tiled_decoder(g["z"].to(bf), sdb, cfg, 32), g["bf16.dec.out"])
+
+
+def test_g11_first_steps_are_outputs_of_the_imported_reference_at_production_size():
+    """Round 6: tools/fulldepth_trajectory.py --check-reference loaded tests/helpers/fulldepth.py's seeded
+    weights into the IMPORTED reference FluxTransformer2DModel at 19 + 38 blocks x 3072 (bf16, 23.8 GB, build container) and ran the first
+    steps of the g11 trajectory: every noise prediction and latent torch.equal to the oracle's, and the oracle's equal to the committed
+    fixture.  The reference's own latents were stored as `ref_traj_bf16` (data only); here: they ARE the first rows of `traj_bf16`, and the
+    committed record says so (profiles/r06_reference_fullsize_pin.json).  The full-depth GPU tests compare the engine with these rows."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from tests.helpers.fulldepth import FIXTURE, REPO
+    fx = load_file(FIXTURE)
+    assert "ref_traj_bf16" in fx and fx["ref_traj_bf16"].shape[0] >= 2
+    n = fx["ref_traj_bf16"].shape[0]
+    assert torch.equal(fx["ref_traj_bf16"], fx["traj_bf16"][:n])
+    with open(os.path.join(REPO, "profiles", "r06_reference_fullsize_pin.json")) as f:
+        rec = json.load(f)
+    assert rec["bit_exact"] and len(rec["rows"]) == n
+    assert all(r["noise_pred_equal"] and r["latents_equal"] and r["oracle_equals_committed_g11"] for r in rec["rows"])

@@ -21,7 +21,7 @@ c_void_p, c_int, c_int32, c_int64, c_float, c_char_p = C.c_void_p, C.c_int, C.c_
 # TFX_ABI_VERSION of the include/textflux_hip.h the ctypes mirrors below were written against (tests/test_capi_symbols.py asserts
 # that it equals the header's): the library's stamp is compared with THIS constant, so a binding copied without include/ still
 # loads, and a ctypes mirror edited without the header (or the other way round) fails a test instead of passing the check.
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GemmArgs(C.Structure):
@@ -162,6 +162,7 @@ SIGNATURES = {
     "tfx_release_scratch": (c_int, []),
     "tfx_prof_enable": (c_int, [c_int]),
     "tfx_prof_collect": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_int)]),
+    "tfx_mfma_peak_probe": (c_int, [c_void_p, c_int64, c_int32, c_int32, C.POINTER(C.c_double), c_void_p]),
     "tfx_attention_mode_counts": (c_int, [C.POINTER(c_int64), c_int32, c_int32]),
     "tfx_debug_attention_timing": (c_int, [c_void_p]),
 }

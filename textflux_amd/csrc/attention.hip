@@ -20,10 +20,12 @@
 namespace tfx {
 
 constexpr int KVBLK = 64, HD = 128;
+#ifdef TFX_BENCH
 constexpr int K_BYTES = KVBLK * HD * 2;          // 16 KiB
 constexpr int ATT_LDS = 2 * 2 * K_BYTES;         // K,V x 2 buffers = 64 KiB
 constexpr int ATT_LDS2 = 2 * ATT_LDS;            // two 64-key sub-tiles per buffer = 128 KiB
 constexpr int ATT_LDS_PP = 5 * K_BYTES;          // ping-pong kernel: K x 2, V x 3 buffers = 80 KiB
+#endif
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ unsigned long long* g_dbg_ptr = nullptr;  // bench-only (tools/attn_timing.py)
@@ -38,6 +40,11 @@ __device__ unsigned long long* g_dbg_ptr = nullptr;  // bench-only (tools/attn_t
     __builtin_amdgcn_sched_barrier(0);                      \
   } while (0)
 
+// Round 6: the 8-wave kernels of this file (attn_kernel: exact online maximum; attn_mx_kernel: matrix-pipe softmax, the round-1 default;
+// attn_pp_kernel: ping-pong) are superseded by attn_w4_kernel (attention_w4.hip) and compiled into the BENCH library only
+// (`make bench`, -DTFX_BENCH: tools/variant_tests/ runs their sweeps there); the product library carries the dispatcher below and the
+// two attn_w4_kernel instantiations the DiT launches.
+#ifdef TFX_BENCH
 // Q and O may alias (the single-stream blocks write O over Q; a block only touches its own QBLK rows of one head).
 // SUB = 64-key sub-tiles staged per barrier (SUB = 2: 128 keys per barrier, 128 KiB LDS, half the barriers).
 // NW waves per workgroup (QBLK = 32 * NW query rows).  NW = 8: one workgroup per CU; NW = 4: two independent
@@ -499,7 +506,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_mx_kernel(const bf16_t* Q, co
 }
 
 
-#ifdef TFX_BENCH
 // -------------------------------------------------------------------------------------------------------------
 // Ping-pong variant.  Same math and data layouts as attn_kernel<8>, different schedule: the tile loop is split into
 // a VALU phase   PA(u) = request the 16 V(u) fragments into registers; online softmax of tile u (scores already in
@@ -803,17 +809,19 @@ void set_attention_waves(int nw) {
   g_attn_waves = (nw == 4 || nw == 8 || nw == 9 || nw == 10 || nw == 12 || nw == 20 || (nw >= 30 && nw <= 34) || nw == 40) ? nw : 16;
 }
 
-// The product library carries the default kernel (30: attention_w4.hip; it needs 16-byte aligned output rows and falls back to
-// 10 otherwise), its predecessor (10: matrix-pipe softmax, 8 waves x 32 rows), the textbook exact-online-maximum kernel (8: the
-// independent implementation the tests compare them with) and the half-tile pipelined kernel (20, attention_hp.hip).  The other
-// schedules tried on the way (4 / 12: two 4-wave workgroups per CU, 9: 128 keys per barrier, 16: ping-pong) and the timing
-// ablations are compiled only with -DTFX_BENCH (`make bench` -> libtextflux_hip_bench.so, used by tools/).
+// The product library carries the default kernel only (attention_w4.hip: attn_w4_kernel<4>, the reference-free stream the DiT's
+// per-block score bound selects, and attn_w4_kernel<0>, the guarded form every other call gets).  It needs 16-byte aligned output
+// rows (whole-row stores) and fails loudly otherwise -- the DiT's layouts always are.  Everything else that was tried on the way
+// (8: exact online maximum, 10: matrix-pipe softmax with 8 waves x 32 rows, 20: half-tile pipelined, 31 .. 33: other bookkeeping
+// modes of the one-wave-per-SIMD kernel, 40: the 16 x 16 x 32 kernel, 4 / 9 / 12 / 16: further schedules) and the timing ablations are
+// compiled only with -DTFX_BENCH (`make bench` -> libtextflux_hip_bench.so, used by tools/ and tools/variant_tests/).
 int joint_attention(const AttnArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.H <= 0 || a.N <= 0) return 0;
   if ((a.ldq | a.ldk | a.ldv | a.q_bstride | a.k_bstride | a.v_bstride) % 8 || (a.ldo | a.o_bstride) % 4)
     return fail("attention: strides must be multiples of 8 elements (q,k,v) / 4 (o)");
   if (((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v) % 16 || (uintptr_t)a.o % 8)
     return fail("attention: q/k/v must be 16-byte aligned, o 8-byte aligned");
+#ifdef TFX_BENCH
   if (g_attn_waves == 20 && !g_attn_abl) {   // half-tile software-pipelined kernel
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
@@ -822,6 +830,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     ++g_attn_mode_count[5];
     return rc ? rc : check_launch("joint_attention");
   }
+#endif
   // option 30: whole-row 16-byte output stores; its K / V buffer descriptors cover one head's rows with a 32-bit byte count,
   // and its pipeline requests up to three 64-key tiles past the last one: those offsets are computed in 32 bits too and must
   // stay beyond the descriptor's range (zero fill) instead of wrapping back into it
@@ -832,6 +841,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
   // 2.23 GHz where 30 sustains 1.95) -- but ~9 % more wave cycles per tile (474 instructions against 358), and inside the DiT step
   // the clock is set by the power-capped GEMMs around it (~1.7 GHz): there cycles decide and 40 measures 2 % SLOWER per forward
   // (tools/dit_ab.py attention_waves=30,40: 481.5 vs 471.1 ms).  Kept selectable, not the default.
+#ifdef TFX_BENCH
   if (g_attn_waves == 40 && w4_ok) {     // same output-store and descriptor constraints as 30
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
@@ -840,24 +850,35 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
     ++g_attn_mode_count[6];
     return rc ? rc : check_launch("joint_attention");
   }
+#endif
+#ifdef TFX_BENCH
   if (((g_attn_waves >= 30 && g_attn_waves <= 34) || g_attn_waves == 40) && w4_ok) {
+#else
+  if ((g_attn_waves == 30 || g_attn_waves == 34) && w4_ok) {
+#endif
     const bool prof = prof_on(st);
     if (prof) prof_begin(1, 4.0 * a.B * a.H * (double)a.N * a.N * HD, st);
     // 30 (the default) takes the reference-free stream (34) when the caller's score bound allows it (attn_bound_admissible above);
     // an explicit 31 .. 33 runs as named
     const bool bounded = attn_bound_admissible(a.score_bound, a.N);
+#ifdef TFX_BENCH
     const int mode = g_attn_waves == 34 ? (bounded ? 4 : 3) : g_attn_waves == 30 ? (bounded && g_attn_bound ? 4 : 0)
                    : g_attn_waves >= 31 && g_attn_waves <= 33 ? g_attn_waves - 30 : 0;
+#else
+    const int mode = bounded && (g_attn_bound || g_attn_waves == 34) ? 4 : 0;    // 30 / 34; the other bookkeeping modes are bench-only
+#endif
     const int rc = joint_attention_w4(a, st, mode);
     if (prof) prof_end(1, st);
     ++g_attn_mode_count[mode];
     return rc ? rc : check_launch("joint_attention");
   }
 #ifndef TFX_BENCH
-  if (g_attn_waves != 8 && g_attn_waves != 10 && !(g_attn_waves >= 30 && g_attn_waves <= 34) && g_attn_waves != 40)
-    return fail("attention: kernel variant %d is a bench-only schedule (build with -DTFX_BENCH)", g_attn_waves);
-  if (g_attn_abl) return fail("attention: ablations are bench-only (build with -DTFX_BENCH)");
-#endif
+  if (g_attn_waves != 30 && g_attn_waves != 34)
+    return fail("attention: kernel variant %d is a bench-only schedule (libtextflux_hip_bench.so, `make bench`)", g_attn_waves);
+  return fail("attention: output rows must be 16-byte aligned (ldo and o_bstride multiples of 8 elements) and one head's K / V rows "
+              "addressable in 32 bits; got ldo %lld, o_bstride %lld, N %d, ldk %lld, ldv %lld", (long long)a.ldo, (long long)a.o_bstride,
+              a.N, (long long)a.ldk, (long long)a.ldv);
+#else
   const int NW = (g_attn_waves == 16 || g_attn_waves == 9 || g_attn_waves == 10 || g_attn_waves >= 30) ? 8 : g_attn_waves == 12 ? 4 : g_attn_waves;
   const int qblk = NW * 32;
   static bool attr_set = false;
@@ -931,6 +952,7 @@ int joint_attention(const AttnArgs& a, hipStream_t st) {
   if (prof) prof_end(1, st);
   ++g_attn_mode_count[7];
   return check_launch("joint_attention");
+#endif  // TFX_BENCH
 }
 
 }  // namespace tfx

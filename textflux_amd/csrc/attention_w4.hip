@@ -1115,11 +1115,17 @@ int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode) {
     }
   }
   const unsigned grid = nsplit > 1 ? (unsigned)(((nfull + 7) & ~7) + nparts) : (unsigned)T;
+#ifdef TFX_BENCH
   const int rc = mode == 4 ? w4_launch<4>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
                : mode == 3 ? w4_launch<3>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
                : mode == 2 ? w4_launch<2>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
                : mode == 1 ? w4_launch<1>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
                            : w4_launch<0>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part);
+#else   // product library: the reference-free stream and the guarded form; modes 1 .. 3 are A/B builds (round 4), bench library only
+  if (mode != 4 && mode != 0) return fail("attention: attn_w4_kernel<%d> is bench-only (libtextflux_hip_bench.so)", mode);
+  const int rc = mode == 4 ? w4_launch<4>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
+                           : w4_launch<0>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part);
+#endif
   if (rc) return rc;
   if (nsplit > 1)
     attn_w4_merge_kernel<<<(unsigned)(xsplit * a.B * 32), 256, 0, st>>>(part, (bf16_t*)a.o, a.ldo, a.o_bstride, a.H, a.N, nqb,

@@ -595,6 +595,11 @@ int tfx_set_option(const char* name, int value) {
     if (value == 0) { set_attention_waves(0); return 0; }     // back to the library default and its size heuristic
     if (value != 4 && value != 8 && value != 9 && value != 10 && value != 12 && value != 16 && value != 20 && !(value >= 30 && value <= 34) && value != 40)
       return fail("tfx_set_option: attention_waves must be 4, 8, 9 (128 keys per barrier), 10 / 12 (matrix-pipe softmax, 8 / 4 waves), 16 (ping-pong), 20 (half-tile pipelined), 30 .. 34 (one wave per SIMD, 32x32x16 MFMA: 30 bookkeeping on the matrix pipe -- or no reference at all when the call carries an admissible score bound -- / 31 row sums on the VALU / 32 = 31 + lazy reference offset / 33 = 30 + lazy reference offset / 34 = no reference with a score bound, else 33) or 40 (one wave per SIMD, 16x16x32 MFMA)");
+#ifndef TFX_BENCH
+    if (value != 30 && value != 34)
+      return fail("tfx_set_option: attention_waves %d is a bench-only kernel (libtextflux_hip_bench.so, `make bench`); the product library "
+                  "carries 30 (the default) and 34", value);
+#endif
     set_attention_waves(value);
     return 0;
   }
@@ -603,7 +608,13 @@ int tfx_set_option(const char* name, int value) {
   if (!std::strcmp(name, "attention_use_bound")) { set_attention_use_bound(value); return 0; }
   if (!std::strcmp(name, "attention_persistent")) { set_attention_persistent(value); return 0; }
   if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
-  if (!std::strcmp(name, "gemm_waves")) { set_gemm_waves(value); return 0; }
+  if (!std::strcmp(name, "gemm_waves")) {
+#ifndef TFX_BENCH
+    if (value != 8 && value != 0) return fail("tfx_set_option: gemm_waves 4 (gemm4w_kernel) is bench-only (libtextflux_hip_bench.so, `make bench`)");
+#endif
+    set_gemm_waves(value);
+    return 0;
+  }
   if (!std::strcmp(name, "gemm_group_streams")) { g_group_streams = value; return 0; }
   if (!std::strcmp(name, "fp8_fuse_qkn")) { g_fp8_fuse_qkn = value; return 0; }
   if (!std::strcmp(name, "gemm_splitk")) { set_gemm_splitk(value); return 0; }
@@ -612,6 +623,10 @@ int tfx_set_option(const char* name, int value) {
 }
 
 int tfx_debug_attention_timing(void* buf) { set_attention_debug(buf); return 0; }
+
+int tfx_mfma_peak_probe(const void* operands, int64_t operand_bytes, int32_t fp8, int32_t ktiles, double* flops, tfx_stream stream) {
+  return mfma_peak_probe(operands, operand_bytes, fp8, ktiles, flops, S(stream));
+}
 
 int tfx_prof_enable(int on) { prof_enable(on); return 0; }
 int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launches) {

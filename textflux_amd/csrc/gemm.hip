@@ -37,6 +37,7 @@
 // first readers: X0_lo/W_lo 8t+15, X1_lo 8t+16, W_hi 8t+17, X0_hi 8t+19, X1_hi 8t+20 -> >= 11 slots in flight; a request
 // is waited for by its issuer (vmcnt(8): the 4 newest sections may still be in flight), then one barrier -> readable.
 // See DESIGN.md "GEMM".
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -1081,6 +1082,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
 #undef PP_TILE_W
 }
 
+#ifdef TFX_BENCH   // round 6: measured 11-14 % slower than the ping-pong kernel (profiles/r04_gemm4w_ab.json): bench library only
 // ------------------------------------------------------------------------------------------------
 // Round 4: the ONE-WAVE-PER-SIMD form of the persistent kernel (tfx_set_option gemm_waves 4).  Same
 // 256 x 256 block tile, same tile order, same accumulation order per output element (bit-identical to the other two MFMA kernels),
@@ -1400,6 +1402,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
 #undef LDS_FRAG
 #undef W4G_SUB
 }
+#endif  // TFX_BENCH (gemm4w_kernel)
 
 // Second pass of the K-sliced units: C = epi(sum_s P[s] + bias) over the tail tiles, 8 columns per thread, slices summed in order.
 // Thread i -> (tail tile i / 8192, row (i / 32) % 256, columns 8 (i % 32) .. + 8) of ws [slice][tail tile][256][256].
@@ -1470,6 +1473,81 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams p) {
     val = pack8(fv);
   }
   *reinterpret_cast<u32x4*>(p.C + b * p.c_bs + (int64_t)m * p.ldc + n) = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA-only probe (tfx_mfma_peak_probe; round 6): the matrix-pipe rate this BOARD sustains on the caller's
+// operand data at its power cap, measured by the product library under whatever clock runs the bench -- the denominator of
+// roofline.frac_of_capped.  One workgroup per CU, 8 waves as in the GEMMs (two per SIMD); every wave loads its A / B fragments ONCE
+// from the caller's buffer (random N(0, 1) bf16 / e4m3 values: power depends on operand entropy, zeros run 35 % faster) and then
+// issues nothing but the GEMM kernels' own MFMA sections on registers -- v_mfma_f32_16x16x32_bf16 (fp8: v_mfma_scale_f32_16x16x128_f8f6f4,
+// unit scales) into 8 x 4 accumulators, no dependent pair back to back, accumulators restarted from a zero C operand every 48 K-tiles
+// like a K = 3072 tile -- no LDS, no global traffic, no barrier.  FLOPs per wave and K-tile: 64 MFMAs x 16384 (fp8: 32 x 65536).
+template <bool FP8>
+__global__ __launch_bounds__(512) void mfma_probe_kernel(const u32x4* __restrict__ src, int nfrag, int ktiles, float* sink) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  bf16x8 xf[4][2], wlo[2][2], whi[2][2];
+  // 16 fragments per lane, different for every lane / wave / workgroup (mod the buffer)
+  unsigned f0 = ((unsigned)blockIdx.x * 8u + (unsigned)wave) * 64u * 16u + (unsigned)lane;
+  auto ld = [&](int i) { return __builtin_bit_cast(bf16x8, src[(f0 + (unsigned)i * 64u) % (unsigned)nfrag]); };
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) xf[i][s] = ld(i * 2 + s);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { wlo[j][s] = ld(8 + j * 2 + s); whi[j][s] = ld(12 + j * 2 + s); }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define PROBE_SECTION(WF, MIB, NJB, Z)                      \
+  do {                                                     \
+    mfma_section<FP8, false, 0, Z>(acc, WF, xf, MIB, NJB); \
+    TFX_PIN_SECTION(MIB, NJB);                             \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+  for (int t = 0; t < ktiles; t += 48) {
+    // (the fragments are loop invariants, the two row halves share them, and an MFMA from a zero C operand is a pure function of its
+    // operands: without the opaque copies the compiler computes the first K-tile's products once and copies them in)
+#define PROBE_OPAQUE()                                                                      \
+  do {                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(xf[i][0]));        \
+  } while (0)
+    PROBE_OPAQUE(); PROBE_SECTION(wlo, 0, 0, true);
+    PROBE_OPAQUE(); PROBE_SECTION(whi, 0, 2, true);
+    PROBE_OPAQUE(); PROBE_SECTION(whi, 4, 2, true);
+    PROBE_OPAQUE(); PROBE_SECTION(wlo, 4, 0, true);
+#undef PROBE_OPAQUE
+    for (int u = 1; u < 48; ++u) {
+      PROBE_SECTION(wlo, 0, 0, false); PROBE_SECTION(whi, 0, 2, false); PROBE_SECTION(whi, 4, 2, false); PROBE_SECTION(wlo, 4, 0, false);
+    }
+  }
+#undef PROBE_SECTION
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (r == 123456.789f) sink[0] = r;     // keeps the accumulators live; (practically) never taken
+}
+
+int mfma_peak_probe(const void* operands, int64_t operand_bytes, int fp8, int ktiles, double* flops, hipStream_t st) {
+  if (!operands || (uintptr_t)operands % 16 || operand_bytes < 16 * 64 * 16) return fail("mfma_peak_probe: operands must be a 16-byte aligned buffer of at least 16 KiB");
+  if (ktiles < 48 || ktiles % 48) return fail("mfma_peak_probe: ktiles must be a positive multiple of 48");
+  int dev = 0, cus = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  static float* sink = nullptr;      // 4 bytes, never written in practice (the kernel needs a live side effect)
+  if (!sink && hipMalloc((void**)&sink, 256) != hipSuccess) return fail("mfma_peak_probe: hipMalloc failed");
+  const int nfrag = (int)std::min<int64_t>(operand_bytes / 16, 1 << 30);
+  if (fp8) mfma_probe_kernel<true><<<cus, 512, 0, st>>>((const u32x4*)operands, nfrag, ktiles, sink);
+  else mfma_probe_kernel<false><<<cus, 512, 0, st>>>((const u32x4*)operands, nfrag, ktiles, sink);
+  if (flops) *flops = (double)cus * 8.0 * (double)ktiles * (fp8 ? 32.0 * 65536.0 : 64.0 * 16384.0);
+  return check_launch("mfma_peak_probe");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1624,6 +1702,7 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
     const int nt = p.K >> 6;
     const SlicePlan pl = variant == 1 ? plan_slices(p, grid, nt, ws, ws_bytes) : SlicePlan{1, 0, 0};
     const int sk = pl.sk;
+#ifdef TFX_BENCH
     if (g_gemm_waves == 4 && sk == 1 && p.K >= 256) {   // one wave per SIMD (tfx_set_option gemm_waves 4): every unsliced bf16 launch
       if (p.rope_cs && EPI != EPI_BIAS_GELU) return fail("gemm: the q/k norm + RoPE epilogue rides on the bias(+GELU) epilogue");
       static bool attr4[2] = {false, false};
@@ -1639,7 +1718,9 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
       }
       if (qi) gemm4w_kernel<EPI_BIAS_GELU, true><<<grid, 256, W4G_LDS_TOTAL, st>>>(p);
       else gemm4w_kernel<EPI, false><<<grid, 256, W4G_LDS_TOTAL, st>>>(p);
-    } else if (p.rope_cs) {   // fused q / k RMSNorm + RoPE epilogue: EPI_BIAS_GELU instantiation only (plain bias = gelu_from >= N)
+    } else
+#endif
+    if (p.rope_cs) {   // fused q / k RMSNorm + RoPE epilogue: EPI_BIAS_GELU instantiation only (plain bias = gelu_from >= N)
       if (sk > 1) return fail("gemm: the q/k norm + RoPE epilogue cannot ride on a K-sliced launch (gemm_qkn_ok)");
       if (EPI != EPI_BIAS_GELU) return fail("gemm: the q/k norm + RoPE epilogue rides on the bias(+GELU) epilogue");
       static bool attrq = false;

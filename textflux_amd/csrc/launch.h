@@ -77,6 +77,7 @@ bool gemm_qkn_ok(const GemmArgs& a);                          // can this GEMM c
 bool gemm_fp8_qkn_ok(const GemmArgs& a);   // ... for the e4m3 path (gemm_fp8): an unsliced launch, same column conditions
 int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st);  // 0 = generic, 1 = MFMA 8-phase
 int gemm_bf16_f32out(const GemmArgs& a, hipStream_t st);     // C = fp32 raw accumulators [batch][M, N] (ldc, c_bstride in floats)
+int mfma_peak_probe(const void* operands, int64_t operand_bytes, int fp8, int ktiles, double* flops, hipStream_t st);   // tfx_mfma_peak_probe
 int gemm_fp8(const GemmArgs& a, hipStream_t st);             // persistent MFMA kernel on e4m3 operands (K % 256 == 0)
 // per-row absmax quantisation bf16 -> e4m3: out = x / scale, scale = absmax / 448 (1 for an all-zero row)
 // LayerNorm + modulation whose output is written as the e4m3 quantisation of the bf16 row (fp8 mode; == ln_modulate followed

@@ -309,6 +309,35 @@ def prof_collect(kind: int):
     return ms.value, fl.value, n.value
 
 
+def mfma_peak_probe(operands: torch.Tensor, fp8: bool = False, seconds: float = 2.5) -> dict:
+    """tfx_mfma_peak_probe timed over ~`seconds` with HIP events on the current stream: the rate of an MFMA-only kernel on `operands`
+    (bf16, or uint8 holding e4m3 codes) at the board's power cap -- TFLOP/s of the LAST launch of a back-to-back series (the first ones run
+    inside the power controller's averaging window at the uncapped clock)."""
+    _chk_dev(operands)
+    nbytes = operands.numel() * operands.element_size()
+    st = _stream()
+    fl = C.c_double()
+
+    def launch(ktiles):
+        L.check(L.lib().tfx_mfma_peak_probe(operands.data_ptr(), nbytes, 1 if fp8 else 0, ktiles, C.byref(fl), st), "mfma_peak_probe")
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record(); launch(48 * 64); ev[1].record(); torch.cuda.synchronize()
+    per_ktile_ms = ev[0].elapsed_time(ev[1]) / (48 * 64)
+    kt = max(48, int(250.0 / max(per_ktile_ms, 1e-6)) // 48 * 48)          # ~0.25 s per launch
+    n = max(3, int(seconds / 0.25))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    evs[0].record()
+    for i in range(n):
+        launch(kt)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+    tf = [fl.value / (m * 1e-3) / 1e12 for m in ms]
+    return {"tflops": tf[-1], "tflops_first_launch": tf[0], "tflops_min": min(tf), "launches": n, "seconds": sum(ms) * 1e-3,
+            "dtype": "e4m3" if fp8 else "bf16", "flops_per_launch": fl.value}
+
+
 ATTENTION_MODES = ("w4_guarded", "w4_valu_rowsum", "w4_lazy_valu", "w4_lazy", "w4_reference_free", "hp", "w16", "other")
 
 

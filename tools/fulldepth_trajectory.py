@@ -8,6 +8,9 @@ Two halves, because the oracle needs no GPU and costs ~an hour of host CPU while
     python tools/fulldepth_trajectory.py --oracle [--fp32]      # CPU (the build container): writes tests/golden/g11_fulldepth_c2_oracle.safetensors
     python tools/fulldepth_trajectory.py --engine               # GPU box: same seeded weights, engine trajectory, comparison
                                                                 # -> gpurun_out/r04_fulldepth_trajectory.json (copied to profiles/)
+    python tools/fulldepth_trajectory.py --check-reference      # CPU (the build container ONLY: imports /root/reference): the imported
+                                                                # FluxTransformer2DModel at 19 + 38 x 3072 in bf16 on the same weights,
+                                                                # torch.equal against the oracle, reference latents stored in g11
 
 Weights: seeded on the CPU generator (identical on every host), every layer its own draw, the distribution of
 oracle/flux_oracle.seeded_state_dict (non-zero biases, non-unit norm scales), rounded to bf16 -- both halves regenerate them.
@@ -56,6 +59,89 @@ def run_oracle(fp32: bool, threads: int):
             out["traj_fp32"] = torch.stack([r[0] for r in ref]).float().contiguous()
             print(f"[oracle] fp32 trajectory {time.time() - t0:.0f} s", flush=True)
             save_file(out, FIXTURE)
+
+
+def run_check_reference(threads: int, steps: int, out_path: str):
+    """pin the oracle AT PRODUCTION SIZE against the reference itself.  The imported reference
+    FluxTransformer2DModel (D/models/transformers/transformer_flux.py:1028-1212) with all 19 + 38 blocks at width 3072, bf16 (23.8 GB),
+    takes seeded_weights() by strict load_state_dict and runs the first `steps` steps of g11's trajectory through the oracle's denoise
+    loop (its scheduler arithmetic is pinned bit-exactly by G4 / G5); the oracle's own transformer_forward runs the same steps.  Asserted:
+    every noise prediction and every latent torch.equal, and the oracle's result == the committed g11 traj_bf16 rows.  The reference's
+    latents go into the fixture as `ref_traj_bf16` (data only)."""
+    sys.path.insert(0, "/root/reference/diffusers/src")
+    sys.dont_write_bytecode = True
+    import transformers.utils as tu
+    tu.FLAX_WEIGHTS_NAME = "flax_model.msgpack"   # removed in transformers 5.x; the reference imports it (tests/golden/make_goldens.py)
+    import diffusers
+    from diffusers.models.transformers.transformer_flux import FluxTransformer2DModel as RefModel
+    from safetensors.torch import load_file, save_file
+    from oracle import flux_oracle as fo
+    from oracle import pipeline_oracle as po
+    assert diffusers.__version__ == "0.32.0.dev0" and diffusers.__file__.startswith("/root/reference/")
+    torch.set_num_threads(threads)
+    torch.set_grad_enabled(False)
+    t0 = time.time()
+    cfg, sd = seeded_weights()
+    with torch.device("meta"):
+        m = RefModel(patch_size=cfg.patch_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels, num_layers=cfg.num_layers,
+                     num_single_layers=cfg.num_single_layers, attention_head_dim=cfg.attention_head_dim,
+                     num_attention_heads=cfg.num_attention_heads, joint_attention_dim=cfg.joint_attention_dim,
+                     pooled_projection_dim=cfg.pooled_projection_dim, guidance_embeds=cfg.guidance_embeds, axes_dims_rope=cfg.axes_dims_rope)
+    assert list(m.state_dict().keys()) == list(sd.keys()), "oracle key order != reference key order"
+    m.load_state_dict(sd, strict=True, assign=True)     # the reference's parameters ARE the fixture's bf16 tensors (no second 23.8 GB copy)
+    m.eval()
+    nparam = sum(p.numel() for p in m.parameters())
+    assert all(p.dtype == BF and p.device.type == "cpu" for p in m.parameters()) and nparam == sum(v.numel() for v in sd.values())
+    print(f"[check-reference] reference model: {nparam / 1e9:.2f} B bf16 parameters, {cfg.num_layers}+{cfg.num_single_layers} blocks, "
+          f"width {cfg.num_attention_heads * cfg.attention_head_dim}, {time.time() - t0:.0f} s", flush=True)
+    lat, mil, pe, pooled = inputs()
+    preds = {"ref": [], "oracle": []}
+
+    def ref_fn(**kw):
+        out = m(hidden_states=kw["hidden_states"], encoder_hidden_states=kw["encoder_hidden_states"], pooled_projections=kw["pooled_projections"],
+                timestep=kw["timestep"], img_ids=kw["img_ids"], txt_ids=kw["txt_ids"], guidance=kw["guidance"], return_dict=False)[0]
+        preds["ref"].append(out)
+        return out
+
+    def oracle_fn(**kw):
+        out = fo.transformer_forward(sd, cfg, **kw)
+        preds["oracle"].append(out)
+        return out
+
+    t0 = time.time()
+    _, traj_ref = po.denoise(sd, cfg, lat, mil, pe, pooled, H // 16, W // 16, N_SCHED, 30.0, model_fn=ref_fn, max_steps=steps)
+    t_ref = time.time() - t0
+    print(f"[check-reference] reference: {steps} steps in {t_ref:.0f} s", flush=True)
+    t0 = time.time()
+    _, traj_or = po.denoise(sd, cfg, lat, mil, pe, pooled, H // 16, W // 16, N_SCHED, 30.0, model_fn=oracle_fn, max_steps=steps)
+    t_or = time.time() - t0
+    print(f"[check-reference] oracle: {steps} steps in {t_or:.0f} s", flush=True)
+    fx = load_file(FIXTURE)
+    rows = []
+    for i in range(steps):
+        row = {"step": i + 1,
+               "noise_pred_equal": bool(torch.equal(preds["ref"][i], preds["oracle"][i])),
+               "latents_equal": bool(torch.equal(traj_ref[i], traj_or[i])),
+               "oracle_equals_committed_g11": bool(torch.equal(traj_or[i][0].to(BF), fx["traj_bf16"][i])),
+               "noise_pred_max_abs_diff": (preds["ref"][i].float() - preds["oracle"][i].float()).abs().max().item(),
+               "noise_pred_abs_mean": preds["ref"][i].float().abs().mean().item()}
+        rows.append(row)
+        print(row, flush=True)
+    ok = all(r["noise_pred_equal"] and r["latents_equal"] and r["oracle_equals_committed_g11"] for r in rows)
+    rec = {"what": "the imported reference FluxTransformer2DModel (diffusers 0.32.0.dev0 under /root/reference) at PRODUCTION size -- 19 + 38 "
+                   "blocks, width 3072, 11.9 B bf16 parameters = tests/helpers/fulldepth.py::seeded_weights() by strict load_state_dict -- run "
+                   "on the build container's CPU over the first steps of the g11 trajectory (SL512, batch 1, guidance 30, 30-step Euler "
+                   "schedule), next to oracle.flux_oracle.transformer_forward on the same inputs: torch.equal on every noise prediction and "
+                   "every latent, and the oracle's latents equal the committed g11 fixture",
+           "bit_exact": ok, "rows": rows, "seconds_reference": t_ref, "seconds_oracle": t_or, "threads": threads,
+           "torch": torch.__version__, "diffusers": diffusers.__version__, "tool": "tools/fulldepth_trajectory.py --check-reference"}
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(rec, f, indent=1)
+    assert ok, rows
+    fx["ref_traj_bf16"] = torch.stack([t[0] for t in traj_ref]).to(BF).contiguous()     # the REFERENCE's own latents, steps 1..`steps`
+    save_file(fx, FIXTURE)
+    print(f"[check-reference] bit-exact at 57 blocks x 3072; ref_traj_bf16 {tuple(fx['ref_traj_bf16'].shape)} stored in {FIXTURE}", flush=True)
 
 
 def run_engine(out_path):
@@ -116,10 +202,14 @@ if __name__ == "__main__":
     ap.add_argument("--oracle", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="with --oracle: also the fp32 trajectory (the reference's own bf16 noise floor)")
     ap.add_argument("--engine", action="store_true")
+    ap.add_argument("--check-reference", action="store_true", help="build container only: the imported reference at full size vs the oracle")
+    ap.add_argument("--ref-steps", type=int, default=2)
     ap.add_argument("--threads", type=int, default=max(1, (os.cpu_count() or 2) // 2))
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r04_fulldepth_trajectory.json"))
     a = ap.parse_args()
     if a.oracle:
         run_oracle(a.fp32, a.threads)
+    if a.check_reference:
+        run_check_reference(a.threads, a.ref_steps, os.path.join(REPO, "profiles", "r06_reference_fullsize_pin.json"))
     if a.engine:
         run_engine(a.out)
