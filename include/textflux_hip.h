@@ -65,6 +65,22 @@ typedef struct tfx_gemm_args {
 } tfx_gemm_args;
 int tfx_gemm_bf16(const tfx_gemm_args* args, int variant, tfx_stream stream);
 
+/* Round 6 (ABI 7).  The fused q | k | v (| mlp) projection of a FLUX block as ONE operation: tfx_gemm_bf16 (epilogue 0 or 1) whose
+ * epilogue also applies the per-head RMSNorm (weights norm_q / norm_k, bf16 [128]) and the interleaved-pair RoPE to the q and k column
+ * ranges [q0, q1) / [k0, k1) of the output (multiples of 256: whole pairs of 128-wide heads), rounding for rounding as tfx_rmsnorm_rope
+ * does it after the fact (D/models/attention_processor.py:1990-1992, 2001-2004, 2023-2037; transformer_flux.py:715-739).  rope_cs: the
+ * rotary table as fp32 (cos, sin) pairs [rows, 64, 2]; output row m of a batch sample uses table row pos0 + m.  This is the kernel
+ * tfx_dit_forward launches internally for every block projection with at least as many 256 x 256 tiles as the device has CUs; shapes it
+ * cannot take (K % 128 != 0, unaligned ranges, fewer tiles than CUs with a workspace: the K-sliced path has no such epilogue) are
+ * refused -- run tfx_gemm_bf16 + tfx_rmsnorm_rope instead. */
+typedef struct tfx_qkn_args {
+  const void* norm_q; const void* norm_k;
+  const float* rope_cs;
+  int32_t pos0, q0, q1, k0, k1;
+  float eps;
+} tfx_qkn_args;
+int tfx_gemm_bf16_qkn(const tfx_gemm_args* args, const tfx_qkn_args* qkn, tfx_stream stream);
+
 /* Same operands, C = fp32 raw accumulators [batch][M, N] (ldc / c_bstride in floats, C 16-byte aligned); bias must be
  * NULL and epilogue 0.  Used where a product must reach its consumer unrounded: the q k^T scores of the VAE mid-block
  * attention (D/models/attention_processor.py:2858-2862) on their way to tfx_row_softmax. */

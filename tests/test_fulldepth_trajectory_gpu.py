@@ -62,6 +62,13 @@ def test_teacher_forced_every_step_within_1e3(setting):
     for i in range(fd.N_SCHED):
         assert errs[i] <= max(1e-3, 1.15 * floor[i]), (i, errs[i], floor[i])
     assert sum(e <= 1e-3 for e in errs) >= 28 and max(errs[:28]) <= 1e-3, errs
+    # ... and a hard ABSOLUTE cap beside the floor-relative bound: whatever the committed floor says, no step may leave
+    # north_star's 1e-3 by more than a tenth; the floor itself cannot drift silently -- it must be the file tools/oracle_self_noise.py wrote
+    # (its copy under profiles/) and monotone enough to be that measurement (2.8e-4 at step 1, <= 1e-3 at step 30)
+    assert max(errs) <= 1.1e-3, errs
+    with open(os.path.join(fd.REPO, "profiles", "r05_oracle_self_noise_all.json")) as f:
+        assert json.load(f)["teacher_forced"] == floor
+    assert 2e-4 < floor[0] < 3.5e-4 and 8e-4 < floor[-1] <= 1e-3 and all(floor[i + 1] > 0.9 * floor[i] for i in range(fd.N_SCHED - 1))
 
 
 def test_free_running_trajectory_and_graph_equals_eager(setting):

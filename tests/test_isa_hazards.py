@@ -29,13 +29,15 @@ def isa(src, tmp_path, *flags):
 
 def test_default_attention_kernel_has_no_mfma_result_hazard(tmp_path):
     import check_mfma_hazard as ck
-    asm = isa("attention_w4.hip", tmp_path)
-    ks = [k for k in ck.check_all(asm) if "attn_w4_kernel" in k[0]]      # (the file also holds the tail-split merge kernel)
-    assert len(ks) == 5                                                  # attn_w4_kernel<0 .. 4>: every bookkeeping mode is checked
-    for name, n, n_mfma, rep in ks:
-        assert n_mfma > 250 and n > 3000, name                           # the kernel was really parsed
-        assert rep == [], (name, rep[:5])
-    assert asm.count("v_readfirstlane_b32") >= 5 * 16                    # the compiler-visible touches are in the stream
+    # product build: attn_w4_kernel<0> (guarded) and <4> (reference-free); bench build (-DTFX_BENCH, round 6): every bookkeeping mode
+    for flags, nk in (((), 2), (("-DTFX_BENCH",), 5)):
+        asm = isa("attention_w4.hip", tmp_path, *flags)
+        ks = [k for k in ck.check_all(asm) if "attn_w4_kernel" in k[0]]      # (the file also holds the tail-split merge kernel)
+        assert len(ks) == nk, (flags, [k[0] for k in ks])
+        for name, n, n_mfma, rep in ks:
+            assert n_mfma > 250 and n > 3000, name                           # the kernel was really parsed
+            assert rep == [], (name, rep[:5])
+        assert asm.count("v_readfirstlane_b32") >= nk * 16                   # the compiler-visible touches are in the stream
 
 
 def test_attention_w16_kernel_has_no_mfma_or_transcendental_result_hazard(tmp_path):
@@ -43,7 +45,7 @@ def test_attention_w16_kernel_has_no_mfma_or_transcendental_result_hazard(tmp_pa
     version ordered the exponentials / packs so that hipcc could put a pack right behind the v_exp_f32 it reads: this check found
     it before the GPU did.)"""
     import check_mfma_hazard as ck
-    asm = isa("attention_w16.hip", tmp_path)
+    asm = isa("attention_w16.hip", tmp_path, "-DTFX_BENCH")     # bench library only since round 6
     (name, n, n_mfma, rep), = ck.check_all(asm)
     assert "attn_w16_kernel" in name and n_mfma >= 4 * 136
     assert rep == [], rep[:5]
@@ -52,13 +54,13 @@ def test_attention_w16_kernel_has_no_mfma_or_transcendental_result_hazard(tmp_pa
 def test_checker_catches_a_shortened_distance(tmp_path):
     """The self-test variant reads a score from inline asm right behind its chain's last MFMA, with the touch removed."""
     import check_mfma_hazard as ck
-    asm = isa("attention_w4.hip", tmp_path, "-DW4_NO_TOUCH", "-DW4_HAZARD_SELFTEST")
+    asm = isa("attention_w4.hip", tmp_path, "-DTFX_BENCH", "-DW4_NO_TOUCH", "-DW4_HAZARD_SELFTEST")
     reps = [k[3] for k in ck.check_all(asm) if "attn_w4_kernel" in k[0]]
     assert len(reps) == 5
     for rep in reps:
         assert len(rep) >= 4 and all("mfma write" in r for r in rep), rep[:3]
     # ... and the touch alone is what makes the compiler pad: same shortened read, touch in place right behind the MFMA
-    padded = isa("attention_w4.hip", tmp_path, "-DW4_HAZARD_SELFTEST")
+    padded = isa("attention_w4.hip", tmp_path, "-DTFX_BENCH", "-DW4_HAZARD_SELFTEST")
     reps2 = [k[3] for k in ck.check_all(padded) if "attn_w4_kernel" in k[0]]
     assert len(reps2) == 5 and all(len(r) >= 4 and all("mfma write" in x for x in r) for r in reps2)   # the unprotected asm read is still flagged (the touch sits in front of the REAL reads only)
 
@@ -74,10 +76,12 @@ def test_checker_agrees_with_hipcc_on_visible_instructions(tmp_path):
     assert any(rep for _, _, _, rep in ck.check_all(stripped))
 
 
-@pytest.mark.parametrize("src", ["attention.hip", "attention_hp.hip", "gemm.hip"])
-def test_other_mfma_kernels_are_clean(src, tmp_path):
+@pytest.mark.parametrize("src,flags", [("attention.hip", ("-DTFX_BENCH",)), ("attention_hp.hip", ("-DTFX_BENCH",)), ("gemm.hip", ()),
+                                       ("gemm.hip", ("-DTFX_BENCH",)), ("textenc.hip", ())])
+def test_other_mfma_kernels_are_clean(src, flags, tmp_path):
+    """(the 8-wave attention kernels, the half-tile kernel and the 4-wave GEMM are bench-library builds since round 6)"""
     import check_mfma_hazard as ck
-    res = ck.check_all(isa(src, tmp_path))
+    res = ck.check_all(isa(src, tmp_path, *flags))
     assert res and all(rep == [] for _, _, _, rep in res), [(n, r[:2]) for n, _, _, r in res if r]
 
 

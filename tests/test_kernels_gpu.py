@@ -170,6 +170,37 @@ def test_gemm_tail_split_matches_unsplit(ops, B, M, N, K):
                 ops.set_option("gemm_splitk", 2)
 
 
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_qkn_entry_point_matches_gemm_plus_separate_norm_rope_pass(ops, gelu):
+    """tfx_gemm_bf16_qkn (round 6, ABI 7): the fused [k | v | q (| mlp)] projection -- per-head RMSNorm + RoPE of the q / k column ranges in
+    the GEMM's epilogue, the kernel tfx_dit_forward launches -- against tfx_gemm_bf16 followed by tfx_rmsnorm_rope on the same operands:
+    v (and the GELU'd mlp) columns bit-identical, q / k columns within one bf16 step of their rotation pair on all but a sliver of elements
+    (same rounding points, another fp32 summation order of the 128 squares); position offset pos0; shapes it cannot take are refused."""
+    D, M, K, pos0 = 3072, 2304 + 40, 512, 7                  # 10 row tiles (the last ragged) x 36 / 48 column tiles >= 256 CUs
+    N = 4 * D if gelu else 3 * D
+    a, w, b = rnd((M, K), 81).to(BF).cuda(), rnd((N, K), 82, 0.05).to(BF).cuda(), rnd((N,), 83).to(BF).cuda()
+    wq, wk = (1 + 0.1 * rnd((128,), 84)).to(BF).cuda(), (1 + 0.1 * rnd((128,), 85)).to(BF).cuda()
+    ang = rnd((M + pos0, 64), 86) * 3.0
+    cs = torch.stack([torch.cos(ang), torch.sin(ang)], -1).contiguous().cuda()                       # [rows, 64, 2] fp32
+    cos = torch.cos(ang).repeat_interleave(2, 1).contiguous().cuda()[pos0:]
+    sin = torch.sin(ang).repeat_interleave(2, 1).contiguous().cuda()[pos0:]
+    kw = dict(epilogue=ops.EPI_BIAS_GELU, gelu_from_col=3 * D) if gelu else dict(epilogue=ops.EPI_BIAS)
+    sep = ops.gemm(a, w, b, **kw)
+    ops.rmsnorm_rope_(sep.view(1, M, N), 2 * D, 0, 24, 0, wq, wk, wq, wk, cos, sin)
+    fused = ops.gemm_qkn(a, w, b, wq, wk, cs, (2 * D, 3 * D), (0, D), pos0=pos0, **kw)
+    assert torch.isfinite(fused.float()).all()
+    assert torch.equal(fused[:, D:2 * D], sep[:, D:2 * D]) and torch.equal(fused[:, 3 * D:], sep[:, 3 * D:])
+    for lo in (0, 2 * D):
+        x, y = sep[:, lo:lo + D].float(), fused[:, lo:lo + D].float()
+        diff = (x - y).abs()
+        pair = (x.view(M, -1, 2) ** 2).sum(-1).sqrt().repeat_interleave(2, dim=-1)
+        assert (diff <= 2 ** -6 * pair + 1e-6).all(), (lo, (diff / (2 ** -6 * pair + 1e-6)).max().item())
+        assert (diff > 0).float().mean().item() < 2e-2
+    assert torch.equal(ops.gemm_qkn(a, w, b, wq, wk, cs, (2 * D, 3 * D), (0, D), pos0=pos0, **kw), fused)     # deterministic
+    with pytest.raises(RuntimeError, match="not eligible|gemm_qkn"):
+        ops.gemm_qkn(a, w, b, wq, wk, cs, (2 * D + 128, 3 * D), (0, D), pos0=pos0, **kw)              # not whole head pairs
+
+
 def test_gemm_persistent_rejects_odd_k_tiles(ops):
     a, w = rnd((512, 192), 1).to(BF).cuda(), rnd((256, 192), 2).to(BF).cuda()
     with pytest.raises(RuntimeError, match="persistent"):

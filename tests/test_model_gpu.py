@@ -191,3 +191,48 @@ def test_3d_ids_and_return_dict_follow_the_reference(golden):
     assert isinstance(two_d, tuple) and len(two_d) == 1 and torch.equal(two_d[0], three_d[0])
     obj = m.forward(img_ids=inp["img_ids"], txt_ids=inp["txt_ids"], return_dict=True, **kw)
     assert torch.equal(obj.sample, two_d[0])
+
+
+def test_fp8_fused_qk_norm_rope_epilogue_matches_the_separate_pass():
+    """the e4m3 projections carry the fused q / k RMSNorm + RoPE epilogue since round 5 (`fp8_fuse_qkn`, default 1); the
+    header claims "same rounding points either way" (dequantise, bias, bf16 round, RMSNorm, RoPE).  A/B on one double and one single block
+    at the production width and a token count at which the launches are eligible (>= one tile per CU): the k columns -- normalised and
+    rotated, not overwritten by attention -- agree to one bf16 step of their rotation pair on all but a sliver of elements (another fp32
+    summation order of the 128 squares), the v columns bit for bit, and the knob really switches paths."""
+    from textflux_amd import ops
+    from textflux_amd.transformer import FluxTransformer2DModel
+    D = 3072
+    m = FluxTransformer2DModel(in_channels=384, out_channels=64, num_layers=1, num_single_layers=1,
+                               guidance_embeds=True).init_random_(seed=9, device="cuda").enable_fp8()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    B, S, T = 2, 4096, 512
+    temb = torch.randn(B, D, generator=g, device="cuda").to(BF)
+    hid0 = torch.randn(B, S + T, D, generator=g, device="cuda").to(BF)
+    ids = torch.zeros(S, 3)
+    ids[:, 1] = torch.arange(S) // 64
+    ids[:, 2] = torch.arange(S) % 64
+    ses = m.session(B, S, T)
+    ses.set_conditioning(torch.zeros(B, T, 4096, dtype=BF, device="cuda"), torch.zeros(T, 3), ids)
+    assert ses.desc.rope_cs is not None
+    mod = m.modulation(temb)
+    ks, vs = {}, {}
+    try:
+        for fused in (1, 0):
+            ops.set_option("fp8_fuse_qkn", fused)
+            for blk in (0, 1):
+                ses.hid.copy_(hid0)
+                ses.run(mod, first_block=blk, last_block=blk + 1, flags=3 | 4)
+                ks[(fused, blk)] = ses.y[:, :, :D].clone()
+                vs[(fused, blk)] = ses.y[:, :, D:2 * D].clone()
+    finally:
+        ops.set_option("fp8_fuse_qkn", 1)
+    for blk in (0, 1):
+        assert torch.equal(vs[(1, blk)], vs[(0, blk)])
+        a, b = ks[(0, blk)].float(), ks[(1, blk)].float()
+        assert torch.isfinite(b).all()
+        diff = (a - b).abs()
+        pair = (a.view(*a.shape[:-1], -1, 2) ** 2).sum(-1).sqrt().repeat_interleave(2, dim=-1)
+        assert (diff <= 2 ** -6 * pair + 1e-6).all(), (blk, (diff / (2 ** -6 * pair + 1e-6)).max().item())
+        frac = (diff > 0).float().mean().item()
+        print(f"fp8 block {blk}: fused vs separate q/k norm + RoPE: {frac:.2e} of the k elements differ, all within one bf16 step of their pair")
+        assert 0 < frac < 2e-2          # > 0: the knob switched paths (the separate pass sums the squares in another order)

@@ -38,6 +38,11 @@ class GemmArgs(C.Structure):
     ]
 
 
+class QknArgs(C.Structure):
+    _fields_ = [("norm_q", c_void_p), ("norm_k", c_void_p), ("rope_cs", c_void_p), ("pos0", c_int32), ("q0", c_int32), ("q1", c_int32),
+                ("k0", c_int32), ("k1", c_int32), ("eps", c_float)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p),
@@ -94,6 +99,7 @@ SIGNATURES = {
     "tfx_abi_info": (c_int, [C.POINTER(c_int32), c_int]),
     "tfx_query_arch": (c_int, [c_char_p, c_int]),
     "tfx_gemm_bf16": (c_int, [C.POINTER(GemmArgs), c_int, c_void_p]),
+    "tfx_gemm_bf16_qkn": (c_int, [C.POINTER(GemmArgs), C.POINTER(QknArgs), c_void_p]),
     "tfx_gemm_bf16_f32": (c_int, [C.POINTER(GemmArgs), c_void_p]),
     "tfx_gemm_fp8": (c_int, [C.POINTER(GemmArgs), c_void_p, c_int64, c_void_p, c_void_p]),
     "tfx_ln_modulate_fp8": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p,

@@ -312,6 +312,28 @@ int tfx_gemm_bf16(const tfx_gemm_args* g, int variant, tfx_stream stream) {
   return variant < 0 ? gemm_bf16(a, S(stream)) : gemm_bf16_variant(a, variant, S(stream));
 }
 
+int tfx_gemm_bf16_qkn(const tfx_gemm_args* g, const tfx_qkn_args* q, tfx_stream stream) {
+  if (!g || !q) return fail("tfx_gemm_bf16_qkn: null args");
+  if (!g->A || !g->W || !g->C) return fail("tfx_gemm_bf16_qkn: null matrix pointer");
+  if (!q->norm_q || !q->norm_k || !q->rope_cs) return fail("tfx_gemm_bf16_qkn: norm weights and the rotary table are required");
+  if ((uintptr_t)q->norm_q % 16 || (uintptr_t)q->norm_k % 16 || (uintptr_t)q->rope_cs % 16)
+    return fail("tfx_gemm_bf16_qkn: norm weights and the rotary table must be 16-byte aligned");
+  if (q->q0 < 0 || q->q1 < q->q0 || q->q1 > g->N || q->k0 < 0 || q->k1 < q->k0 || q->k1 > g->N || q->pos0 < 0)
+    return fail("tfx_gemm_bf16_qkn: column ranges outside [0, N)");
+  GemmArgs a;
+  a.A = g->A; a.lda = g->lda; a.a_bstride = g->a_bstride;
+  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias;
+  a.C = g->C; a.ldc = g->ldc; a.c_bstride = g->c_bstride;
+  a.M = g->M; a.N = g->N; a.K = g->K; a.batch = g->batch;
+  a.epilogue = g->epilogue; a.gelu_from_col = g->epilogue == EPI_BIAS_GELU ? g->gelu_from_col : 0;
+  a.gate = nullptr; a.gate_bstride = 0; a.res = nullptr; a.ldr = 0; a.r_bstride = 0;
+  a.workspace = g->workspace; a.workspace_bytes = g->workspace_bytes;
+  a.qkn_wq = q->norm_q; a.qkn_wk = q->norm_k; a.qkn_rope_cs = q->rope_cs; a.qkn_pos0 = q->pos0;
+  a.qkn_q0 = q->q0; a.qkn_q1 = q->q1; a.qkn_k0 = q->k0; a.qkn_k1 = q->k1; a.qkn_eps = q->eps;
+  if (a.epilogue != EPI_BIAS && a.epilogue != EPI_BIAS_GELU) return fail("tfx_gemm_bf16_qkn: epilogue must be 0 (bias) or 1 (bias + GELU from a column)");
+  return gemm_bf16(a, S(stream));     // refuses shapes the fused epilogue cannot take (gemm_qkn_ok)
+}
+
 int tfx_gemm_bf16_f32(const tfx_gemm_args* g, tfx_stream stream) {
   if (!g) return fail("tfx_gemm_bf16_f32: null args");
   if (!g->A || !g->W || !g->C) return fail("tfx_gemm_bf16_f32: null matrix pointer");

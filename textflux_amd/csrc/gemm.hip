@@ -1933,8 +1933,10 @@ static int launch_fp8(const GemmParams& p, void* ws, int64_t ws_bytes, hipStream
       hipFuncAttributes fa;
       (void)hipFuncGetAttributes(&fa, fn);
       (void)hipGetLastError();
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess)
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess) {
+        if (prof) prof_end(2, st);
         return fail("gemm_fp8: cannot raise dynamic LDS limit for the q/k-norm kernel");
+      }
       attrq = true;
     }
     gemm8pp_kernel<EPI_BIAS_GELU, 2, true, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
@@ -1967,6 +1969,13 @@ int gemm_fp8(const GemmArgs& a, hipStream_t st) {
   if (a.epilogue == EPI_BIAS_GATE_RES && !(a.gate && a.gate_bstride % 4 == 0 && (uintptr_t)a.gate % 8 == 0))
     return fail("gemm_fp8: gate pointer / alignment");
   if (a.epilogue == EPI_BIAS_GELU && a.gelu_from_col % 256) return fail("gemm_fp8: gelu_from_col must be a multiple of 256");
+  // the fused q / k norm + RoPE epilogue: every condition of gemm_fp8_qkn_ok is re-checked HERE -- a public caller
+  // that sets rope_cs with unaligned column ranges, a GELU range overlapping q / k, row-split weights or null norm weights would
+  // otherwise reach the kernel and fault on the device
+  if (a.qkn_rope_cs) {
+    if (!a.qkn_wq || !a.qkn_wk) return fail("gemm_fp8: the fused q/k norm + RoPE epilogue needs both norm weight vectors");
+    if (!gemm_fp8_qkn_ok(a)) return fail("gemm_fp8: shape / column ranges not eligible for the fused q/k norm + RoPE epilogue (gemm_fp8_qkn_ok)");
+  }
   const GemmParams p = make_params(a);
   switch (a.epilogue) {
     case EPI_BIAS: return launch_fp8<EPI_BIAS>(p, a.workspace, a.workspace_bytes, st);

@@ -74,6 +74,36 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_qkn(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], norm_q: torch.Tensor, norm_k: torch.Tensor,
+             rope_cs: torch.Tensor, q_range, k_range, out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS,
+             gelu_from_col: int = 0, pos0: int = 0, eps: float = 1e-6, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """tfx_gemm_bf16_qkn: the fused [k | v | q (| mlp)] projection of a FLUX block with the per-head RMSNorm + RoPE of the q / k column
+    ranges applied in the GEMM's epilogue (what tfx_dit_forward launches).  rope_cs: fp32 [rows, 64, 2] (cos, sin) pairs."""
+    _chk_dev(a, w, bias, out, norm_q, norm_k, rope_cs, workspace)
+    assert a.dtype == BF16 and w.dtype == BF16 and w.dim() == 2 and w.stride(1) == 1
+    assert norm_q.dtype == norm_k.dtype == BF16 and norm_q.numel() == norm_k.numel() == 128 and rope_cs.dtype == torch.float32 and rope_cs.is_contiguous()
+    ap, lda, abs_, M, batch = _rows_view(a)
+    N, K = w.shape
+    assert a.shape[-1] == K and rope_cs.shape[-2:] == (64, 2) and rope_cs.shape[0] >= pos0 + M
+    if out is None:
+        out = torch.empty(*a.shape[:-1], N, dtype=BF16, device=a.device)
+    cp, ldc, cbs, M2, b2 = _rows_view(out)
+    assert (M2, b2) == (M, batch) and out.shape[-1] == N
+    g = L.GemmArgs()
+    g.A, g.lda, g.a_bstride = ap, lda, abs_
+    g.W, g.ldw, g.bias = w.data_ptr(), w.stride(0), _p(bias)
+    g.C, g.ldc, g.c_bstride = cp, ldc, cbs
+    g.M, g.N, g.K, g.batch = M, N, K, batch
+    g.epilogue, g.gelu_from_col = epilogue, gelu_from_col
+    if workspace is not None:
+        g.workspace, g.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    q = L.QknArgs()
+    q.norm_q, q.norm_k, q.rope_cs = norm_q.data_ptr(), norm_k.data_ptr(), rope_cs.data_ptr()
+    q.pos0, q.q0, q.q1, q.k0, q.k1, q.eps = pos0, q_range[0], q_range[1], k_range[0], k_range[1], eps
+    L.check(L.lib().tfx_gemm_bf16_qkn(C.byref(g), C.byref(q), _stream()), "gemm_qkn")
+    return out
+
+
 def quantize_rows_fp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
     """Per-row absmax quantisation bf16 -> e4m3 bytes: returns (q uint8 [.., rows, K], scale f32 [.., rows]) with
     x ~= q * scale[..., None];  x [rows, K] or [B, rows, K] (row/batch strided views allowed)."""
