@@ -16,6 +16,9 @@ def pytest_collection_modifyitems(config, items):
     import torch
 
     if torch.cuda.is_available():
+        # the GPU box has 256 logical CPUs: torch's default (one thread per logical CPU) makes the CPU oracle several times SLOWER than ~one
+        # thread per 8 (bench.py's sweep finds 32 fastest there); the oracle-backed tests were 400 s of the suite's 600 (round 5)
+        torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // 4)))
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:

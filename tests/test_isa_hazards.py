@@ -144,4 +144,10 @@ def test_persistent_gemm_keeps_its_k_loop_free_of_spills_and_full_drains(tmp_pat
                 continue
             assert "s_waitcnt vmcnt(0)" not in body, name
             assert "scratch_" not in body, name
+            # round 6: no COMPILER-inserted VMEM wait of any count in a K loop (the hand-placed counted waits are inline asm: ;;#ASMSTART
+            # precedes them).  Round 5's fp8 q/k-norm instantiation had three `s_waitcnt vmcnt(4)` there -- hipcc protecting spill reloads
+            # of the request offsets -- which vmcnt(0) alone did not catch
+            lines = body.split("\n")
+            own = [l.strip() for i, l in enumerate(lines) if "s_waitcnt vmcnt" in l and "ASMSTART" not in lines[i - 1]]
+            assert own == [], (name, own)
             assert len(re.findall(r"s_waitcnt vmcnt\(1[02]\)", body)) >= 4, name   # the counted waits are there

@@ -325,12 +325,15 @@ int tfx_gemm_bf16_qkn(const tfx_gemm_args* g, const tfx_qkn_args* q, tfx_stream 
   a.W = g->W; a.ldw = g->ldw; a.bias = g->bias;
   a.C = g->C; a.ldc = g->ldc; a.c_bstride = g->c_bstride;
   a.M = g->M; a.N = g->N; a.K = g->K; a.batch = g->batch;
-  a.epilogue = g->epilogue; a.gelu_from_col = g->epilogue == EPI_BIAS_GELU ? g->gelu_from_col : 0;
+  if (g->epilogue != EPI_BIAS && g->epilogue != EPI_BIAS_GELU) return fail("tfx_gemm_bf16_qkn: epilogue must be 0 (bias) or 1 (bias + GELU from a column)");
+  // the fused epilogue is an instantiation of the bias + GELU kernel (norm tiles and GELU tiles are separate straight-line paths): plain
+  // bias = GELU from a column beyond N, as tfx_dit_forward passes it
+  a.epilogue = EPI_BIAS_GELU;
+  a.gelu_from_col = g->epilogue == EPI_BIAS_GELU ? g->gelu_from_col : (g->N + 255) / 256 * 256;
   a.gate = nullptr; a.gate_bstride = 0; a.res = nullptr; a.ldr = 0; a.r_bstride = 0;
   a.workspace = g->workspace; a.workspace_bytes = g->workspace_bytes;
   a.qkn_wq = q->norm_q; a.qkn_wk = q->norm_k; a.qkn_rope_cs = q->rope_cs; a.qkn_pos0 = q->pos0;
   a.qkn_q0 = q->q0; a.qkn_q1 = q->q1; a.qkn_k0 = q->k0; a.qkn_k1 = q->k1; a.qkn_eps = q->eps;
-  if (a.epilogue != EPI_BIAS && a.epilogue != EPI_BIAS_GELU) return fail("tfx_gemm_bf16_qkn: epilogue must be 0 (bias) or 1 (bias + GELU from a column)");
   return gemm_bf16(a, S(stream));     // refuses shapes the fused epilogue cannot take (gemm_qkn_ok)
 }
 

@@ -163,6 +163,9 @@ constexpr int GSTORE_AUX = TFX_GSTORE_AUX;  // epilogue's output stores
 #define TFX_GRES_AUX 0
 #endif
 constexpr int GRES_AUX = TFX_GRES_AUX;      // epilogue's residual reads (read once)
+#ifndef TFX_FP8_HEAD
+#define TFX_FP8_HEAD 2                      // which fp8 instantiations unroll a tile's first two K-tiles (gemm8pp_kernel)
+#endif
 constexpr int LDS_X = 0;            // X_g set s at g*32768 + s*16384   (128 rows x 128 B)
 constexpr int LDS_W = 65536;        // W   set s at 65536 + s*32768     (256 rows x 128 B)
 constexpr int LDS_DUMMY = 131072;   // 8 x 1 KiB sink for out-of-range prefetches (keeps vmcnt counts uniform)
@@ -324,11 +327,17 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
   __builtin_amdgcn_sched_barrier(0);
   TFX_STAMP(1);
   float rinv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  u32x4 nw8 = u32x4{0u, 0u, 0u, 0u};     // norm weights of the 8 columns this lane stores (norm tiles)
+  u32x4 nwlo = u32x4{0u, 0u, 0u, 0u}, nwhi = u32x4{0u, 0u, 0u, 0u};   // norm weights of the 8 columns this lane stores: even / odd column of each pair, the other half zero
   if (norm_tile) {
-    nw8 = *reinterpret_cast<const u32x4*>((in_q ? p_nq : p_nk) + (wc & 1) * 64 + cchunk * 8);
-    // Linear output in bf16 (what the reference's RMSNorm sees), in place; sum of squares of this lane's 16 columns, then of
-    // the row's 64 columns in this wave (the four lanes l, l ^ 16, l ^ 32, l ^ 48 hold one row)
+    {
+      const u32x4 nw8 = *reinterpret_cast<const u32x4*>((in_q ? p_nq : p_nk) + (wc & 1) * 64 + cchunk * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { nwlo[i] = nw8[i] & 0xffffu; nwhi[i] = nw8[i] & 0xffff0000u; }
+    }
+    // Round 6: the Linear's output as PACKED bf16 pairs (what the reference's RMSNorm sees), kept in the first two registers of each
+    // accumulator quad -- one v_cvt_pk_bf16_f32 per pair, no unpack -- and the sum of squares by v_dot2c_f32_bf16 on the packed pair
+    // (p.lo^2 + p.hi^2 + ss: one instruction where round 2-5 spent two unpacks and two FMAs); then the row's 64 columns of this wave
+    // (the four lanes l, l ^ 16, l ^ 32, l ^ 48 hold one row)
     float ss[8];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
@@ -339,17 +348,19 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
         const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
                              __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
 #pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          float x0 = acc[mi][nj][e] + bs[e], x1 = acc[mi][nj][e + 1] + bs[e + 1];
-          round_bf2(x0, x1);
-          acc[mi][nj][e] = x0;
-          acc[mi][nj][e + 1] = x1;
-          ss[mi] += x0 * x0;
-          ss[mi] += x1 * x1;
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const uint32_t pk = pack_bf2(acc[mi][nj][2 * h2] + bs[2 * h2], acc[mi][nj][2 * h2 + 1] + bs[2 * h2 + 1]);
+          asm("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(ss[mi]) : "v"(pk));
+          acc[mi][nj][h2] = __uint_as_float(pk);
         }
       }
-      ss[mi] += __shfl_xor(ss[mi], 16, 64);
-      ss[mi] += __shfl_xor(ss[mi], 32, 64);
+      // lanes l ^ 16, l ^ 32 by v_permlane16_swap / v_permlane32_swap (VALU: rounds 2-5 used two ds_bpermute round trips per row block)
+      {
+        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ss[mi]), __float_as_uint(ss[mi]), false, false);
+        ss[mi] = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss[mi]), __float_as_uint(ss[mi]), false, false);
+        ss[mi] = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+      }
     }
     if (q_e == 0) {
       *reinterpret_cast<f32x4*>(stg + r16 * 32) = f32x4{ss[0], ss[1], ss[2], ss[3]};
@@ -372,13 +383,15 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
     // stores of block k: vmcnt retires in issue order, so a table load behind a store would only return after that store's
     // acknowledgement from L2 (~1 us), four times per tile.
     f32x4 csr[4][2];
+    // round 6: through a buffer descriptor that starts at this wave's first table row (rows beyond M read zeros and are never stored):
+    // one per-lane offset for the whole tile, the row block in the SCALAR offset -- no 64-bit address arithmetic per request
+    const auto rsrcT = uniform_rsrc(NORM ? p.rope_cs + (int64_t)(p.rope_pos0 + m0 + g * 128) * 128 : (const float*)p.C, NORM ? rows_ok * 512 : 0);
+    const int cs_off = crow * 512 + (wc & 1) * 256 + cchunk * 32;
     auto load_cs = [&](int blk) {
 #pragma unroll
       for (int itr = 0; itr < 4; ++itr) {
-        const int mrow = min(m0 + g * 128 + blk * 32 + itr * 8 + crow, p.M - 1);
-        const float* cs = p.rope_cs + (int64_t)(p.rope_pos0 + mrow) * 128 + (wc & 1) * 64 + cchunk * 8;
-        csr[itr][0] = *reinterpret_cast<const f32x4*>(cs);
-        csr[itr][1] = *reinterpret_cast<const f32x4*>(cs + 4);
+        csr[itr][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcT, cs_off, (blk * 32 + itr * 8) * 512, 0));
+        csr[itr][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcT, cs_off + 16, (blk * 32 + itr * 8) * 512, 0));
       }
     };
     if (NORM) load_cs(0);
@@ -394,9 +407,13 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
           const float bs[4] = {__uint_as_float(br[0] << 16), __uint_as_float(br[0] & 0xffff0000u),
                                __uint_as_float(br[1] << 16), __uint_as_float(br[1] & 0xffff0000u)};
           float v[4];
-          if (NORM) {      // already bias-added and bf16-rounded by the pre-pass; normalised + rotated after the transpose
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][e];
+          if (NORM) {      // the pre-pass left the bias-added, bf16-rounded pairs packed in acc[mi][nj][0..1]: x * (1 / rms) here, where the
+                           // row's factor is lane-local (round 6; rounds 2-5 shuffled it to the transposed rows), rounded by the pack below
+            const uint32_t p0 = __float_as_uint(acc[mi][nj][0]), p1 = __float_as_uint(acc[mi][nj][1]);
+            v[0] = __uint_as_float(p0 << 16) * rinv[mi];
+            v[1] = __uint_as_float(p0 & 0xffff0000u) * rinv[mi];
+            v[2] = __uint_as_float(p1 << 16) * rinv[mi];
+            v[3] = __uint_as_float(p1 & 0xffff0000u) * rinv[mi];
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[mi][nj][e] + bs[e];
@@ -432,22 +449,20 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
         const int row = itr * 8 + crow;
         u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((cchunk ^ ((row >> 1) & 7)) << 4));
         if (NORM) {
-          // this lane now holds 8 consecutive columns (4 rotation pairs) of row `row`: its 1/rms sits in every lane whose l & 15 is
-          // that row's index in its 16-row block, its (cos, sin) pairs are 32 contiguous bytes of the table
-          const float rr_row = __shfl(rinv[blk * 2 + (itr >> 1)], row & 15, 64);
+          // this lane now holds 8 consecutive columns (4 rotation pairs) of row `row`, normalised and rounded: a * weight is the EXACT fp32
+          // product of two bf16 values -- v_dot2_f32_bf16 against the weight pair with its other half zeroed does unpack + multiply in one
+          // instruction --, rounded (the reference's second rounding point, normalization.py:543), then the rotation with the row's
+          // (cos, sin) pairs, 32 contiguous bytes of the table, rounded once
           const f32x4 c0 = csr[itr][0], c1 = csr[itr][1];
-          float x[8], wv[8], y[8], o8[8];
-          unpack8(val, x);
-          unpack8(nw8, wv);
+          float y[8], o8[8];
 #pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            float a0 = x[e] * rr_row, a1 = x[e + 1] * rr_row;
+          for (int i = 0; i < 4; ++i) {
+            float a0, a1;
+            asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a0) : "v"(val[i]), "v"(nwlo[i]));
+            asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a1) : "v"(val[i]), "v"(nwhi[i]));
             round_bf2(a0, a1);
-            a0 *= wv[e];
-            a1 *= wv[e + 1];
-            round_bf2(a0, a1);
-            y[e] = a0;
-            y[e + 1] = a1;
+            y[2 * i] = a0;
+            y[2 * i + 1] = a1;
           }
           o8[0] = y[0] * c0[0] + (-y[1]) * c0[1];  o8[1] = y[1] * c0[0] + y[0] * c0[1];
           o8[2] = y[2] * c0[2] + (-y[3]) * c0[3];  o8[3] = y[3] * c0[2] + y[2] * c0[3];
@@ -1002,8 +1017,13 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     // a zero C operand instead of zeroed accumulators.
     int u0 = 0;
     const int nt = cur.nt;
-    // (not in the fp8 gated-residual instantiation: there the two extra loop bodies tip hipcc's allocation into spills)
-    if (nt >= 4 && !(FP8 && EPI == EPI_BIAS_GATE_RES)) {
+    // (not in the fp8 gated-residual instantiation: there the two extra loop bodies tip hipcc's allocation into spills.  Round 6: nor in
+    // the fp8 q / k-norm instantiation -- round 5 added it with the two bodies and hipcc spilled the request offsets, reloaded them in
+    // front of the K loop and then protected the reloaded registers INSIDE the loop with its own s_waitcnt vmcnt(4): three near-drains of
+    // the operand prefetch per two K-tiles in the kernel that carries 47 % of an fp8 forward's GEMM FLOPs; tests/test_isa_hazards.py now
+    // rejects ANY compiler-inserted vmcnt wait in a K loop.  TFX_FP8_HEAD: A/B builds, 1 = round 5's rule, 0 = no fp8 kernel has the bodies)
+    constexpr bool kHead = !FP8 || (TFX_FP8_HEAD == 1 ? EPI != EPI_BIAS_GATE_RES : TFX_FP8_HEAD == 2 ? (EPI != EPI_BIAS_GATE_RES && !QKN) : false);
+    if (nt >= 4 && kHead) {
       PP_TILE_W(0, cx, cw, 2, 0, 0, 0, true);
       PP_TILE_W(1, cx, cw, 3, 0, 0, 1, false);
       u0 = 2;
