@@ -65,6 +65,7 @@ constexpr float W4_THR = 4.0f;                 // lazy-reference threshold (log2
 constexpr float W4_BIG = 64.0f;                // MODE 2: a row's reference stays 0 while its scores stay inside +-W4_BIG
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
 template <int V>
 using IC = std::integral_constant<int, V>;
 }  // namespace
@@ -73,7 +74,7 @@ constexpr int ATT_LDS_W4 = W4_NBUF * (W4_VT + W4_KT);   // 99 KiB
 
 #define W4_GAP() __builtin_amdgcn_sched_barrier(0)
 #ifndef W4_ABL
-#define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier, 64 no staging writes (requests kept), 128 no staging requests (writes kept), 256 requests as LDS-DMA into a scratch region (use with 64), 512 V fragments by one ds_read_b128 (a transposed V tile)
+#define W4_ABL 0   // timing ablations (wrong results): 1 no exp / pack, 2 no fragment reloads, 4 no staging, 8 no row maximum / branch, 16 no barrier, 64 no staging writes (requests kept), 128 no staging requests (writes kept), 256 requests as LDS-DMA into a scratch region (use with 64), 512 V fragments by one ds_read_b128 (a transposed V tile), 1024 the Q-side RMSNorm + RoPE in the Q prologue (what moving it out of the projection GEMM would cost here)
 #endif
 // wait until every issued MFMA has written its result (there is no counter for the matrix pipe): 24 x 16 idle issue slots,
 // used twice per workgroup (before the first softmax, before the output)
@@ -283,6 +284,44 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   };
   __builtin_amdgcn_sched_barrier(0);
   auto convert_q = [&]() __attribute__((always_inline)) {
+    if constexpr (W4_ABL & 1024) {
+      // timing ablation (round 6): what the Q-side per-head RMSNorm + RoPE would cost HERE, in the Q prologue,
+      // if the projection GEMM's epilogue left q un-normalised -- the real instruction mix on the real registers (sum of squares by
+      // v_dot2c on the packed pairs, the two halves of a row meeting by v_permlane32_swap, x / rms -> bf16 -> * weight by v_dot2 -> bf16 ->
+      // rotation -> bf16, then the existing pre-scale), with opaque stand-ins for the weight / table VALUES: the 32 float4 table loads per
+      // lane and item are NOT issued, so the price measured is a lower bound
+      float cc = scale_log2e, sn = scale_log2e * 0.5f;
+      uint32_t wlo = 0x3f80u, whi = 0x3f800000u;
+      asm volatile("" : "+v"(cc), "+v"(sn), "+v"(wlo), "+v"(whi));
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const u32x4 pk = __builtin_bit_cast(u32x4, qf[qb][s]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, pk[i]), __builtin_bit_cast(bf2_t, pk[i]), ss, false);
+        }
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+        const float rinv = rsqrtf((__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * (1.0f / 128.0f) + 1e-6f);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          u32x4 pk = __builtin_bit_cast(u32x4, qf[qb][s]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t a = pack_bf2(__uint_as_float(pk[i] << 16) * rinv, __uint_as_float(pk[i] & 0xffff0000u) * rinv);
+            float y0, y1;
+            y0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, wlo), 0.0f, false);
+            y1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, a), __builtin_bit_cast(bf2_t, whi), 0.0f, false);
+            const uint32_t yp = pack_bf2(y0, y1);
+            y0 = __uint_as_float(yp << 16);
+            y1 = __uint_as_float(yp & 0xffff0000u);
+            pk[i] = pack_bf2(y0 * cc + (-y1) * sn, y1 * cc + y0 * sn);
+          }
+          qf[qb][s] = __builtin_bit_cast(bf16x8, pk);
+        }
+      }
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
