@@ -141,9 +141,9 @@ def test_fused_qk_norm_rope_epilogue_matches_separate_pass(B, S):
     from textflux_amd.transformer import FluxTransformer2DModel
     m = FluxTransformer2DModel(in_channels=384, out_channels=64, num_layers=1, num_single_layers=1,
                                guidance_embeds=True).init_random_(seed=9, device="cuda")
-    # (1, 1152) = BASELINE config 2's geometry (576 x 512, batch 1): the single block's [k | v | q | mlp] projection has 588 tiles, its
-    # last round is K-sliced -- round 6: the fused epilogue rides on that launch too (the sliced tiles are mlp columns), through the
-    # <.., SPLIT, QKN> instantiation of the kernel; the double block's 252-tile projection is sliced as a whole and keeps the separate pass
+    # (1, 1152) = BASELINE config 2's geometry (576 x 512, batch 1): the double block's joint 252-tile projection runs unsliced WITH the
+    # fused epilogue (fewer tiles than CUs but no admissible slicing), the single block's 588-tile projection has a K-sliced last round
+    # and keeps the separate pass
     g = torch.Generator(device="cuda").manual_seed(4)
     T = 512
     hs = torch.randn(B, S, 384, generator=g, device="cuda").to(BF)

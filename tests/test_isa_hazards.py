@@ -131,9 +131,7 @@ def test_persistent_gemm_keeps_its_k_loop_free_of_spills_and_full_drains(tmp_pat
     for name, text in ks.items():
         fp8 = re.search(r"gemm8pp_kernelILi\dELi\dELb1", name) is not None
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", asm[asm.index(".amdhsa_kernel " + name):]).group(1))
-        # (round 6: the K-sliced q / k-norm instantiation of the batch-1 geometries -- <1, 2, false, true, true> -- spills a dozen registers
-        # at its tile boundaries; its K loop is held to the same standard as every other below)
-        if not fp8 and "ILi1ELi2ELb0ELb1ELb1" not in name:
+        if not fp8:
             assert scratch == 0, (name, scratch)
         loops = [m.start() for m in re.finditer(r"Inner Loop Header", text)]
         assert loops, name

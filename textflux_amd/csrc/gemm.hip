@@ -1026,8 +1026,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     // front of the K loop and then protected the reloaded registers INSIDE the loop with its own s_waitcnt vmcnt(4): three near-drains of
     // the operand prefetch per two K-tiles in the kernel that carries 47 % of an fp8 forward's GEMM FLOPs; tests/test_isa_hazards.py now
     // rejects ANY compiler-inserted vmcnt wait in a K loop.  TFX_FP8_HEAD: A/B builds, 1 = round 5's rule, 0 = no fp8 kernel has the bodies)
-    // (... nor, for the same reason, in the K-sliced q / k-norm instantiation of the batch-1 geometries)
-    constexpr bool kHead = (SPLIT && QKN) ? false : !FP8 || (TFX_FP8_HEAD == 1 ? EPI != EPI_BIAS_GATE_RES : TFX_FP8_HEAD == 2 ? (EPI != EPI_BIAS_GATE_RES && !QKN) : false);
+    constexpr bool kHead = !FP8 || (TFX_FP8_HEAD == 1 ? EPI != EPI_BIAS_GATE_RES : TFX_FP8_HEAD == 2 ? (EPI != EPI_BIAS_GATE_RES && !QKN) : false);
     if (nt >= 4 && kHead) {
       PP_TILE_W(0, cx, cw, 2, 0, 0, 0, true);
       PP_TILE_W(1, cx, cw, 3, 0, 0, 1, false);
@@ -1672,24 +1671,6 @@ static SlicePlan plan_slices(const GemmParams& p, int grid, int nt, void* ws, in
   return pl;
 }
 
-// Round 6: the fused q / k norm + RoPE epilogue may ride on a launch whose LAST round is K-sliced (batch-1 geometries: 588 tiles = 512
-// whole + 76 x 3 slices at 576 x 512) as long as no sliced tile lies in the q / k column ranges -- tail_reduce_kernel has no such epilogue.
-// The sliced tiles are the last tail_r of every sample's tile order, i.e. the highest column tiles of the last row group: in the
-// [k | v | q | mlp] layout those are mlp columns.  (Whole-GEMM slicing, u_full == 0, never qualifies.)
-static bool tail_outside_qk(const GemmParams& p, const SlicePlan& pl) {
-  if (pl.sk == 1) return true;
-  if (pl.u_full == 0) return false;
-  const int per_batch = p.tm * p.tn;
-  for (int idx0 = per_batch - pl.tail_r; idx0 < per_batch; ++idx0) {
-    int idx = idx0;
-    const int grp = idx / (p.gm * p.tn), first_m = grp * p.gm, gsz = std::min(p.gm, p.tm - first_m);
-    idx -= grp * p.gm * p.tn;
-    const int n0 = (idx / gsz) * 256;
-    if ((n0 >= p.nq0 && n0 < p.nq1) || (n0 >= p.nk0 && n0 < p.nk1)) return false;
-  }
-  return true;
-}
-
 #ifdef TFX_BENCH
 template <int ABL>
 static int launch_ablation(const GemmParams& p, hipStream_t st) {
@@ -1764,26 +1745,22 @@ static int launch_variant(const GemmParams& p, int variant, void* ws, int64_t ws
     } else
 #endif
     if (p.rope_cs) {   // fused q / k RMSNorm + RoPE epilogue: EPI_BIAS_GELU instantiation only (plain bias = gelu_from >= N)
-      if (sk > 1 && !tail_outside_qk(p, pl)) return fail("gemm: the q/k norm + RoPE epilogue cannot ride on a launch whose K-sliced tiles hold q / k columns (gemm_qkn_ok)");
+      // (round 6 tried to let it ride on launches whose last round is K-sliced -- the batch-1 geometries, where the sliced tiles are mlp
+      // columns -- through a <.., SPLIT, QKN> instantiation: 256 VGPRs + 9-12 spilled, and 0.3 % SLOWER per 576 x 512 image than the
+      // unfused launch + the separate 12 us pass it replaces, profiles/r06_batch1_experiments.md; not kept)
+      if (sk > 1) return fail("gemm: the q/k norm + RoPE epilogue cannot ride on a K-sliced launch (gemm_qkn_ok)");
       if (EPI != EPI_BIAS_GELU) return fail("gemm: the q/k norm + RoPE epilogue rides on the bias(+GELU) epilogue");
-      static bool attrq[2] = {false, false};
-      const void* fn = sk > 1 ? (const void*)gemm8pp_kernel<EPI_BIAS_GELU, 2, false, true, true> : (const void*)gemm8pp_kernel<EPI_BIAS_GELU, 2, false, false, true>;
-      if (!attrq[sk > 1]) {
+      static bool attrq = false;
+      const void* fn = (const void*)gemm8pp_kernel<EPI_BIAS_GELU, 2, false, false, true>;
+      if (!attrq) {
         hipFuncAttributes fa;
         (void)hipFuncGetAttributes(&fa, fn);
         (void)hipGetLastError();
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_TOTAL) != hipSuccess)
           return fail("gemm: cannot raise dynamic LDS limit for the q/k-norm kernel");
-        attrq[sk > 1] = true;
+        attrq = true;
       }
-      if (sk > 1) {   // round 6: whole tiles with the fused epilogue, the last round's (mlp-column) tiles K-sliced and finished by tail_reduce_kernel
-        GemmParams ps = p;
-        ps.ws = (float*)ws; ps.sk = sk; ps.u_full = pl.u_full; ps.tail_r = pl.tail_r;
-        gemm8pp_kernel<EPI_BIAS_GELU, 2, false, true, true><<<grid, 512, PP_LDS_TOTAL, st>>>(ps);
-        tail_reduce_kernel<EPI_BIAS_GELU><<<(unsigned)(p.batch * pl.tail_r * 32), 256, 0, st>>>(ps);
-      } else {
-        gemm8pp_kernel<EPI_BIAS_GELU, 2, false, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
-      }
+      gemm8pp_kernel<EPI_BIAS_GELU, 2, false, false, true><<<grid, 512, PP_LDS_TOTAL, st>>>(p);
     } else if (sk > 1) {
       static bool attr = false;
       if (!attr) {
@@ -1894,9 +1871,8 @@ bool gemm_qkn_ok(const GemmArgs& a) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-  // ... and no K-sliced unit of the launch the auto path would make with this workspace holds q / k columns (tail_reduce_kernel has
-  // no such epilogue; round 6: a sliced last round of mlp-column tiles is fine)
-  return tail_outside_qk(p, plan_slices(p, cus & ~7, p.K >> 6, a.workspace, a.workspace_bytes));
+  // ... and no K-sliced units in the launch the auto path would make with this workspace (tail_reduce_kernel has no such epilogue)
+  return plan_slices(p, cus & ~7, p.K >> 6, a.workspace, a.workspace_bytes).sk == 1;
 }
 
 // The same question for the e4m3 path (gemm_fp8): it slices K only when the whole GEMM has fewer tiles than CUs, so the fused epilogue
