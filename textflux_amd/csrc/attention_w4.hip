@@ -300,7 +300,10 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
         for (int s = 0; s < 8; ++s) {
           const u32x4 pk = __builtin_bit_cast(u32x4, qf[qb][s]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, pk[i]), __builtin_bit_cast(bf2_t, pk[i]), ss, false);
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t pi = pk[i];
+            ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, pi), __builtin_bit_cast(bf2_t, pi), ss, false);
+          }
         }
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
         const float rinv = rsqrtf((__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * (1.0f / 128.0f) + 1e-6f);

@@ -462,8 +462,11 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float a0, a1;
-            a0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, val[i]), __builtin_bit_cast(bf16x2_t, nwlo[i]), 0.0f, false);
-            a1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, val[i]), __builtin_bit_cast(bf16x2_t, nwhi[i]), 0.0f, false);
+            // VOP3P form with a literal zero addend (the builtin lowers to v_mov 0 + v_dot2c: one instruction more per product); inline
+            // asm is fine HERE -- the consumers are ordinary VALU instructions, interlocked by the hardware.  (And a trap on the way:
+            // __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 whatever the index, hipcc 7.2.)
+            asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a0) : "v"(val[i]), "v"(nwlo[i]));
+            asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a1) : "v"(val[i]), "v"(nwhi[i]));
             round_bf2(a0, a1);
             y[2 * i] = a0;
             y[2 * i + 1] = a1;
