@@ -462,11 +462,12 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             float a0, a1;
-            // VOP3P form with a literal zero addend (the builtin lowers to v_mov 0 + v_dot2c: one instruction more per product); inline
-            // asm is fine HERE -- the consumers are ordinary VALU instructions, interlocked by the hardware.  (And a trap on the way:
-            // __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 whatever the index, hipcc 7.2.)
-            asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a0) : "v"(val[i]), "v"(nwlo[i]));
-            asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a1) : "v"(val[i]), "v"(nwhi[i]));
+            // VOP3P form with a literal zero addend (the builtin lowers to v_mov 0 + v_dot2c: one instruction more per product).  A DOT
+            // result is NOT interlocked on gfx940+: a VALU reading it needs 3 wait states (LLVM GCNHazardRecognizer, DotWriteDifferentVALURead)
+            // and hipcc pads only behind DOTs it can see -- the first version of this statement had no s_nop and the pack behind it read stale
+            // registers now and then (a forward was not deterministic).  So: both products of a pair and their wait states in ONE statement.
+            // (A second trap on the way: __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 whatever the index.)
+            asm("v_dot2_f32_bf16 %0, %2, %3, 0\n\tv_dot2_f32_bf16 %1, %2, %4, 0\n\ts_nop 2" : "=&v"(a0), "=&v"(a1) : "v"(val[i]), "v"(nwlo[i]), "v"(nwhi[i]));
             round_bf2(a0, a1);
             y[2 * i] = a0;
             y[2 * i + 1] = a1;
