@@ -101,6 +101,15 @@ def test_synthetic_listing_known_answers():
         "\ts_nop 11\n\tds_write_b32 v50, v3\n\ts_endpgm\n"
     assert ck.check(chain, "k")[3] == []
     assert len(ck.check(chain.replace("s_nop 11", "s_nop 2"), "k")[3]) == 1
+    # round 6: a DOT result needs three wait states before a VALU reads it (not interlocked on gfx940+); the same opcode may chain it as
+    # its accumulator at once.  The q / k-norm epilogue's first version had these instructions in inline asm without the s_nop: a forward
+    # was not deterministic, and nothing static noticed
+    dot = head + "\tv_dot2_f32_bf16 v14, v10, v46, 0\n\tv_dot2_f32_bf16 v15, v10, v50, 0\n\tv_cvt_pk_bf16_f32 v14, v14, v15\n\ts_endpgm\n"
+    assert len(ck.check(dot, "k")[3]) == 2
+    assert ck.check(dot.replace("\tv_cvt", "\ts_nop 2\n\tv_cvt"), "k")[3] == []
+    chain = head + "\tv_dot2c_f32_bf16_e32 v1, v2, v2\n\tv_dot2c_f32_bf16_e32 v1, v3, v3\n\ts_nop 2\n\tv_add_f32 v4, v1, v1\n\ts_endpgm\n"
+    assert ck.check(chain, "k")[3] == []
+    assert len(ck.check(chain.replace("s_nop 2", "s_nop 0"), "k")[3]) == 1
     # transcendental result -> VALU: one instruction in between
     tr = head + "\tv_exp_f32_e32 v1, v2\n\tv_cvt_pk_bf16_f32 v3, v1, v4\n\ts_endpgm\n"
     assert len(ck.check(tr, "k")[3]) == 1

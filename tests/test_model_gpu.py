@@ -227,6 +227,8 @@ def test_fp8_fused_qk_norm_rope_epilogue_matches_the_separate_pass():
     finally:
         ops.set_option("fp8_fuse_qkn", 1)
     for blk in (0, 1):
+        dv = (vs[(1, blk)].float() - vs[(0, blk)].float()).abs()
+        print(f"fp8 block {blk}: v columns fused vs separate: {int((dv > 0).sum())} of {dv.numel()} elements differ, max {dv.max().item():.3e}")
         assert torch.equal(vs[(1, blk)], vs[(0, blk)])
         a, b = ks[(0, blk)].float(), ks[(1, blk)].float()
         assert torch.isfinite(b).all()

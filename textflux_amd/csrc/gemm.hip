@@ -459,19 +459,22 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[8][4], const GemmPara
           // (cos, sin) pairs, 32 contiguous bytes of the table, rounded once
           const f32x4 c0 = csr[itr][0], c1 = csr[itr][1];
           float y[8], o8[8];
+          // The eight products of a row's eight columns in ONE statement: VOP3P form with a literal zero addend (the builtin lowers to
+          // v_mov 0 + v_dot2c: one instruction more per product).  A DOT result is NOT interlocked on gfx940+ -- a VALU reading it needs 3
+          // wait states (LLVM GCNHazardRecognizer, DotWriteDifferentVALURead) and hipcc pads only behind DOTs it can see: the first version
+          // (one statement per product, no s_nop) let the pack behind it read stale registers now and then, a forward was not
+          // deterministic; tools/check_mfma_hazard.py knows the rule since.  Eight in a row + ONE s_nop 2: only the last results are
+          // inside the window when the statement ends.  (A second trap on the way: __builtin_bit_cast applied directly to an ext-vector
+          // ELEMENT reads element 0 whatever the index, hipcc 7.2 -- hence no fdot2 builtin on val[i] here.)
+          asm("v_dot2_f32_bf16 %0, %8, %12, 0\n\tv_dot2_f32_bf16 %1, %8, %16, 0\n\t"
+              "v_dot2_f32_bf16 %2, %9, %13, 0\n\tv_dot2_f32_bf16 %3, %9, %17, 0\n\t"
+              "v_dot2_f32_bf16 %4, %10, %14, 0\n\tv_dot2_f32_bf16 %5, %10, %18, 0\n\t"
+              "v_dot2_f32_bf16 %6, %11, %15, 0\n\tv_dot2_f32_bf16 %7, %11, %19, 0\n\ts_nop 2"
+              : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(y[4]), "=&v"(y[5]), "=&v"(y[6]), "=&v"(y[7])
+              : "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(nwlo[0]), "v"(nwlo[1]), "v"(nwlo[2]), "v"(nwlo[3]),
+                "v"(nwhi[0]), "v"(nwhi[1]), "v"(nwhi[2]), "v"(nwhi[3]));
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float a0, a1;
-            // VOP3P form with a literal zero addend (the builtin lowers to v_mov 0 + v_dot2c: one instruction more per product).  A DOT
-            // result is NOT interlocked on gfx940+: a VALU reading it needs 3 wait states (LLVM GCNHazardRecognizer, DotWriteDifferentVALURead)
-            // and hipcc pads only behind DOTs it can see -- the first version of this statement had no s_nop and the pack behind it read stale
-            // registers now and then (a forward was not deterministic).  So: both products of a pair and their wait states in ONE statement.
-            // (A second trap on the way: __builtin_bit_cast applied directly to an ext-vector ELEMENT reads element 0 whatever the index.)
-            asm("v_dot2_f32_bf16 %0, %2, %3, 0\n\tv_dot2_f32_bf16 %1, %2, %4, 0\n\ts_nop 2" : "=&v"(a0), "=&v"(a1) : "v"(val[i]), "v"(nwlo[i]), "v"(nwhi[i]));
-            round_bf2(a0, a1);
-            y[2 * i] = a0;
-            y[2 * i + 1] = a1;
-          }
+          for (int i = 0; i < 4; ++i) round_bf2(y[2 * i], y[2 * i + 1]);
           o8[0] = y[0] * c0[0] + (-y[1]) * c0[1];  o8[1] = y[1] * c0[0] + y[0] * c0[1];
           o8[2] = y[2] * c0[2] + (-y[3]) * c0[3];  o8[3] = y[3] * c0[2] + y[2] * c0[3];
           o8[4] = y[4] * c1[0] + (-y[5]) * c1[1];  o8[5] = y[5] * c1[0] + y[4] * c1[1];

@@ -4,8 +4,8 @@
 On CDNA3/4 the matrix pipe's results are NOT interlocked against the vector ALU / memory pipes: after an XDL (MFMA) write
 of a VGPR tuple a VALU / VMEM / LDS instruction touching any register of that tuple needs passes + 4 wait states on gfx950
 (8-pass v_mfma_f32_32x32x16_bf16: 12; this is what LLVM's GCNHazardRecognizer pads with s_nop in front of instructions it
-KNOWS to be VALU -- checked against its own output), and a transcendental result (v_exp / v_rcp / ...) needs one
-instruction before a VALU reads it.  Instructions inside `asm` blocks are opaque to the recogniser, so a kernel that reads
+KNOWS to be VALU -- checked against its own output), a transcendental result (v_exp / v_rcp / ...) needs one
+instruction before a VALU reads it, and (round 6) a DOT result (v_dot2*_f32_bf16 ...) three wait states before a VALU reads it.  Instructions inside `asm` blocks are opaque to the recogniser, so a kernel that reads
 MFMA results from inline asm (attention_w4.hip keeps its row maxima and bf16 packs there so that they stay where the
 schedule puts them) is only correct if the DISTANCE happens to be large enough.  This script makes that a build-time
 property: it walks the kernel's control-flow graph in the compiler's assembly output and reports every non-MFMA
@@ -73,8 +73,8 @@ class Ins:
         if self.mn.startswith("s_cbranch") or self.mn == "s_branch":
             self.label_target = self.ops[-1]
         is_mfma = self.mn.startswith(("v_mfma", "v_smfmac"))
-        self.kind = "mfma" if is_mfma else "trans" if self.mn.startswith(TRANS) else "other"
-        self.dst = regs_of(self.ops[0]) if (self.ops and self.kind in ("mfma", "trans")) else set()
+        self.kind = "mfma" if is_mfma else "trans" if self.mn.startswith(TRANS) else "dot" if self.mn.startswith("v_dot") else "other"
+        self.dst = regs_of(self.ops[0]) if (self.ops and self.kind in ("mfma", "trans", "dot")) else set()
         # every vector / memory instruction that names a register may read or overwrite it; scalar instructions cannot
         touches = self.mn.startswith(("v_", "ds_", "buffer_", "global_", "flat_", "scratch_", "exp", "image_", "tbuffer_"))
         self.touch = set().union(*(regs_of(o) for o in self.ops)) if (touches and self.ops) else set()
@@ -135,6 +135,7 @@ def check(asm: str, kernel: Optional[str] = None, margin: int = 0, verbose: bool
     work = [0]
     seen[0] = True
     violations = {}
+    ins_by_line = {x.line: x for x in ins}
     while work:
         i = work.pop()
         x = ins[i]
@@ -145,6 +146,17 @@ def check(asm: str, kernel: Optional[str] = None, margin: int = 0, verbose: bool
                     rem, src, kind = st[r]
                     if kind == "trans" and (x.kind == "trans" or not x.mn.startswith("v_")):
                         continue      # TRANS -> TRANS forwards; memory instructions read the register file later
+                    if kind == "dot":
+                        # round 6.  A DOT (v_dot2*_f32_bf16 ...) result is not interlocked on gfx940+: 3 wait states before a VALU reads it
+                        # (LLVM GCNHazardRecognizer: DotWriteDifferentVALURead / DotWriteSameDotReadSrcAB = 3).  Free: the same opcode
+                        # taking it as its accumulator (SrcC: the destination of the VOP2 `c` forms, the fourth operand of the VOP3P forms)
+                        if not x.mn.startswith("v_"):
+                            continue
+                        if x.kind == "dot" and x.mn == ins_by_line[src].mn:
+                            acc_ops = x.ops[0:1] if "dot2c" in x.mn or x.mn.rstrip("_e32").endswith("c") else x.ops[3:4]
+                            other = set().union(*(regs_of(o) for k, o in enumerate(x.ops) if o not in acc_ops and k != 0)) if x.ops else set()
+                            if r not in other:
+                                continue
                     violations[(x.line, src)] = (x, r, rem, kind)
         out = {}
         for r, (rem, src, kind) in st.items():
@@ -157,6 +169,9 @@ def check(asm: str, kernel: Optional[str] = None, margin: int = 0, verbose: bool
         elif x.kind == "trans":
             for r in x.dst:
                 out[r] = (1, x.line, "trans")
+        elif x.kind == "dot":
+            for r in x.dst:
+                out[r] = (3, x.line, "dot")
         else:     # an ordinary write retires older pending entries of the same register only after it passed the check above
             pass
         for t in succ[i]:
