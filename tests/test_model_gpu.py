@@ -217,18 +217,22 @@ def test_fp8_fused_qk_norm_rope_epilogue_matches_the_separate_pass():
     mod = m.modulation(temb)
     ks, vs = {}, {}
     try:
-        for fused in (1, 0):
+        for fused in (1, 0, 1, 0):
             ops.set_option("fp8_fuse_qkn", fused)
             for blk in (0, 1):
                 ses.hid.copy_(hid0)
                 ses.run(mod, first_block=blk, last_block=blk + 1, flags=3 | 4)
-                ks[(fused, blk)] = ses.y[:, :, :D].clone()
-                vs[(fused, blk)] = ses.y[:, :, D:2 * D].clone()
+                k_, v_ = ses.y[:, :, :D].clone(), ses.y[:, :, D:2 * D].clone()
+                if (fused, blk) in ks:          # second visit of a mode: the same launches must give the same bits
+                    for name, a_, b_ in (("k", ks[(fused, blk)], k_), ("v", vs[(fused, blk)], v_)):
+                        nz = (a_ != b_).nonzero()
+                        assert nz.numel() == 0, (f"fp8_fuse_qkn={fused} block {blk}: {name} columns differ between two identical runs at", nz[:8].tolist())
+                ks[(fused, blk)], vs[(fused, blk)] = k_, v_
     finally:
         ops.set_option("fp8_fuse_qkn", 1)
     for blk in (0, 1):
-        dv = (vs[(1, blk)].float() - vs[(0, blk)].float()).abs()
-        print(f"fp8 block {blk}: v columns fused vs separate: {int((dv > 0).sum())} of {dv.numel()} elements differ, max {dv.max().item():.3e}")
+        nz = (vs[(1, blk)] != vs[(0, blk)]).nonzero()
+        print(f"fp8 block {blk}: v columns fused vs separate: {nz.shape[0]} of {vs[(1, blk)].numel()} elements differ; first at (batch, row, col) {nz[:12].tolist()}")
         assert torch.equal(vs[(1, blk)], vs[(0, blk)])
         a, b = ks[(0, blk)].float(), ks[(1, blk)].float()
         assert torch.isfinite(b).all()
