@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--layers", type=int, nargs=2, default=[19, 38], help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pil-delta", action="store_true", help="skip the untimed output_type='pil' vs 'pt' comparison")
+    ap.add_argument("--no-peak-probe", action="store_true", help="skip the live MFMA-only probes (tfx_mfma_peak_probe, ~5 s): profiler passes use it so that the probe kernels stay out of the trace")
     ap.add_argument("--no-attention-ab", action="store_true", help="skip the untimed call with the attention score bound ignored (attention_use_bound=0)")
     ap.add_argument("--cpu-baseline-c1", action="store_true", help="only run BASELINE config 1 on the host cores (minutes, ~50 GB RAM) and print it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of per-step hipGraph replay")
@@ -353,7 +354,7 @@ def main():
     # the matrix-pipe rate this board sustains at its power cap on random operands (tfx_mfma_peak_probe, LIVE: the product library's own
     # MFMA-only kernel, ~2.5 s each): the denominator of roofline.frac_of_capped; bf16 and e4m3
     probe = {}
-    if rank == 0:
+    if rank == 0 and not a.no_peak_probe:
         gp = torch.Generator().manual_seed(5)
         rb = torch.randn(1 << 20, generator=gp)
         probe["bf16"] = ops.mfma_peak_probe(rb.to(torch.bfloat16).to(dev), fp8=False, seconds=2.5)

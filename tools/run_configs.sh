@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measures the rows of profiles/r0N_configs.md (one bench.py line each) into gpurun_out/configs.jsonl
 out=gpurun_out/configs.jsonl; : > $out
-run() { timeout 600 python bench.py --no-cpu-baseline --no-attention-ab "$@" 2>&1 | grep '^{"metric"' | tail -1 >> $out; }
+run() { timeout 600 python bench.py --no-cpu-baseline --no-attention-ab --no-peak-probe "$@" 2>&1 | grep '^{"metric"' | tail -1 >> $out; }
 run --batch 1
 run --batch 1 --height 576 --width 512
 run --batch 1 --height 1184 --width 1024

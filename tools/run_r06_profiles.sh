@@ -6,11 +6,11 @@ out=gpurun_out/r06; mkdir -p $out
 # 0. the default bench line (hipGraph replay; live power-capped peak + live C1 cpu_baseline) as the driver runs it
 timeout 900 python bench.py > $out/bench.log 2>&1; grep '^{"metric"' $out/bench.log > $out/r06_bench.json
 # 1. kernel-trace summary of the default bench run (eager, so that every launch is in the trace) + its bench line
-rocprofv3 --kernel-trace --stats -d $out/trace -o r06 --output-format csv -- python bench.py --no-cpu-baseline --no-pil-delta --no-attention-ab --no-graph --steps 1 --warmup 1 > $out/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/trace -o r06 --output-format csv -- python bench.py --no-cpu-baseline --no-pil-delta --no-attention-ab --no-peak-probe --no-graph --steps 1 --warmup 1 > $out/bench_under_rocprof.log 2>&1
 grep "^{\"metric\"" $out/bench_under_rocprof.log > $out/r06_bench_under_rocprof.json
 cp $out/trace/*kernel_stats.csv $out/r06_bench_kernel_stats.csv 2>/dev/null; rm -rf $out/trace
 # 2. matrix-pipe busy over a 2-step bench
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/mfma -o r06 --output-format csv -- python bench.py --no-cpu-baseline --no-pil-delta --no-attention-ab --no-graph --steps 1 --warmup 0 --denoise-steps 2 > $out/mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/mfma -o r06 --output-format csv -- python bench.py --no-cpu-baseline --no-pil-delta --no-attention-ab --no-peak-probe --no-graph --steps 1 --warmup 0 --denoise-steps 2 > $out/mfma.log 2>&1
 python tools/pmc_bench_util.py $out/mfma/r06_counter_collection.csv $out/r06_mfma_util.json > $out/mfma_util.log 2>&1
 # 3. GEMM traffic at the three dominant shapes (separate passes)
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
