@@ -403,8 +403,28 @@ def g13_vae_tiled():
     save("g13_vae_tiled", out)
 
 
+# ----------------------------------------------------------------------------- G15 the seam blend alone
+def g15_vae_blend():
+    """AutoencoderKL.blend_v / blend_h (autoencoder_kl.py:322-344) on bf16 NCHW tiles, the extent clamped by a short tile: inputs and the
+    REFERENCE's outputs, so that tfx_blend_edge_nhwc is pinned to the reference's two bf16 tensor ops directly, not through the oracle."""
+    from diffusers import AutoencoderKL
+    vae = AutoencoderKL(in_channels=3, out_channels=3, block_out_channels=(32,), layers_per_block=1, down_block_types=("DownEncoderBlock2D",),
+                        up_block_types=("UpDecoderBlock2D",), latent_channels=4, norm_num_groups=8)
+    out = {}
+    a = rnd((2, 16, 9, 12), 1500).to(torch.bfloat16)          # NCHW: the tile above / to the left
+    b = rnd((2, 16, 5, 12), 1501).to(torch.bfloat16)          # the (shorter) tile below
+    out["v.a"], out["v.b"] = a, b
+    for ext in (8, 3):
+        out[f"v.out.{ext}"] = vae.blend_v(a.clone(), b.clone(), ext)
+    at, bt = a.transpose(2, 3).contiguous(), b.transpose(2, 3).contiguous()
+    out["h.a"], out["h.b"] = at, bt
+    for ext in (8, 1):
+        out[f"h.out.{ext}"] = vae.blend_h(at.clone(), bt.clone(), ext)
+    save("g15_vae_blend", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g9", "g13"]
-    fns = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_sched, g5=g5_pipeline, g6=g6_g7, g9=g9_vae, g13=g13_vae_tiled)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g9", "g13", "g15"]
+    fns = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_sched, g5=g5_pipeline, g6=g6_g7, g9=g9_vae, g13=g13_vae_tiled, g15=g15_vae_blend)
     for w in which:
         fns[w]()

@@ -280,3 +280,16 @@ def test_g11_first_steps_are_outputs_of_the_imported_reference_at_production_siz
         rec = json.load(f)
     assert rec["bit_exact"] and len(rec["rows"]) == n
     assert all(r["noise_pred_equal"] and r["latents_equal"] and r["oracle_equals_committed_g11"] for r in rec["rows"])
+
+
+def test_seam_blend_oracle_matches_the_references_blend_v_blend_h_bit_for_bit(golden):
+    """g15 holds AutoencoderKL.blend_v / blend_h outputs of the IMPORTED reference on bf16 tiles (extent clamped by a short
+    tile); the oracle's _blend_v / _blend_h reproduce them bit for bit.  tests/test_vae_kernels_gpu.py pins tfx_blend_edge_nhwc to the same
+    reference outputs directly."""
+    from oracle import vae_oracle as vo
+    g = golden("g15_vae_blend")
+    for ax, fn, exts in (("v", vo._blend_v, (8, 3)), ("h", vo._blend_h, (8, 1))):
+        for ext in exts:
+            b = g[f"{ax}.b"].clone()
+            fn(g[f"{ax}.a"], b, ext)
+            assert torch.equal(b, g[f"{ax}.out.{ext}"]), (ax, ext)

@@ -160,6 +160,37 @@ def test_production_vae_matches_fp32_oracle_64x64(prod_vae):
     print(f"production VAE vs fp32 oracle (64x64): rel MAE mean {r1:.2e}, std {r2:.2e}, decode {r3:.2e}")
 
 
+def test_production_vae_tiling_with_16px_edge_tiles_matches_the_tiled_oracle(prod_vae):
+    """tiling at the PRODUCTION widths (128 / 256 / 512 / 512, 32 groups) with the ragged edge tiles the FLUX geometry
+    produces when an image is a little larger than a whole number of strides -- here sample_size 64 (tiles of 64 px / 8 latent px every
+    48 / 6, seams of 16 px / 2 latent px) on a 208 x 80 image: the last tile column is 16 px wide (2 latent px), the last tile row 32 px --
+    i.e. every convolution / GroupNorm / mid-attention kernel on a 16 x 32-pixel tile, its 2 x 4-token attention included.  Against the fp32
+    tiled oracle (pinned to the imported reference's tiling by g13) at the untiled path's tolerance; the fixture's 1024-px form (a 1040-px
+    image under sample_size 1024) runs the same code with the same edge-tile shapes."""
+    from textflux_amd.vae import AutoencoderKL
+    cfg, sd, _ = prod_vae
+    vae = AutoencoderKL(sample_size=64).load_state_dict(sd, device="cuda")
+    assert (vae.tile_sample_min_size, vae.tile_latent_min_size) == (64, 8)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 3, 80, 208, generator=g).clamp(-1, 1)
+    z = torch.randn(1, 16, 10, 26, generator=g)
+    sdb = {k: v.to(BF).float() for k, v in sd.items()}
+    with torch.no_grad():
+        mom = vo.tiled_encoder(x.to(BF).float(), sdb, cfg, 64)
+        dec_ref = vo.tiled_decoder(z.to(BF).float(), sdb, cfg, 64)
+    mean = mom[:, :16]
+    vae.enable_tiling()
+    try:
+        post = vae.encode(x.to(BF).cuda()).latent_dist
+        dec = vae.decode(z.to(BF).cuda(), return_dict=False)[0]
+    finally:
+        vae.disable_tiling()
+    assert dec.shape == (1, 3, 80, 208) and post.mean.shape == (1, 16, 10, 26) and torch.isfinite(dec.float()).all()
+    r1 = _close(post.mean, mean, 5e-2, 1.5e-2)
+    r2 = _close(dec, dec_ref, 5e-2, 1.5e-2)
+    print(f"production VAE, tiled with 16-px edge tiles, vs the fp32 tiled oracle: rel MAE mean {r1:.2e}, decode {r2:.2e}")
+
+
 def test_production_vae_1024_batch8_properties(prod_vae):
     """Encoder and decoder at the bench's geometry (8 x 1024 x 1024): sample 7 duplicates sample 0 and must reproduce it bit
     for bit although it lives beyond the 2 GiB mark of every full-resolution activation; reruns are bit-identical; the

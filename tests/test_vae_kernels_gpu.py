@@ -218,6 +218,18 @@ def test_vae_tiling_matches_the_references_tiled_encode_decode(golden):
         assert torch.equal(got.cpu().permute(0, 3, 1, 2), ref), (axis, ext)
 
 
+def test_blend_edge_kernel_matches_the_references_own_blend_outputs(golden):
+    """tfx_blend_edge_nhwc against AutoencoderKL.blend_v / blend_h outputs of the IMPORTED reference (fixture g15, bf16, the
+    extent clamped by a short tile), bit for bit -- not through the oracle's restatement of the blend."""
+    from textflux_amd import ops as o
+    g = golden("g15_vae_blend")
+    for ax, axis, exts in (("v", 1, (8, 3)), ("h", 2, (8, 1))):
+        a, b = g[f"{ax}.a"].permute(0, 2, 3, 1).contiguous(), g[f"{ax}.b"].permute(0, 2, 3, 1).contiguous()      # NCHW -> NHWC
+        for ext in exts:
+            got = o.blend_edge_nhwc_(a.cuda(), b.cuda().clone(), ext, axis)
+            assert torch.equal(got.cpu().permute(0, 3, 1, 2), g[f"{ax}.out.{ext}"]), (ax, ext)
+
+
 def test_vae_rejects_configs_the_kernels_do_not_cover():
     from textflux_amd.vae import AutoencoderKL
     with pytest.raises(ValueError):
