@@ -62,6 +62,10 @@ typedef struct tfx_gemm_args {
    * auto path splits K into 2-4 slices, writes fp32 partials [slices][batch][M][N] here and finishes in a second pass
    * (deterministic: slices are summed in order).  NULL / too small = no split. */
   void* workspace; int64_t workspace_bytes;
+  /* ABI 7 (round 6): per-batch weights, W [batch][N, K] with batch stride w_bstride elements (a multiple of 8; 0 = ONE weight matrix
+   * for every batch sample, every nn.Linear).  bf16 entry points only; what the VAE mid-block attention's q k^T and P v products are
+   * (k and v^T differ per image): one launch per query-row chunk for the whole batch instead of one per image. */
+  int64_t w_bstride;
 } tfx_gemm_args;
 int tfx_gemm_bf16(const tfx_gemm_args* args, int variant, tfx_stream stream);
 

@@ -201,6 +201,26 @@ def test_gemm_qkn_entry_point_matches_gemm_plus_separate_norm_rope_pass(ops, gel
         ops.gemm_qkn(a, w, b, wq, wk, cs, (2 * D + 128, 3 * D), (0, D), pos0=pos0, **kw)              # not whole head pairs
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_gemm_per_batch_weights_equal_one_launch_per_sample(ops, variant):
+    """tfx_gemm_args.w_bstride (round 6): W [B, N, K], a different weight matrix per batch sample -- what the VAE mid-block attention's q k^T
+    and P v products are -- in ONE launch, bit-identical to a launch per sample (same tiles, same kernel), in every kernel form (0 generic,
+    1 auto incl. K-sliced units, 2 one-tile, 3 persistent) and for the fp32-output entry point."""
+    B, M, N, K = 3, 520, 392, 256
+    a, w, bias = rnd((B, M, K), 91).to(BF).cuda(), rnd((B, N, K), 92, 0.05).to(BF).cuda(), rnd((N,), 93).to(BF).cuda()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda") if variant == 1 else None
+    got = ops.gemm(a, w, bias, variant=variant, workspace=ws)
+    for b in range(B):
+        assert torch.equal(got[b], ops.gemm(a[b], w[b], bias, variant=variant, workspace=ws)), b
+    close(got, (a.float() @ w.float().transpose(1, 2) + bias.float()).to(BF))
+    f = ops.gemm_f32(a, w)
+    for b in range(B):
+        assert torch.equal(f[b], ops.gemm_f32(a[b], w[b])), b
+    wv = torch.zeros(B, N, K + 64, dtype=BF, device="cuda")[:, :, :K]          # strided views: row pitch and batch pitch of their own
+    wv.copy_(w)
+    assert torch.equal(ops.gemm(a, wv, bias, variant=variant, workspace=ws), got)
+
+
 def test_gemm_persistent_rejects_odd_k_tiles(ops):
     a, w = rnd((512, 192), 1).to(BF).cuda(), rnd((256, 192), 2).to(BF).cuda()
     with pytest.raises(RuntimeError, match="persistent"):

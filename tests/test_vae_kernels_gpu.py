@@ -258,7 +258,7 @@ def test_mid_block_attention_matches_fp32_softmax_attention():
 def test_mid_block_attention_score_chunks_bound_the_scratch():
     """Round 5: the mid-block attention walks the query rows in chunks through one reused score / weight
     buffer pair whose size is capped (AutoencoderKL.ATTEND_CHUNK_BYTES) instead of materialising [N, N]: ragged token count, ragged last
-    chunk, batch 2.  The scratch holds `rows` rows, not N; reruns are bit-identical; against one chunk per image the result differs only
+    chunk, batch 2.  The scratch holds `rows` rows per image, not N; reruns are bit-identical; against one chunk per image the result differs only
     by the fp32 summation order of the K-sliced P v product (isolated last-ulp flips); both match fp32 softmax attention."""
     from textflux_amd.vae import AutoencoderKL
     vae = AutoencoderKL.__new__(AutoencoderKL)
@@ -267,10 +267,10 @@ def test_mid_block_attention_score_chunks_bound_the_scratch():
     q, k, v = ((rnd((B, N, C), 40 + i, 1.2).to(BF)).cuda() for i in range(3))
     vae.ATTEND_CHUNK_BYTES = 1 << 40
     whole = vae._attend(q, k, v)
-    assert vae._scores[0].shape[0] == N
-    vae.ATTEND_CHUNK_BYTES = 4 << 20                       # 4 MiB / (2176 * 6 B) -> 256 rows per chunk: 9 chunks, the last one ragged
+    assert vae._scores[0].shape[:2] == (B, N)              # round 6: the whole batch per launch (per-batch weights: tfx_gemm_args.w_bstride)
+    vae.ATTEND_CHUNK_BYTES = 8 << 20                       # 8 MiB / (2 x 2176 x 6 B) -> 256 rows per chunk: 9 chunks, the last one ragged
     parts = vae._attend(q, k, v)
-    assert vae._scores[0].shape[0] == 256 and vae._scores[0].numel() * 6 <= 4 << 20
+    assert vae._scores[0].shape[:2] == (B, 256) and vae._scores[0].numel() * 6 <= 8 << 20
     assert torch.equal(parts, vae._attend(q, k, v))
     d = (parts.float() - whole.float()).abs()
     assert d.max().item() <= 2 ** -7 * whole.float().abs().max().item() and (d > 0).float().mean().item() < 0.05

@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("gate", c_void_p), ("gate_bstride", c_int64),
         ("res", c_void_p), ("ldr", c_int64), ("r_bstride", c_int64),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("w_bstride", c_int64),
     ]
 
 

@@ -293,7 +293,7 @@ int tfx_gemm_bf16(const tfx_gemm_args* g, int variant, tfx_stream stream) {
   if (!g) return fail("tfx_gemm_bf16: null args");
   GemmArgs a;
   a.A = g->A; a.lda = g->lda; a.a_bstride = g->a_bstride;
-  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias;
+  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias; a.w_bstride = g->w_bstride;
   a.C = g->C; a.ldc = g->ldc; a.c_bstride = g->c_bstride;
   a.M = g->M; a.N = g->N; a.K = g->K; a.batch = g->batch;
   a.epilogue = g->epilogue; a.gelu_from_col = g->gelu_from_col;
@@ -322,7 +322,7 @@ int tfx_gemm_bf16_qkn(const tfx_gemm_args* g, const tfx_qkn_args* q, tfx_stream 
     return fail("tfx_gemm_bf16_qkn: column ranges outside [0, N)");
   GemmArgs a;
   a.A = g->A; a.lda = g->lda; a.a_bstride = g->a_bstride;
-  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias;
+  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias; a.w_bstride = g->w_bstride;
   a.C = g->C; a.ldc = g->ldc; a.c_bstride = g->c_bstride;
   a.M = g->M; a.N = g->N; a.K = g->K; a.batch = g->batch;
   if (g->epilogue != EPI_BIAS && g->epilogue != EPI_BIAS_GELU) return fail("tfx_gemm_bf16_qkn: epilogue must be 0 (bias) or 1 (bias + GELU from a column)");
@@ -342,7 +342,7 @@ int tfx_gemm_bf16_f32(const tfx_gemm_args* g, tfx_stream stream) {
   if (!g->A || !g->W || !g->C) return fail("tfx_gemm_bf16_f32: null matrix pointer");
   GemmArgs a;
   a.A = g->A; a.lda = g->lda; a.a_bstride = g->a_bstride;
-  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias;
+  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias; a.w_bstride = g->w_bstride;
   a.C = g->C; a.ldc = g->ldc; a.c_bstride = g->c_bstride;
   a.M = g->M; a.N = g->N; a.K = g->K; a.batch = g->batch;
   a.epilogue = g->epilogue; a.gelu_from_col = 0;
@@ -355,7 +355,7 @@ int tfx_gemm_fp8(const tfx_gemm_args* g, const float* a_scale, int64_t a_scale_b
   if (!g) return fail("tfx_gemm_fp8: null args");
   GemmArgs a;
   a.A = g->A; a.lda = g->lda; a.a_bstride = g->a_bstride;
-  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias;
+  a.W = g->W; a.ldw = g->ldw; a.bias = g->bias; a.w_bstride = g->w_bstride;
   a.C = g->C; a.ldc = g->ldc; a.c_bstride = g->c_bstride;
   a.M = g->M; a.N = g->N; a.K = g->K; a.batch = g->batch;
   a.epilogue = g->epilogue; a.gelu_from_col = g->gelu_from_col;

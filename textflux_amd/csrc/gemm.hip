@@ -47,7 +47,7 @@ namespace tfx {
 
 struct GemmParams {
   const bf16_t* A; int64_t lda, a_bs;
-  const bf16_t* W; int64_t ldw;
+  const bf16_t* W; int64_t ldw, w_bs;
   const bf16_t* bias;
   bf16_t* C; int64_t ldc, c_bs;
   int M, N, K, batch, tm, tn, gm;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
         }
       }
       As[c][r] = av;
-      Ws[c][r] = (n < p.N && k < p.K) ? bf2f(p.W[(int64_t)n * p.ldw + k]) : 0.f;
+      Ws[c][r] = (n < p.N && k < p.K) ? bf2f(p.W[b * p.w_bs + (int64_t)n * p.ldw + k]) : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmParams p) {
   const int m0 = tile_m * 256, n0 = tile_n * 256;
 
   const bf16_t* Xb = p.A + b * p.a_bs + (int64_t)((ABL & 8) ? 0 : m0) * p.lda;   // ABL bit3: every tile loads panel 0
-  const bf16_t* Wb = p.W + (int64_t)((ABL & 8) ? 0 : n0) * p.ldw;
+  const bf16_t* Wb = p.W + b * p.w_bs + (int64_t)((ABL & 8) ? 0 : n0) * p.ldw;
   const int nt = p.K >> 6;
 
   // ---- prefetch bookkeeping.  Item table of this wave's group, in phase order q0..q3 (u = tile being computed):
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
     t.n0 = (idx / gsz) * 256;
     t.second = t.m0 < p.split_row;
     t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * ESZ) + (uint32_t)(slice * nt_slice) * 128u;
-    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * ESZ) + (uint32_t)(slice * nt_slice) * 128u + (t.second ? p.w2_off : 0u);
+    t.woff = (uint32_t)((t.b * p.w_bs + (int64_t)t.n0 * p.ldw) * ESZ) + (uint32_t)(slice * nt_slice) * 128u + (t.second ? p.w2_off : 0u);
     return t;
   };
 
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(512) void gemm8pp_kernel(GemmParams p) {
   const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.A, 0, (int)(uint32_t)((((int64_t)(p.batch - 1) * p.a_bs + (int64_t)(p.M - 1) * p.lda + p.K) * ESZ)), 0x00020000);
   const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.W, 0, (int)((uint32_t)((((int64_t)(p.N - 1) * p.ldw + p.K) * ESZ)) + (p.split_row > 0 ? p.w2_off : 0u)), 0x00020000);
+      (void*)p.W, 0, (int)((uint32_t)((((int64_t)(p.batch - 1) * p.w_bs + (int64_t)(p.N - 1) * p.ldw + p.K) * ESZ)) + (p.split_row > 0 ? p.w2_off : 0u)), 0x00020000);
 
   // request item q of K-tile kt of the tile with origins (xo, wo) into buffer set `set`
   auto stage = [&](int q, uint32_t xo, uint32_t wo, int kt, int set) {
@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
     t.n0 = (idx / gsz) * 256;
     t.second = t.m0 < p.split_row;
     t.xoff = (uint32_t)((t.b * p.a_bs + (int64_t)t.m0 * p.lda) * 2);
-    t.woff = (uint32_t)((int64_t)t.n0 * p.ldw * 2) + (t.second ? p.w2_off : 0u);
+    t.woff = (uint32_t)((t.b * p.w_bs + (int64_t)t.n0 * p.ldw) * 2) + (t.second ? p.w2_off : 0u);
     return t;
   };
 
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(256) void gemm4w_kernel(GemmParams p) {
   const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.A, 0, (int)(uint32_t)((((int64_t)(p.batch - 1) * p.a_bs + (int64_t)(p.M - 1) * p.lda + p.K) * 2)), 0x00020000);
   const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.W, 0, (int)((uint32_t)((((int64_t)(p.N - 1) * p.ldw + p.K) * 2)) + (p.split_row > 0 ? p.w2_off : 0u)), 0x00020000);
+      (void*)p.W, 0, (int)((uint32_t)((((int64_t)(p.batch - 1) * p.w_bs + (int64_t)(p.N - 1) * p.ldw + p.K) * 2)) + (p.split_row > 0 ? p.w2_off : 0u)), 0x00020000);
   const int rowx = wave * 64 * (int)p.lda * 2, roww = wave * 64 * (int)p.ldw * 2;       // byte offset of the wave's first row
   const int px = 16 * (int)p.lda * 2, pw = 16 * (int)p.ldw * 2;                          // ... of a piece
   // piece pc (0..3 X, 4..7 W) of sub-tile `sub` of the tile with origins (xo, wo) into LDS set `set`
@@ -1600,7 +1600,7 @@ void set_gemm_group_m(int gm) { g_gemm_group_m = gm < 0 ? 0 : gm; }
 static GemmParams make_params(const GemmArgs& a) {
   GemmParams p;
   p.A = (const bf16_t*)a.A; p.lda = a.lda; p.a_bs = a.a_bstride;
-  p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
+  p.W = (const bf16_t*)a.W; p.ldw = a.ldw; p.w_bs = a.w_bstride;
   p.bias = (const bf16_t*)a.bias;
   p.C = (bf16_t*)a.C; p.ldc = a.ldc; p.c_bs = a.c_bstride;
   p.M = a.M; p.N = a.N; p.K = a.K; p.batch = a.batch;
@@ -1638,7 +1638,7 @@ static bool fast_ok(const GemmArgs& a) {
   if (a.conv_cin > 0 && !conv_ok(a)) return false;
   const bool al16 = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.C % 16 == 0) &&
                     ((uintptr_t)a.bias % 8 == 0);
-  return a.K % 64 == 0 && a.K >= 64 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0 &&
+  return a.K % 64 == 0 && a.K >= 64 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0 && a.w_bstride % 8 == 0 && a.w_bstride >= 0 &&
          a.a_bstride % 8 == 0 && a.c_bstride % 8 == 0 && al16 && (int64_t)255 * a.lda < (1ll << 31) &&
          (int64_t)255 * a.ldw < (1ll << 31) &&
          ((a.epilogue != EPI_BIAS_GATE_RES && a.epilogue != EPI_BIAS_RES) || (a.ldr % 8 == 0 && a.r_bstride % 8 == 0 && a.gate_bstride % 4 == 0 &&
@@ -1652,7 +1652,7 @@ static bool fast_ok(const GemmArgs& a) {
 static bool persist_ok(const GemmParams& p) {
   return p.cin == 0 && p.K % 128 == 0 &&
          ((int64_t)(p.batch - 1) * p.a_bs + (int64_t)p.tm * 256 * p.lda) * 2 < (1ll << 32) - 65536 &&
-         (int64_t)p.tn * 256 * p.ldw * 2 < (1ll << 32) - 65536;
+         ((int64_t)(p.batch - 1) * p.w_bs + (int64_t)p.tn * 256 * p.ldw) * 2 < (1ll << 32) - 65536;
 }
 
 // Which work units of a persistent-kernel GEMM are K-sliced (GemmParams::sk / u_full / tail_r).  T < grid: every tile, so that
@@ -1848,7 +1848,7 @@ int gemm_bf16_variant(const GemmArgs& a, int variant, hipStream_t st) {
 // Row-split weights need the persistent kernel (the tile origin decides the weight set), split_row on a tile boundary, the second
 // weight matrix behind the first inside one 32-bit descriptor range, and both bias / gate pointers (or neither).
 bool gemm_rowsplit_ok(const GemmArgs& a) {
-  if (a.split_row <= 0 || a.split_row % 256 || a.split_row >= a.M || !fast_ok(a) || a.conv_cin > 0 || !a.W2) return false;
+  if (a.split_row <= 0 || a.split_row % 256 || a.split_row >= a.M || !fast_ok(a) || a.conv_cin > 0 || !a.W2 || a.w_bstride) return false;
   const GemmParams p = make_params(a);
   if (!persist_ok(p)) return false;
   const int64_t d = (const char*)a.W2 - (const char*)a.W;
@@ -1989,6 +1989,7 @@ static int launch_fp8(const GemmParams& p, void* ws, int64_t ws_bytes, hipStream
 int gemm_fp8(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return 0;
   if (!a.a_scale || !a.w_scale) return fail("gemm_fp8: scale pointers required");
+  if (a.w_bstride) return fail("gemm_fp8: per-batch weights (w_bstride) are a bf16-path feature");
   if (a.conv_cin > 0) return fail("gemm_fp8: no convolution mode");
   const bool al = ((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.C % 16 == 0) &&
                   ((uintptr_t)a.bias % 8 == 0) && ((uintptr_t)a.w_scale % 16 == 0);

@@ -33,6 +33,7 @@ struct GemmArgs {
   const void* A; int64_t lda; int64_t a_bstride;     // activations  [batch][M, K] bf16, row stride lda
   const void* W;                                      // weights      [N, K] bf16 (nn.Linear layout), row stride ldw
   int64_t ldw;
+  int64_t w_bstride = 0;                              // round 6: per-batch weights [batch][N, K] (elements; 0 = one W for every batch sample): the VAE mid-block attention's k / v^T
   const void* bias;                                   // [N] bf16 or null
   void* C; int64_t ldc; int64_t c_bstride;           // output       [batch][M, N] bf16
   int M, N, K, batch;

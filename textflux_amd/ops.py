@@ -46,17 +46,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     """out[b] = epi(a[b] @ w.T + bias).  a: [M,K] or [B,M,K] (row/batch strided views allowed), w: [N,K].
     workspace: optional device scratch tensor; lets the auto path split K when the GEMM has fewer tiles than CUs."""
     _chk_dev(a, w, bias, out, gate, res, workspace)
-    assert a.dtype == BF16 and w.dtype == BF16 and w.dim() == 2 and w.stride(1) == 1
+    assert a.dtype == BF16 and w.dtype == BF16 and w.dim() in (2, 3) and w.stride(-1) == 1
     ap, lda, abs_, M, batch = _rows_view(a)
-    N, K = w.shape
-    assert a.shape[-1] == K
+    N, K = w.shape[-2:]
+    assert a.shape[-1] == K and (w.dim() == 2 or (a.dim() == 3 and w.shape[0] == batch)), "w [N, K], or [B, N, K] with a [B, M, K]"
     if out is None:
         out = torch.empty(*a.shape[:-1], N, dtype=BF16, device=a.device)
     cp, ldc, cbs, M2, b2 = _rows_view(out)
     assert (M2, b2) == (M, batch) and out.shape[-1] == N
     g = L.GemmArgs()
     g.A, g.lda, g.a_bstride = ap, lda, abs_
-    g.W, g.ldw, g.bias = w.data_ptr(), w.stride(0), _p(bias)
+    g.W, g.ldw, g.bias = w.data_ptr(), w.stride(-2), _p(bias)
+    g.w_bstride = w.stride(0) if w.dim() == 3 else 0
     g.C, g.ldc, g.c_bstride = cp, ldc, cbs
     g.M, g.N, g.K, g.batch = M, N, K, batch
     g.epilogue, g.gelu_from_col = epilogue, gelu_from_col
@@ -660,10 +661,10 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
     """out[b] = a[b] @ w.T as fp32 raw accumulators (no bias / epilogue).  a [M, K] or [B, M, K] bf16, w [N, K] bf16,
     out [.., M, N] fp32 (row-strided views allowed)."""
     _chk_dev(a, w, out)
-    assert a.dtype == BF16 and w.dtype == BF16 and w.dim() == 2 and w.stride(1) == 1
+    assert a.dtype == BF16 and w.dtype == BF16 and w.dim() in (2, 3) and w.stride(-1) == 1
     ap, lda, abs_, M, batch = _rows_view(a)
-    N, K = w.shape
-    assert a.shape[-1] == K
+    N, K = w.shape[-2:]
+    assert a.shape[-1] == K and (w.dim() == 2 or (a.dim() == 3 and w.shape[0] == batch)), "w [N, K], or [B, N, K] with a [B, M, K]"
     if out is None:   # rows padded to a multiple of 4 floats (16-byte aligned vector stores)
         out = torch.empty(*a.shape[:-1], (N + 3) // 4 * 4, dtype=torch.float32, device=a.device)[..., :N]
     assert out.dtype == torch.float32
@@ -671,7 +672,8 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
     assert (M2, b2) == (M, batch) and out.shape[-1] == N
     g = L.GemmArgs()
     g.A, g.lda, g.a_bstride = ap, lda, abs_
-    g.W, g.ldw, g.bias = w.data_ptr(), w.stride(0), None
+    g.W, g.ldw, g.bias = w.data_ptr(), w.stride(-2), None
+    g.w_bstride = w.stride(0) if w.dim() == 3 else 0
     g.C, g.ldc, g.c_bstride = cp, ldc, cbs
     g.M, g.N, g.K, g.batch = M, N, K, batch
     g.epilogue = EPI_BIAS

@@ -185,7 +185,7 @@ class AutoencoderKL:
         D/models/attention_processor.py:2799-2881).  Scores stay fp32 between the two GEMMs (a flash kernel would keep them
         in registers); token counts are padded to a multiple of 64 with zero weights / zero v^T columns so that the P v
         product takes the MFMA kernel for any h * w.  Query rows are independent, so the score matrix is never materialised as a
-        whole: one image at a time, `rows` query rows at a time through ONE reused [rows, Np] score / weight buffer pair whose size
+        whole: the whole batch at a time (round 6), `rows` query rows at a time through ONE reused [B, rows, Np] score / weight buffer pair whose size
         does not grow with the image (round 4 held the full [N, N]: 1.5 GiB at 1024 x 1024, 6 GiB at 2048 x 1024).  Scores and
         softmax weights of a row do not depend on the chunking (bit-identical); the P v sum over the keys is K-sliced according to the
         chunk's tile count, so two chunk sizes agree to the last bf16 ulp, not bit for bit (tests/test_vae_kernels_gpu.py)."""
@@ -193,23 +193,29 @@ class AutoencoderKL:
         Np = (N + 63) // 64 * 64
         vt = torch.zeros(B, C, Np, dtype=torch.bfloat16, device=q.device) if Np != N else torch.empty(B, C, N, dtype=torch.bfloat16, device=q.device)
         ops.transpose(v, out=vt[:, :, :N])
-        rows = max(256, min(N, self.ATTEND_CHUNK_BYTES // (Np * 6) // 256 * 256))
-        if self._scores is None or self._scores[0].shape != (rows, Np):
+        # round 6: the whole BATCH per launch (k and v^T are per-image weight matrices: tfx_gemm_args.w_bstride) -- three launches per
+        # query-row chunk instead of three per image and chunk (1024 x 1024, batch 8: 24 instead of 192 per attention); the chunk's rows
+        # shrink with the batch so that the score / weight scratch keeps its bound
+        rows = max(256, min(N, self.ATTEND_CHUNK_BYTES // (B * Np * 6) // 256 * 256))
+        if self._scores is None or self._scores[0].shape != (B, rows, Np):
             self._scores = None                                          # release before re-allocating
-            self._scores = (torch.empty(rows, Np, dtype=torch.float32, device=q.device),
-                            torch.zeros(rows, Np, dtype=torch.bfloat16, device=q.device))
+            self._scores = (torch.empty(B, rows, Np, dtype=torch.float32, device=q.device),
+                            torch.zeros(B, rows, Np, dtype=torch.bfloat16, device=q.device))
         s, pw = self._scores
-        # the P v product of one chunk has rows / 256 x C / 256 tiles (16 at rows = 2048, C = 512) for 256 CUs and K = Np: it runs K-sliced
-        # through the GEMM's split-K scratch (fp32 partials, fixed order: deterministic for a given image size)
+        # the P v product of one chunk has B x rows / 256 x C / 256 tiles for 256 CUs and K = Np: where that is fewer than the CUs it runs
+        # K-sliced through the GEMM's split-K scratch (fp32 partials, fixed order: deterministic for a given image and batch size)
         if getattr(self, "_pv_ws", None) is None or self._pv_ws.device != q.device:
             self._pv_ws = torch.empty(64 << 20, dtype=torch.uint8, device=q.device)
         o = torch.empty(B, N, C, dtype=torch.bfloat16, device=q.device)
-        for b in range(B):
-            for r0 in range(0, N, rows):
-                n = min(rows, N - r0)
-                ops.gemm_f32(q[b, r0:r0 + n], k[b], out=s[:n, :N])
-                ops.row_softmax(s[:n, :N], C ** -0.5, pw[:n])
-                ops.gemm(pw[:n], vt[b], None, out=o[b, r0:r0 + n], workspace=self._pv_ws)
+        for r0 in range(0, N, rows):
+            n = min(rows, N - r0)
+            ops.gemm_f32(q[:, r0:r0 + n], k, out=s[:, :n, :N])
+            if n == rows:                                   # rows of all images at one stride: one launch
+                ops.row_softmax(s.view(B * rows, Np)[:, :N], C ** -0.5, pw.view(B * rows, Np))
+            else:                                           # the ragged last chunk: one per image
+                for b in range(B):
+                    ops.row_softmax(s[b, :n, :N], C ** -0.5, pw[b, :n])
+            ops.gemm(pw[:, :n], vt, None, out=o[:, r0:r0 + n], workspace=self._pv_ws)
         return o
 
     def _mid(self, x, p):
