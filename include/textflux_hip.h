@@ -420,7 +420,11 @@ int tfx_mul_act(const void* a, int64_t lda, const void* b, int64_t ldb, void* ou
  *      "gemm_place": slot assignment of the persistent GEMM's operand requests, 1 or 2 (default 2; gemm.hip).
  *      "gemm_splitk": 0 disables the split-K path of few-tile GEMMs (default 1).
  *      "fp8_fuse_qkn": 0 = in fp8 mode the q | k | v (| mlp) projections are followed by the separate q / k norm + RoPE pass (default 1:
- *      fused into the e4m3 GEMM's epilogue like the bf16 mode's). */
+ *      fused into the e4m3 GEMM's epilogue like the bf16 mode's).
+ *      "ln_joint": 0 = the LayerNorm + modulation of a double block's text and image rows as two launches (default 1: one launch over the
+ *      joint rows, the text rows taking the second modulation; bit-identical, round 6).
+ *      "ln_prefetch": the LayerNorm + modulation kernel requests the modulation rows up front: 0 never, 1 always, 2 (default) for <= 16384
+ *      rows (latency-bound launches: batch 1); bit-identical either way. */
 int tfx_set_option(const char* name, int value);
 /* The only device memory the library ever allocates itself is behind an opt-in knob: the attention tail-split partials
  * ("attention_tail_split" 1; 138 MB per (device, stream) that launched with it, at most 8).  tfx_release_scratch synchronises the

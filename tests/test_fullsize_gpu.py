@@ -232,3 +232,11 @@ def test_row_split_launches_with_k_sliced_text_tiles_match_separate_launches():
         ops.set_option("gemm_splitk", 2)
         ops.set_option("gemm_group_streams", 1)
     assert torch.equal(j0, s0) and torch.equal(b3[0], s0[0])      # ... and a sample's bits no longer depend on the batch it shares
+    # round 6: the LayerNorm + modulation of a double block's two streams as ONE launch over the joint rows (ln_joint, default 1): the same
+    # kernel on the same rows, the text rows selecting the second modulation -- bit-identical to the two launches
+    ops.set_option("ln_joint", 0)
+    try:
+        two = run(1)
+    finally:
+        ops.set_option("ln_joint", 1)
+    assert torch.equal(two, joint1)

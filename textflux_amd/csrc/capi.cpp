@@ -82,6 +82,7 @@ struct Gemm {
   } while (0)
 
 static int g_fp8_fuse_qkn = 1;    // tfx_set_option fp8_fuse_qkn: 0 = fp8 projections followed by the separate q / k norm + RoPE pass (round 4; A/B knob)
+static int g_ln_joint = 1;        // tfx_set_option ln_joint: 0 = the LayerNorm + modulation of a double block's text and image rows as two launches (A/B knob)
 static int g_group_streams = 1;   // tfx_set_option gemm_group_streams: 0 = the text and image GEMMs of a double block as separate launches (A/B knob)
 
 int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
@@ -174,8 +175,12 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
       j2.gate_res(mi + 5 * D, mbs, hid, D, hid_bs).rowsplit(T, w.ff2_txt, mt + 5 * D).scratch(d.gemm_workspace, d.gemm_workspace_bytes);
       const bool joint = g_group_streams && T > 0 && !q8 && jq.rowsplit_ok() && jo.rowsplit_ok() && j1.rowsplit_ok() && j2.rowsplit_ok();
       if (joint) {
-        TRY(ln_modulate(hid_img, xn_img, mi, mi + D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
-        TRY(ln_modulate(hid, xn, mt, mt + D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
+        if (g_ln_joint) {   // round 6: both streams' LayerNorm + modulation as ONE launch over the joint rows (text rows: the second modulation)
+          TRY(ln_modulate_split(hid, xn, mi, mi + D, mt, mt + D, T, mbs, N, B, D, D, hid_bs, D, hid_bs, eps, st));
+        } else {
+          TRY(ln_modulate(hid_img, xn_img, mi, mi + D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
+          TRY(ln_modulate(hid, xn, mt, mt + D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
+        }
         const bool fj = may_fuse && jq.qknorm_ok(w.norm_q, w.norm_k, d.rope_cs, 0, D, eps);
         if (fj) jq.qknorm(w.norm_q, w.norm_k, d.rope_cs, 0, D, eps);
         TRY(jq.run(st));
@@ -183,8 +188,12 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
           TRY(rmsnorm_rope(y, D7, y_bs, 2 * D, 0, H, N, T, B, w.norm_q, w.norm_k, w.norm_added_q, w.norm_added_k, d.cos_tab, d.sin_tab, eps, st));
         TRY(attention(w.attn_score_bound));
         TRY(jo.run(st));                                                      // hidden += gate_msa * to_out(attn), both streams
-        TRY(ln_modulate(hid_img, xn_img, mi + 3 * D, mi + 4 * D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
-        TRY(ln_modulate(hid, xn, mt + 3 * D, mt + 4 * D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
+        if (g_ln_joint) {
+          TRY(ln_modulate_split(hid, xn, mi + 3 * D, mi + 4 * D, mt + 3 * D, mt + 4 * D, T, mbs, N, B, D, D, hid_bs, D, hid_bs, eps, st));
+        } else {
+          TRY(ln_modulate(hid_img, xn_img, mi + 3 * D, mi + 4 * D, mbs, Sn, B, D, D, hid_bs, D, hid_bs, eps, st));
+          TRY(ln_modulate(hid, xn, mt + 3 * D, mt + 4 * D, mbs, T, B, D, D, hid_bs, D, hid_bs, eps, st));
+        }
         TRY(j1.run(st));
         TRY(j2.run(st));
         continue;
@@ -641,6 +650,8 @@ int tfx_set_option(const char* name, int value) {
     return 0;
   }
   if (!std::strcmp(name, "gemm_group_streams")) { g_group_streams = value; return 0; }
+  if (!std::strcmp(name, "ln_joint")) { g_ln_joint = value; return 0; }
+  if (!std::strcmp(name, "ln_prefetch")) { set_ln_prefetch(value); return 0; }
   if (!std::strcmp(name, "fp8_fuse_qkn")) { g_fp8_fuse_qkn = value; return 0; }
   if (!std::strcmp(name, "gemm_splitk")) { set_gemm_splitk(value); return 0; }
   if (!std::strcmp(name, "attention_ablation")) { set_attention_ablation(value); return 0; }  // bench-only

@@ -19,14 +19,20 @@ namespace tfx {
 // AFFINE: nn.LayerNorm with elementwise affine instead -- out = bf16((x - mean) * rstd * gamma + beta), fp32 throughout and
 // ONE rounding, which is what F.layer_norm does on bf16 tensors (scale = gamma, shift = beta, mod_bstride = 0; the CLIP text
 // model's LayerNorms, transformers models/clip/modeling_clip.py CLIPEncoderLayer / final_layer_norm).
-template <int NCH, bool F8 = false, bool AFFINE = false>
+// PREF (round 6): the row's chunks are requested together (rounds 1-5 loaded each under its own `if (chunk < nchunk)`: hipcc waited for every
+// load before the next -- six dependent memory round trips per row, invisible at batch 8 behind 20 waves per CU and the whole 8.9 us of
+// the kernel at batch 1), and with PREF the modulation rows, which do not depend on the statistics, right behind them.
+template <int NCH, bool F8 = false, bool AFFINE = false, bool PREF = false>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ shift,
                                                           const bf16_t* __restrict__ scale, int64_t mod_bstride,
                                                           int rows_per_batch, int64_t rows, int D, int64_t ldx,
                                                           int64_t x_bstride, int64_t ldo, int64_t o_bstride, float eps,
                                                           uint8_t* __restrict__ q8 = nullptr, float* __restrict__ q8_scale = nullptr,
-                                                          int64_t s_bstride = 0) {
+                                                          int64_t s_bstride = 0, int split_row = 0,
+                                                          const bf16_t* __restrict__ shift2 = nullptr, const bf16_t* __restrict__ scale2 = nullptr) {
+  // split_row > 0 (round 6): rows below split_row of every batch sample -- the TEXT rows of the joint [text | image] stream -- take the
+  // second modulation (shift2 / scale2): the two LayerNorm + modulation launches of a double block's streams as one (a wave-uniform select)
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -37,12 +43,28 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restri
   const int nchunk = D >> 3;
   float v[NCH][8];
   float sum = 0.f;
+  const bool second = r < split_row;
+  const bf16_t* sh = (second ? shift2 : shift) + b * mod_bstride;
+  const bf16_t* sc = (second ? scale2 : scale) + b * mod_bstride;
+  u32x4 raw[NCH], scr[PREF ? NCH : 1], shr[PREF ? NCH : 1];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {     // clamped, unconditional: all requests of the row in flight at once (a chunk beyond D re-reads the last one)
+    const int chc = min(lane + c * 64, nchunk - 1);
+    raw[c] = *reinterpret_cast<const u32x4*>(xr + chc * 8);
+  }
+  if constexpr (PREF) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int chc = min(lane + c * 64, nchunk - 1);
+      scr[c] = *reinterpret_cast<const u32x4*>(sc + chc * 8);
+      shr[c] = *reinterpret_cast<const u32x4*>(sh + chc * 8);
+    }
+  }
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int ch = lane + c * 64;
     if (ch < nchunk) {
-      u32x4 raw = *reinterpret_cast<const u32x4*>(xr + ch * 8);
-      unpack8(raw, v[c]);
+      unpack8(raw[c], v[c]);
 #pragma unroll
       for (int i = 0; i < 8; ++i) sum += v[c][i];
     } else {
@@ -63,15 +85,18 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restri
     }
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-  const bf16_t* sh = shift + b * mod_bstride;
-  const bf16_t* sc = scale + b * mod_bstride;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int ch = lane + c * 64;
     if (ch < nchunk) {
       float s8[8], h8[8], o8[8];
-      unpack8(*reinterpret_cast<const u32x4*>(sc + ch * 8), s8);
-      unpack8(*reinterpret_cast<const u32x4*>(sh + ch * 8), h8);
+      if constexpr (PREF) {
+        unpack8(scr[c], s8);
+        unpack8(shr[c], h8);
+      } else {
+        unpack8(*reinterpret_cast<const u32x4*>(sc + ch * 8), s8);
+        unpack8(*reinterpret_cast<const u32x4*>(sh + ch * 8), h8);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (AFFINE) {
@@ -429,16 +454,47 @@ __global__ __launch_bounds__(256) void select_step_kernel(const bf16_t* __restri
 __global__ void advance_step_kernel(int* step_ptr) { *step_ptr += 1; }
 
 // ---------------------------------------------------------------------------------------------
+// tfx_set_option ln_prefetch: 0 never, 1 always, 2 (default) by size -- the modulation rows requested up front cost 48 more registers per
+// lane (occupancy 6 -> 3 waves per SIMD): free where the kernel is latency-bound (few rows), measured per size below
+static int g_ln_prefetch = 2;
+void set_ln_prefetch(int v) { g_ln_prefetch = v; }
+static bool ln_prefetch_for(int64_t rows) { return g_ln_prefetch == 1 || (g_ln_prefetch == 2 && rows <= 16384); }
 int ln_modulate(const void* x, void* out, const void* shift, const void* scale, int64_t mod_bstride,
                 int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldo,
                 int64_t o_bstride, float eps, hipStream_t st) {
   if (D % 8 || D > 6 * 512) return fail("ln_modulate: D must be a multiple of 8 and <= 3072");
   const int64_t rows = (int64_t)rows_per_batch * batch;
   if (rows == 0) return 0;
-  ln_modulate_kernel<6><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(
-      (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)shift, (const bf16_t*)scale, mod_bstride, rows_per_batch, rows, D,
-      ldx, x_bstride, ldo, o_bstride, eps);
+  if (ln_prefetch_for(rows))
+    ln_modulate_kernel<6, false, false, true><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(
+        (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)shift, (const bf16_t*)scale, mod_bstride, rows_per_batch, rows, D,
+        ldx, x_bstride, ldo, o_bstride, eps);
+  else
+    ln_modulate_kernel<6><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(
+        (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)shift, (const bf16_t*)scale, mod_bstride, rows_per_batch, rows, D,
+        ldx, x_bstride, ldo, o_bstride, eps);
   return check_launch("ln_modulate");
+}
+
+// The LayerNorm + modulation of BOTH streams of a double block in one launch over the joint [text | image] rows: rows < split_row of a
+// sample take (shift2, scale2) -- norm1_context / the text stream's norm2 --, the others (shift, scale).  Same kernel, same arithmetic per
+// row: bit-identical to the two launches it replaces; at batch 1 it removes a 6 us latency-bound launch per pair (38 per step).
+int ln_modulate_split(const void* x, void* out, const void* shift, const void* scale, const void* shift2, const void* scale2,
+                      int split_row, int64_t mod_bstride, int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldo,
+                      int64_t o_bstride, float eps, hipStream_t st) {
+  if (D % 8 || D > 6 * 512) return fail("ln_modulate: D must be a multiple of 8 and <= 3072");
+  if (split_row < 0 || split_row > rows_per_batch || (split_row > 0 && (!shift2 || !scale2))) return fail("ln_modulate_split: split_row / second modulation");
+  const int64_t rows = (int64_t)rows_per_batch * batch;
+  if (rows == 0) return 0;
+  if (ln_prefetch_for(rows))
+    ln_modulate_kernel<6, false, false, true><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(
+        (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)shift, (const bf16_t*)scale, mod_bstride, rows_per_batch, rows, D,
+        ldx, x_bstride, ldo, o_bstride, eps, nullptr, nullptr, 0, split_row, (const bf16_t*)shift2, (const bf16_t*)scale2);
+  else
+    ln_modulate_kernel<6><<<dim3((unsigned)((rows + 3) / 4)), 256, 0, st>>>(
+        (const bf16_t*)x, (bf16_t*)out, (const bf16_t*)shift, (const bf16_t*)scale, mod_bstride, rows_per_batch, rows, D,
+        ldx, x_bstride, ldo, o_bstride, eps, nullptr, nullptr, 0, split_row, (const bf16_t*)shift2, (const bf16_t*)scale2);
+  return check_launch("ln_modulate_split");
 }
 
 int layernorm_affine(const void* x, void* out, const void* gamma, const void* beta, int64_t rows, int D, int64_t ldx, int64_t ldo,

@@ -1460,16 +1460,46 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams p) {
   const int64_t slice_stride = (int64_t)TT * 65536;
   const float* src = p.ws + (int64_t)tt * 65536 + row * 256 + c8 * 8;
   float v[8];
-  {
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+  // Round 6: everything this thread needs from memory is requested up front -- bias, gate, residual and ALL slices (the slice loop used to
+  // be a runtime loop of load / wait / add: sk dependent round trips in a kernel that is 11-15 us of pure latency at batch 1); the slices
+  // are still ADDED in order (deterministic, the same bits as before)
+  const bf16_t* bias = second ? p.bias2 : p.bias;
+  u32x4 braw = u32x4{0u, 0u, 0u, 0u}, graw = braw, rraw = braw;
+  if (bias) braw = *reinterpret_cast<const u32x4*>(bias + n);
+  if (EPI == EPI_BIAS_GATE_RES) graw = *reinterpret_cast<const u32x4*>((second ? p.gate2 : p.gate) + b * p.gate_bs + n);
+  if (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES) rraw = *reinterpret_cast<const u32x4*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + n);
+  auto sum_slices = [&](auto SKc) __attribute__((always_inline)) {
+    constexpr int SK = decltype(SKc)::value;
+    f32x4 a[SK][2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
-  }
-  for (int s = 1; s < p.sk; ++s) {
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + s * slice_stride);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + s * slice_stride + 4);
+    for (int s = 0; s < SK; ++s) {
+      a[s][0] = *reinterpret_cast<const f32x4*>(src + s * slice_stride);
+      a[s][1] = *reinterpret_cast<const f32x4*>(src + s * slice_stride + 4);
+    }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
+    for (int e = 0; e < 4; ++e) { v[e] = a[0][0][e]; v[4 + e] = a[0][1][e]; }
+#pragma unroll
+    for (int s = 1; s < SK; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += a[s][0][e]; v[4 + e] += a[s][1][e]; }
+  };
+  switch (p.sk) {      // plan_slices: 2, 3, 4, 6 or 8 (1 = the fp32-output mode never comes here)
+    case 2: sum_slices(std::integral_constant<int, 2>{}); break;
+    case 3: sum_slices(std::integral_constant<int, 3>{}); break;
+    case 4: sum_slices(std::integral_constant<int, 4>{}); break;
+    case 6: sum_slices(std::integral_constant<int, 6>{}); break;
+    case 8: sum_slices(std::integral_constant<int, 8>{}); break;
+    default: {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[4 + e] = a1[e]; }
+      for (int s = 1; s < p.sk; ++s) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(src + s * slice_stride);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(src + s * slice_stride + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+      }
+    }
   }
   if (FP8) {  // dequantise: row scale, then channel scale (the order of the unsplit epilogue)
     const float sa = p.a_scale[b * p.as_bs + m];
@@ -1477,10 +1507,9 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = (v[e] * sa) * w0[e]; v[4 + e] = (v[4 + e] * sa) * w1[e]; }
   }
-  const bf16_t* bias = second ? p.bias2 : p.bias;
   if (bias) {
     float bs[8];
-    unpack8(*reinterpret_cast<const u32x4*>(bias + n), bs);
+    unpack8(braw, bs);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += bs[e];
   }
@@ -1490,7 +1519,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams p) {
   }
   if (EPI == EPI_BIAS_GATE_RES) {
     float gt[8];
-    unpack8(*reinterpret_cast<const u32x4*>((second ? p.gate2 : p.gate) + b * p.gate_bs + n), gt);
+    unpack8(graw, gt);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = gt[e] * round_bf(v[e]);
   }
@@ -1498,7 +1527,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams p) {
   if (EPI == EPI_BIAS_GATE_RES || EPI == EPI_BIAS_RES) {
     float fv[8], fr[8];
     unpack8(val, fv);
-    unpack8(*reinterpret_cast<const u32x4*>(p.res + b * p.r_bs + (int64_t)m * p.ldr + n), fr);
+    unpack8(rraw, fr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) fv[e] += fr[e];
     val = pack8(fv);

@@ -117,6 +117,10 @@ void set_attention_waves(int nw);  // 8 (one 512-thread workgroup per CU) or 4 (
 
 int groupnorm_silu_nhwc(const void* x, void* out, const void* gamma, const void* beta, float* stats_ws, int B,
                         int64_t HW, int C, int groups, float eps, bool silu, hipStream_t st);
+void set_ln_prefetch(int v);   // tfx_set_option ln_prefetch
+int ln_modulate_split(const void* x, void* out, const void* shift, const void* scale, const void* shift2, const void* scale2,
+                      int split_row, int64_t mod_bstride, int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldo,
+                      int64_t o_bstride, float eps, hipStream_t st);   // rows < split_row of a sample: (shift2, scale2)
 int ln_modulate(const void* x, void* out, const void* shift, const void* scale, int64_t mod_bstride,
                 int rows_per_batch, int batch, int D, int64_t ldx, int64_t x_bstride, int64_t ldo,
                 int64_t o_bstride, float eps, hipStream_t st);
