@@ -290,7 +290,11 @@ def main():
     torch.cuda.synchronize()
     c1_rec = None
     if c1_proc is not None:      # the host-side baseline finishes before anything is timed
-        c1_out, _ = c1_proc.communicate()
+        try:
+            c1_out, _ = c1_proc.communicate(timeout=900)
+        except Exception:            # a host that cannot finish C1 in 15 minutes must not hold the GPU measurement
+            c1_proc.kill()
+            c1_out = ""
         try:
             c1_json = json.loads(c1_out.strip().splitlines()[-1])
             c1_rec = c1_json["cpu_baseline_c1"]
