@@ -74,6 +74,8 @@ def test_null_arguments_are_rejected_without_a_gpu(lib):
     assert b"null" in lib.tfx_last_error()
     assert lib.tfx_dit_forward(None, None) != 0
     assert lib.tfx_joint_attention(None, None) != 0
+    assert lib.tfx_gemm_bf16_qkn(None, None, None) != 0 and b"null" in lib.tfx_last_error()        # ABI 7 entry points
+    assert lib.tfx_mfma_peak_probe(None, 0, 0, 48, None, None) != 0 and b"mfma_peak_probe" in lib.tfx_last_error()
 
 
 def test_workspace_layout_is_host_arithmetic(lib):

@@ -221,6 +221,22 @@ def test_gemm_per_batch_weights_equal_one_launch_per_sample(ops, variant):
     assert torch.equal(ops.gemm(a, wv, bias, variant=variant, workspace=ws), got)
 
 
+def test_mfma_peak_probe_reports_a_plausible_matrix_pipe_rate(ops):
+    """tfx_mfma_peak_probe (round 6): the product library's MFMA-only kernel, the live denominator of bench.py's roofline.frac_of_capped.
+    Its FLOP count is 64 (e4m3: 32) MFMAs per wave and K-tile x 8 waves x CUs; the rate on random operands must lie between half of the
+    nominal dense peak and the peak itself (it is power-capped, never faster than the pipe), e4m3 about twice bf16; bad arguments fail."""
+    g = torch.Generator().manual_seed(5)
+    r = torch.randn(1 << 18, generator=g)
+    bf = ops.mfma_peak_probe(r.to(BF).cuda(), fp8=False, seconds=0.6)
+    f8 = ops.mfma_peak_probe(r.to(torch.float8_e4m3fn).view(torch.uint8).cuda(), fp8=True, seconds=0.6)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert bf["flops_per_launch"] % (cus * 8 * 64 * 16384) == 0 and f8["flops_per_launch"] % (cus * 8 * 32 * 65536) == 0
+    assert 1250 < bf["tflops"] <= 2500 and 2500 < f8["tflops"] <= 5000, (bf, f8)
+    assert 1.6 < f8["tflops"] / bf["tflops"] < 2.4
+    with pytest.raises(RuntimeError, match="mfma_peak_probe"):
+        ops.mfma_peak_probe(torch.zeros(64, dtype=BF, device="cuda"))            # fewer than 16 KiB of operands
+
+
 def test_gemm_persistent_rejects_odd_k_tiles(ops):
     a, w = rnd((512, 192), 1).to(BF).cuda(), rnd((256, 192), 2).to(BF).cuda()
     with pytest.raises(RuntimeError, match="persistent"):
