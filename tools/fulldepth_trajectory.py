@@ -139,7 +139,8 @@ def run_check_reference(threads: int, steps: int, out_path: str):
     with open(out_path, "w") as f:
         json.dump(rec, f, indent=1)
     assert ok, rows
-    fx["ref_traj_bf16"] = torch.stack([t[0] for t in traj_ref]).to(BF).contiguous()     # the REFERENCE's own latents, steps 1..`steps`
+    keep = min(steps, 3)      # the fixture keeps the first three rows (they equal traj_bf16's, asserted above); the record covers all `steps`
+    fx["ref_traj_bf16"] = torch.stack([t[0] for t in traj_ref[:keep]]).to(BF).contiguous()     # the REFERENCE's own latents, steps 1..3
     save_file(fx, FIXTURE)
     print(f"[check-reference] bit-exact at 57 blocks x 3072; ref_traj_bf16 {tuple(fx['ref_traj_bf16'].shape)} stored in {FIXTURE}", flush=True)
 
@@ -210,6 +211,7 @@ if __name__ == "__main__":
     if a.oracle:
         run_oracle(a.fp32, a.threads)
     if a.check_reference:
-        run_check_reference(a.threads, a.ref_steps, os.path.join(REPO, "profiles", "r06_reference_fullsize_pin.json"))
+        run_check_reference(a.threads, a.ref_steps, os.path.join(REPO, "profiles", "r06_reference_fullsize_pin.json" if a.ref_steps <= 3 else
+                                                             f"r06_reference_fullsize_pin_{a.ref_steps}steps.json"))
     if a.engine:
         run_engine(a.out)

@@ -105,14 +105,30 @@ def main():
         rows.append(probe(f"attention (default kernel) B8 H24 N4608, {data} data",
                           lambda: ops.attention(y[:, :, 2 * D:], y[:, :, :D], y[:, :, D:2 * D], out=o), af, a.secs))
         del x, w, y, out, o
+    # round 6: the product library's MFMA-only kernel (tfx_mfma_peak_probe: the GEMM kernels' MFMA sections on register-resident operands, no
+    # prologue, no epilogue, one workgroup per CU) next to the older "pure MFMA" row (the ONE-TILE GEMM with its requests, LDS reads and barriers
+    # compiled out -- 5184 workgroups that still run their address arithmetic, prologue waits and a full epilogue each): bench.py's live
+    # roofline.power_capped_peak is the former
+    if hasattr(ops, "mfma_peak_probe"):
+        import ctypes as C
+        from textflux_amd import _lib as L
+        g = torch.Generator().manual_seed(5)
+        r32 = torch.randn(1 << 20, generator=g)
+        for name, buf, f8 in (("bf16", r32.to(BF).cuda(), 0), ("e4m3", r32.to(torch.float8_e4m3fn).view(torch.uint8).cuda(), 1),
+                              ("bf16, zero data", torch.zeros(1 << 20, dtype=BF, device="cuda"), 0)):
+            fl = C.c_double()
+            kt = 48 * 4096
+            fn = lambda: L.check(L.lib().tfx_mfma_peak_probe(buf.data_ptr(), buf.numel() * buf.element_size(), f8, kt, C.byref(fl),
+                                                             torch.cuda.current_stream().cuda_stream), "probe")
+            fn(); torch.cuda.synchronize()
+            rows.append(probe(f"tfx_mfma_peak_probe ({name}): MFMA sections only, registers only", fn, fl.value, a.secs))
     idle_w = rows[0].get("board_w")
     mf = next((r for r in rows if r["name"].startswith("pure MFMA") and "random" in r["name"] and "tflops" in r), None)
     rec = dict(device=torch.cuda.get_device_name(0), shape=dict(M=M, N=N, K=K), gemm_flops_per_launch=gf, attention_flops_per_launch=af,
                secs_per_row=a.secs, method="wall time of a sustained loop / launches; rocm-smi --showclocks --showpower sampled every 0.25 s "
                                            "during the loop (first two samples dropped); J = mean W x s",
                near_idle_w=idle_w, power_capped_peak_tflops=mf["tflops"] if mf else None,
-               power_capped_peak_note="rate of the MFMA-only ablation on random bf16 operands: nothing but v_mfma_f32_32x32x16_bf16 at "
-                                      "the board's power cap; no kernel that also moves operands can exceed it on this data",
+               power_capped_peak_note="rate of the MFMA-only ablation on random bf16 operands: the one-tile GEMM without requests / LDS reads / barriers (still one workgroup per tile with its prologue and epilogue); the register-only stream is the tfx_mfma_peak_probe row",
                rows=rows)
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     with open(a.out, "w") as f:
