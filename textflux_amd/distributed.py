@@ -16,12 +16,20 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from the torchrun environment; initialises the default process group."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    # Over-subscription hooks for boxes with fewer GPUs than ranks (tests/test_world2_one_gpu.py): TFX_LOCAL_DEVICE pins every rank to
+    # one device index, TFX_DIST_BACKEND names the backend.  RCCL itself refuses two ranks on one device ("Duplicate GPU detected",
+    # tools/rccl_two_ranks_one_gpu.py), so the only way the world-2 branches can run with DEVICE tensors on a 1-GPU box is gloo,
+    # which stages them through the host.  Neither variable is set by bench.py, the driver or scripts/run_eval.py.
+    if os.environ.get("TFX_LOCAL_DEVICE", "") != "":
+        local = int(os.environ["TFX_LOCAL_DEVICE"])
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # torchrun: also exercise the group at world 1
     if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            backend = os.environ.get("TFX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend not in ("nccl", "gloo"):
+            raise ValueError(f"TFX_DIST_BACKEND / backend must be 'nccl' or 'gloo', got {backend!r}")
+        if backend == "nccl" or (torch.cuda.is_available() and local < torch.cuda.device_count()):
+            torch.cuda.set_device(local)          # nccl: fails loudly when the rank has no device of its own
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
