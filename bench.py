@@ -147,6 +147,14 @@ def cpu_baseline_c1(steps=4):
             "cpu_tflops": steps * dit_flops(S) / t / 1e12}
 
 
+def _transport():
+    """What the collectives of this run travelled on: 'RCCL' for the nccl backend (the driver's launch), otherwise the backend's name."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return "RCCL"            # no group at N = 1 without a launcher: the string describes the N > 1 design
+    return "RCCL" if dist.get_backend() == "nccl" else dist.get_backend()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -431,7 +439,7 @@ def main():
                                      "of a17 is outside the timed region, see pil_output_delta_ms_per_call)"
                                    + ("" if full else f" [REDUCED MODEL {a.layers} - not a valid headline]")
                                    + (" [fp8 linears: BASELINE config 5 precision, not the bf16 headline]" if a.fp8 else ""),
-                       "global_batch": world * B, "parallelism": f"dp{world} (batch shards; shared CLIP conditioning broadcast over RCCL, T5 prompts encoded per rank)"},
+                       "global_batch": world * B, "parallelism": f"dp{world} (batch shards; shared CLIP conditioning broadcast over {_transport()}, T5 prompts encoded per rank)"},
             "rccl_ranks_seen": seen, "process_group": tdist.group_info(),
             "elapsed_s": elapsed, "elapsed_per_rank_s": {"min": min(own_all), "max": max(own_all), "ranks": own_all,
                                                          "note": "each rank's own K calls up to its synchronize(), before the closing barrier"},
