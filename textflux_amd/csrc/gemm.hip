@@ -1689,6 +1689,9 @@ static bool persist_ok(const GemmParams& p) {
 // filled round is under a ninth of the time and the fp32 round trip of its tiles costs what the slicing saves): the R = T mod grid
 // tiles of the last round when one short round of slices can take them (R c <= grid), the same tile positions in every batch
 // sample (identical samples keep identical bits).  Slices keep an even number >= 8 of K-tiles; ws: 256 KiB per unit.
+// (Round 6 measured the generalisation -- the last round of a LONG-K GEMM with >= 8 rounds or R c > grid as several short rounds of slices:
+// 1728 tiles, R = 192 as 768 quarter-K units -- and it LOSES: +40 us / +67 us per launch at K = 15360 / 12288, +1.1 % per forward; the
+// partials of every CU leave at the same moment and come back in the second pass.  profiles/r06_splitk_long_k_ab.log.)
 struct SlicePlan { int sk, u_full, tail_r; };
 static SlicePlan plan_slices(const GemmParams& p, int grid, int nt, void* ws, int64_t ws_bytes) {
   SlicePlan pl{1, 0, 0};
