@@ -33,7 +33,7 @@ const char* tfx_last_error(void);
  * two since ABI 6) and returns how many values there are.  A binding
  * compares them with its own view of this header BEFORE the first call that passes a struct: a library built from an older
  * header would otherwise ignore the tail fields of a grown struct silently (no reference counterpart: the reference has no FFI). */
-#define TFX_ABI_VERSION 7
+#define TFX_ABI_VERSION 8
 int tfx_abi_info(int32_t* out, int n);
 /* Writes the gcnArchName of the current device (e.g. "gfx950:sramecc+:xnack-") into buf.  Needs a GPU. */
 int tfx_query_arch(char* buf, int buflen);
@@ -160,6 +160,10 @@ typedef struct tfx_attn_args {
    * takes the bound per block from that block's q / k RMSNorm weights (after the norm |q| <= sqrt(128) max|w_q|, RoPE preserves
    * it).  A wrong promise can overflow to inf / NaN; 0 (or a bound beyond the limit) keeps the kernel's own overflow guard. */
   float score_bound;
+  /* optional scratch (ABI 8; NULL = none), 16-byte aligned, 2 * 256 * 256 * 132 * 4 = 69.2 MB for any shape: lets the head-dim-128 kernel deal
+   * (item, 64-key tile) units to the CUs instead of whole (b, h, 256-query) items ("attention_streamk", tfx_set_option) when that fills
+   * the chip better; contents are scratch, the launch's own stream orders its uses.  tfx_dit_forward passes the split-K scratch. */
+  void* workspace; int64_t workspace_bytes;
 } tfx_attn_args;
 int tfx_joint_attention(const tfx_attn_args* args, tfx_stream stream);
 
@@ -258,7 +262,7 @@ int tfx_dit_forward(const tfx_dit_desc* desc, tfx_stream stream);
 
 /* Caller-owned workspace of tfx_dit_forward for one problem size, as ONE allocation: total bytes, and the byte offsets
  * (256-byte aligned) of its parts in off[0..5] = hid, xn, y, q8, q8_scale, gemm_workspace (q8 / q8_scale only when
- * flags bit 2 (fp8 linears) is set, else -1); *gemm_workspace_bytes = size of the split-K scratch (64 MiB).  Host-side
+ * flags bit 2 (fp8 linears) is set, else -1); *gemm_workspace_bytes = size of the split-K / stream-K scratch (128 MiB).  Host-side
  * arithmetic only, no GPU needed.  ("never allocate persistent memory except through an explicit
  * workspace the Python side owns".) */
 int64_t tfx_workspace_bytes(int32_t B, int32_t S, int32_t T, int32_t D, int32_t flags);
@@ -414,6 +418,12 @@ int tfx_mul_act(const void* a, int64_t lda, const void* b, int64_t ldb, void* ou
  *      CU of 10 / 8; 9 = 8 with 128 keys per barrier; 16 = softmax / MFMA ping-pong between the wave groups.  All compute
  *      the same softmax; 10, 12, 20 and 30 differ from the others in rounding only (one extra bf16 rounding of q * scale,
  *      row sums of the bf16 weights); 40 = 30 on v_mfma_f32_16x16x32_bf16 (attention_w16.hip); 0 restores the default.
+ *      "attention_streamk": 1 (default) lets kernel 30 deal the (b, h, 256-query) items of a batch sample's last, partly filled
+ *                         round of CUs as (item, 64-key tile) units -- every CU of the sample's group gets the same number of key
+ *                         tiles, an item cut by a CU boundary is finished by a merge pass -- when tfx_attn_args.workspace is given
+ *                         and the library's estimate says it pays (P1024 batch 8: -1.1 % per launch, 2048 x 1024 batch 1: -12 %,
+ *                         1024 x 672 batch 1: -16 %); 2 = whenever admissible; 0 = whole items only: a sample's bits then do not
+ *                         depend on how many samples share its batch (identical samples of ONE batch agree either way).
  *      "attention_tail_split": 1 lets kernel 30 cut the q-tiles of a partly filled last round of workgroups into two key ranges
  *      (+ a merge kernel; faster at small batches, but a sample's bits then depend on the batch size: default 0).
  *      "gemm_group_m": row tiles per group of the GEMM tile order (default 0 = by shape: 1 for N <= 3072, else 4).
@@ -448,8 +458,9 @@ int tfx_prof_collect(int kind, double* total_ms, double* total_flops, int* launc
 int tfx_mfma_peak_probe(const void* operands, int64_t operand_bytes, int32_t fp8, int32_t ktiles, double* flops, tfx_stream stream);
 /* Which form of the attention kernel the launches took (host-side counters, also counted at graph capture, not at replay):
  * counts[0..7] = launches since the last reset of { 0: kernel 30 with its own overflow guard, 1..3: its option-31..33 variants,
- * 4: kernel 30 reference-free (score_bound accepted), 5: attention_hp (20), 6: the 16 x 16 kernel (40), 7: any other schedule }.
- * Copies min(n, 8) counters, then clears them when reset != 0.  Returns the number copied. */
+ * 4: kernel 30 reference-free (score_bound accepted), 5: attention_hp (20), 6: the 16 x 16 kernel (40), 7: any other schedule };
+ * counts[8] (ABI 8) = how many of those launches dealt the items of their last, partly filled round as (item, 64-key tile) units
+ * ("attention_streamk").  Copies min(n, 9) counters, then clears them when reset != 0.  Returns the number copied. */
 int tfx_attention_mode_counts(int64_t* counts, int32_t n, int32_t reset);
 /* Phase timing of the attention kernels (tools/attn_timing.py): buf = device uint64 [blocks][8 waves][4 phases] that the
  * instrumented kernel variants fill with cycle counts, NULL switches back to the plain kernels. */

@@ -186,7 +186,7 @@ def test_p1024_one_block_beyond_the_score_bound_falls_back_alone(weights):
     run_config(sd, sd, 1024, 1024, 1, "euler", steps=2, pipe=pipe)
     c = ops.attention_mode_counts(reset=True)
     # 2 eager steps with the callback + 30 eager steps + the graph's capture of one step (replays launch nothing host-side)
-    assert c["w4_reference_free"] == 2 * c["w4_guarded"] > 0 and sum(c.values()) == c["w4_reference_free"] + c["w4_guarded"], c
+    assert c["w4_reference_free"] == 2 * c["w4_guarded"] > 0 and sum(v for k, v in c.items() if k != "streamk_tail") == c["w4_reference_free"] + c["w4_guarded"], c
     # in-place edit of a norm weight (same storage, new version): bounds and session follow
     old_session = tr._session
     tr.w["s0.norm_q"].mul_(3.0)

@@ -107,17 +107,20 @@ def test_full_model_batch_consistency_and_determinism():
     assert torch.equal(o1, o3)
     from textflux_amd import ops
     ops.set_option("gemm_splitk", 0)
+    ops.set_option("attention_streamk", 0)      # round 6: whole attention items only (which items a batch's last round holds depends on the batch size)
     try:
         n1 = m(hidden_states=hs, encoder_hidden_states=pe, pooled_projections=pooled, timestep=t1, guidance=g1, **kw)[0]
         n2 = m(hidden_states=hs.repeat(2, 1, 1), encoder_hidden_states=pe.repeat(2, 1, 1),
                pooled_projections=pooled.repeat(2, 1), timestep=t1.repeat(2), guidance=g1.repeat(2), **kw)[0]
     finally:
         ops.set_option("gemm_splitk", 2)
+        ops.set_option("attention_streamk", 1)
     assert torch.equal(n2[0], n2[1]) and torch.equal(n2[0], n1[0])
     # round 4: the text and image projections of a double block run as ONE launch over the joint rows (row-split weights) -- the same
     # tiles computed by the same code, so with the K-slicing off (which the joint launch's other tile count would plan differently)
     # the outputs are bit-identical to the two-launch form, at either batch size
     ops.set_option("gemm_splitk", 0)
+    ops.set_option("attention_streamk", 0)
     ops.set_option("gemm_group_streams", 0)
     try:
         s1 = m(hidden_states=hs, encoder_hidden_states=pe, pooled_projections=pooled, timestep=t1, guidance=g1, **kw)[0]
@@ -125,6 +128,7 @@ def test_full_model_batch_consistency_and_determinism():
                pooled_projections=pooled.repeat(2, 1), timestep=t1.repeat(2), guidance=g1.repeat(2), **kw)[0]
     finally:
         ops.set_option("gemm_splitk", 2)
+        ops.set_option("attention_streamk", 1)
         ops.set_option("gemm_group_streams", 1)
     assert torch.equal(s1, n1) and torch.equal(s2, n2)
     # (round 6: the one-wave-per-SIMD GEMM kernel -- gemm_waves 4 -- lives in the bench library; its whole-forward check moved to
@@ -223,6 +227,7 @@ def test_row_split_launches_with_k_sliced_text_tiles_match_separate_launches():
         rel = ((a.float() - b.float()).abs().mean() / b.float().abs().mean()).item()
         assert rel < 2e-2, rel
     ops.set_option("gemm_splitk", 0)                      # no K slicing: the joint launch computes the same tiles with the same code
+    ops.set_option("attention_streamk", 0)                # ... and whole attention items only
     try:
         j0 = run(1)
         ops.set_option("gemm_group_streams", 0)
@@ -230,6 +235,7 @@ def test_row_split_launches_with_k_sliced_text_tiles_match_separate_launches():
         b3 = run(3)
     finally:
         ops.set_option("gemm_splitk", 2)
+        ops.set_option("attention_streamk", 1)
         ops.set_option("gemm_group_streams", 1)
     assert torch.equal(j0, s0) and torch.equal(b3[0], s0[0])      # ... and a sample's bits no longer depend on the batch it shares
     # round 6: the LayerNorm + modulation of a double block's two streams as ONE launch over the joint rows (ln_joint, default 1): the same

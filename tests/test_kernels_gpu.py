@@ -520,6 +520,55 @@ def test_attention_tail_split_matches_unsplit_and_reference(ops, B, N):
         ops.release_scratch()
 
 
+@pytest.mark.parametrize("B,H,N,bound", [(1, 24, 4608, 30.0), (8, 24, 1100, 30.0), (2, 5, 2304, 0.0), (3, 24, 2304, 30.0), (1, 24, 1664, 0.0),
+                                         (4, 24, 3100, 30.0), (8, 24, 4608, 30.0)])
+def test_attention_streamk_dealing_matches_whole_items(ops, B, H, N, bound):
+    """Round 6: with a workspace the persistent kernel deals the items of a sample's partly filled LAST round as (item, 64-key tile) units to
+    the sample's group of CUs instead of leaving part of the chip idle (attention_w4.hip::w4_sk_bound; option attention_streamk: 1 = when
+    the estimate says it pays, 2 = whenever admissible, 0 = never).  A tail item cut by a CU boundary leaves un-normalised partials that a
+    merge pass adds: another fp32 summation order for those rows, nothing else.  Cases: the headline launch at batch 1 and 8, ragged N,
+    launches with fewer items than CUs whose items are cut into up to three parts (share < nkv), B = 3 (a group of 85 CUs per sample, one CU
+    idle), few heads, both streams (bound 0 = the guarded kernel).  Asserted: close to the
+    unsplit kernel and to the fp32 reference, deterministic, identical samples of a batch identical, in-place over q, and -- without a
+    workspace or with the option off -- bit-identical to the whole-item form."""
+    D = H * 128
+    g = torch.Generator().manual_seed(1000 + N + B)
+    one = (torch.randn(1, N, 4 * D, generator=g) * 1.2).to(BF)
+    y = torch.cat([one] + [(torch.randn(1, N, 4 * D, generator=g) * 1.2).to(BF) for _ in range(B - 2)] + ([one] if B > 1 else []), 0).cuda()   # first == last sample
+    k, v, q = y[:, :, :D], y[:, :, D:2 * D], y[:, :, 2 * D:3 * D]
+    ws = torch.empty(72 << 20, dtype=torch.uint8, device="cuda")
+    bi = 0
+    qh, kh, vh = (t[bi:bi + 1].float().view(1, N, H, 128).transpose(1, 2) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(1, N, D)
+    try:
+        ops.set_option("attention_streamk", 0)
+        plain = ops.attention(q, k, v, score_bound=bound, workspace=ws)
+        ops.set_option("attention_streamk", 2)
+        no_ws = ops.attention(q, k, v, score_bound=bound)
+        ops.attention_mode_counts(reset=True)
+        dealt = ops.attention(q, k, v, score_bound=bound, workspace=ws)
+        assert ops.attention_mode_counts()["streamk_tail"] == 1
+        again = ops.attention(q, k, v, score_bound=bound, workspace=ws)
+        pad_before = y[:, :, 3 * D:].clone()
+        ops.attention(q, k, v, out=q, score_bound=bound, workspace=ws)
+        inplace_q, pad_after = y[:, :, 2 * D:3 * D].clone(), y[:, :, 3 * D:].clone()
+    finally:
+        ops.set_option("attention_streamk", 1)
+    assert torch.equal(no_ws, plain)
+    assert torch.equal(dealt, again) and torch.isfinite(dealt.float()).all()
+    assert not torch.equal(dealt, plain)                        # some item was cut: the dealt path really ran
+    if B > 1:
+        assert torch.equal(dealt[0], dealt[B - 1])              # every sample is dealt to its own group of CUs by the same rule
+    close(dealt[bi:bi + 1], ref.to(BF), max_rel=2e-2, mae_rel=4e-3)
+    d = (dealt.float() - plain.float()).abs()
+    # (guarded kernel, bound 0: every part rounds its bf16 weights against its OWN reference maximum -- more than a summation order)
+    assert d.max().item() <= 2.0 ** -7 * ref.abs().max().item() and d.mean().item() <= (1e-3 if bound > 0 else 3e-3) * ref.abs().mean().item()
+    frac = (d > 0).float().mean().item()
+    print(f"B {B} H {H} N {N} bound {bound}: {frac:.4f} of the outputs differ from the whole-item form, max {d.max().item():.3g}")
+    assert frac < 0.6
+    assert torch.equal(inplace_q, dealt) and torch.equal(pad_after, pad_before)
+
+
 def test_attention_strided_inplace_over_q(ops):
     """Layout used by the blocks: [k | v | q | pad] rows, output written over q."""
     B, N, H = 2, 200, 2

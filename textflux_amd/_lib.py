@@ -21,7 +21,7 @@ c_void_p, c_int, c_int32, c_int64, c_float, c_char_p = C.c_void_p, C.c_int, C.c_
 # TFX_ABI_VERSION of the include/textflux_hip.h the ctypes mirrors below were written against (tests/test_capi_symbols.py asserts
 # that it equals the header's): the library's stamp is compared with THIS constant, so a binding copied without include/ still
 # loads, and a ctypes mirror edited without the header (or the other way round) fails a test instead of passing the check.
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GemmArgs(C.Structure):
@@ -50,6 +50,7 @@ class AttnArgs(C.Structure):
         ("ldq", c_int64), ("ldk", c_int64), ("ldv", c_int64), ("ldo", c_int64),
         ("q_bstride", c_int64), ("k_bstride", c_int64), ("v_bstride", c_int64), ("o_bstride", c_int64),
         ("B", c_int32), ("H", c_int32), ("N", c_int32), ("scale", c_float), ("score_bound", c_float),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 

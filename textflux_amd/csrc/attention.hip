@@ -780,11 +780,13 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(const bf16_t* Q, const 
 static int g_attn_bound = 1;   // 0: ignore AttnArgs::score_bound (A/B knob, tfx_set_option attention_use_bound)
 void set_attention_use_bound(int v) { g_attn_bound = v; }
 // which kernel form the launches took (tfx_attention_mode_counts): host counters, bumped at launch (and at graph capture)
-static std::atomic<int64_t> g_attn_mode_count[8];   // zero-initialised (static storage); launches may come from several host threads
+static std::atomic<int64_t> g_attn_mode_count[9];   // [8]: launches (already counted under their mode) whose last round was dealt as (item, tile) units -- stream-K tail
+// (zero-initialised: static storage; launches may come from several host threads)
+void attention_note_streamk() { ++g_attn_mode_count[8]; }
 int attention_mode_counts(int64_t* counts, int n, int reset) {
-  n = n < 0 ? 0 : n > 8 ? 8 : n;
+  n = n < 0 ? 0 : n > 9 ? 9 : n;
   for (int i = 0; i < n; ++i) counts[i] = g_attn_mode_count[i].load(std::memory_order_relaxed);
-  if (reset) for (int i = 0; i < 8; ++i) g_attn_mode_count[i].store(0, std::memory_order_relaxed);
+  if (reset) for (int i = 0; i < 9; ++i) g_attn_mode_count[i].store(0, std::memory_order_relaxed);
   return n;
 }
 // The reference-free stream (attn_w4_kernel<4>) is admissible when nothing can leave the exponent range fp32 and bf16 share without any

@@ -60,7 +60,15 @@ constexpr int W4_KROW = 272;                   // K row pitch
 constexpr int W4_KT = W4_KV * W4_KROW;         // K tile bytes
 constexpr int W4_NBUF = 3;
 constexpr int W4_KBASE = W4_NBUF * W4_VT;      // V tiles first, then K tiles
-constexpr int W4_PROW = 132;                   // floats per row of a tail-split partial: 128 d + row sum + reference maximum + pad
+constexpr int W4_PROW = 132;                   // floats per row of a partial (size only: 128 d + row sum + reference maximum + pad; 256 rows per slot)
+// Layout of one partial slot (256 x 132 floats; round 6 -- until then row-major, which made every store instruction of the producing kernel
+// touch 64 different lines): the un-normalised O in the PRODUCER's register order -- 16-byte element ((wq, db, qd), lane), wq = wave * 2 +
+// q-block, lane = hi * 32 + row-in-block, holds columns db * 32 + qd * 8 + hi * 4 .. + 4 of row wq * 32 + (lane & 31): one store instruction
+// = 1 KiB contiguous -- followed by (row sum, reference maximum) pairs per row.
+__device__ __forceinline__ int w4_part_off(int r, int col) {   // float offset of columns col .. col + 3 (col % 4 == 0) of row r (0 .. 255)
+  return ((((r >> 5) * 4 + (col >> 5)) * 4 + ((col >> 3) & 3)) * 64 + ((col >> 2) & 1) * 32 + (r & 31)) * 4;
+}
+constexpr int W4_PART_LM = 256 * 128;          // float offset of the (l, m) pairs
 constexpr float W4_THR = 4.0f;                 // lazy-reference threshold (log2 units), as attn_mx_kernel (MODE 0 / 1)
 constexpr float W4_BIG = 64.0f;                // MODE 2: a row's reference stays 0 while its scores stay inside +-W4_BIG
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -166,12 +174,34 @@ __device__ unsigned long long* g_w4_timers = nullptr;
 #else
 #define W4_STAMP(i) ((void)0)
 #endif
+// Stream-K tail of the persistent form (round 6, tfx_set_option attention_streamk).  Every batch sample has its own group of C / B CUs.  The
+// sample's items run as whole items, round by round (CU c takes items c, c + group, ...: the CUs of a group work on neighbouring items at any
+// time, so a head's K / V stay L2-resident among them), as long as a round is full; the R < group items of the last, partly filled round are
+// dealt as (item, 64-key tile) units instead: their R nkv units, item-major, are cut into `group` contiguous ranges of `share` units, one per
+// CU, so that every CU ends with the same number of key tiles (13 items + half an item each at P1024 batch 8 instead of 14 items on half of
+// the CUs and 13 on the others).  Boundary c of the tail = c * share, snapped to the item boundary when it would leave a piece shorter than
+// W4_SK_MIN tiles.  A tail item cut by a boundary leaves un-normalised partials (the tail split's format) that attn_w4_merge_sk_kernel adds up.
+// Every sample is dealt by the same rule: identical samples of a batch produce identical bits; a sample's bits do depend on the batch
+// size (as with the K-sliced GEMMs).  (First version of the round: ALL units of a sample dealt contiguously -- 15 % SLOWER at P1024 batch 8:
+// the CUs of an XCD then sit 13 items apart and nothing they load is shared in L2.)
+constexpr int W4_SK_MIN = 4;
+__host__ __device__ __forceinline__ int w4_sk_bound(int c, int group, int share, int nkv, int total) {
+  if (c >= group) return total;
+  int p = c * share;
+  if (p >= total) return total;
+  const int r = p % nkv;
+  if (r < W4_SK_MIN) p -= r;
+  else if (r > nkv - W4_SK_MIN) p += nkv - r;
+  return p < total ? p : total;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const bf16_t* __restrict__ Kp,
                                                          const bf16_t* __restrict__ Vp, bf16_t* O, int64_t ldq, int64_t ldk,
                                                          int64_t ldv, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
                                                          int64_t o_bs, int H, int N, int nqb, float scale_log2e, int nfull,
-                                                         int nparts, int nsplit, int xsplit, float* part, int T_items) {
+                                                         int nparts, int nsplit, int xsplit, float* part, int T_items, int sk_group,
+                                                         int sk_share) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool LV = MODE == 1 || MODE == 2, LZ = MODE >= 2, NOREF = MODE == 4, FT = LV || NOREF;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -192,7 +222,39 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   // tile loop and fly while its output is normalised, staged and stored: 6 k cycles (tools/attn_item_timers.py).
   int kpart = -1, ptile = 0, qblk, h, b;
   int item = 0, item_step = 0, item_end = 0;
-  if (T_items > 0) {
+  // stream-K: this CU's range [sk_lo, sk_hi) of its sample's TAIL units, the sample's first item, the CU's two partial slots, its unit list
+  int sk_lo = 0, sk_hi = 0, sk_base = 0, sk_slot0 = 0, sk_u = 0, sk_nunits = 0, sk_nwhole = 0, sk_full = 0, sk_cu = 0, sk_tfirst = 0;
+  const int nkv_all = (N + W4_KV - 1) / W4_KV;
+  // unit u of this CU: (item, first tile, end tile) -- whole items first (stride = the group), then the pieces of its tail range
+  auto sk_unit = [&](int u, int& it, int& ts, int& te) __attribute__((always_inline)) {
+    if (u < sk_nwhole) {
+      it = sk_base + sk_cu + u * sk_group; ts = 0; te = nkv_all;
+    } else {
+      const int ti = sk_tfirst + (u - sk_nwhole);
+      it = sk_base + sk_full + ti; ts = max(sk_lo - ti * nkv_all, 0); te = min(sk_hi - ti * nkv_all, nkv_all);
+    }
+  };
+  int ts = 0, te = nkv_all;      // this pass's key tiles [ts, te) of its item (stream-K; everything otherwise)
+  if (sk_share > 0) {            // T_items = items of ONE sample, nfull = number of samples
+    const int L = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);            // CUs of one XCD are neighbours in a sample's group
+    const int sample = L / sk_group;
+    sk_cu = L - sample * sk_group;
+    if (sample >= nfull) return;
+    sk_full = (T_items / sk_group) * sk_group;
+    sk_nwhole = sk_full / sk_group;
+    const int total = (T_items - sk_full) * nkv_all;
+    sk_lo = w4_sk_bound(sk_cu, sk_group, sk_share, nkv_all, total);
+    sk_hi = w4_sk_bound(sk_cu + 1, sk_group, sk_share, nkv_all, total);
+    sk_tfirst = sk_lo / nkv_all;
+    sk_nunits = sk_nwhole + (sk_hi > sk_lo ? (sk_hi - 1) / nkv_all - sk_tfirst + 1 : 0);
+    if (sk_nunits == 0) return;
+    sk_base = sample * T_items;
+    sk_slot0 = 2 * L;
+    sk_unit(0, item, ts, te);
+    qblk = item % nqb;
+    h = (item / nqb) % H;
+    b = item / (nqb * H);
+  } else if (T_items > 0) {
     const int nwg = gridDim.x, q = T_items >> 3, r = T_items & 7, xcd = bid & 7, slot = bid >> 3;
     const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, xc = q + (xcd < r ? 1 : 0);
     if (slot >= xc) return;
@@ -237,8 +299,13 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
 #endif
   for (;;) {                     // one pass per item (exactly one in the non-persistent form)
   W4_STAMP(0);
-  const bool has_next = item + item_step < item_end;      // (false in the non-persistent form: all three are 0)
-  const int item2 = item + item_step;
+  bool has_next = item + item_step < item_end;            // (false in the non-persistent form: all three are 0)
+  int item2 = item + item_step, ts2 = 0;
+  if (sk_share > 0) {
+    int te2;
+    has_next = sk_u + 1 < sk_nunits;
+    if (has_next) sk_unit(sk_u + 1, item2, ts2, te2);
+  }
   const int qblk2 = item2 % nqb, h2 = (item2 / nqb) % H, b2 = item2 / (nqb * H);
   const bf16_t* Qb = Q + b * q_bs + h * W4_HD;
   const bf16_t* Kb = Kp + b * k_bs + h * W4_HD;   // (advanced to the first key of a split range below)
@@ -252,6 +319,14 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     Nk = min(N, t1 * W4_KV) - t0 * W4_KV;
     Kb += (int64_t)t0 * W4_KV * ldk;
     Vb += (int64_t)t0 * W4_KV * ldv;
+  }
+  int pslot = -1;                // stream-K: >= 0 when this pass covers only a part of its item's keys (its partial slot)
+  if (sk_share > 0) {
+    if (ts > 0) pslot = sk_slot0;
+    else if (te < nkv_all) pslot = sk_slot0 + 1;
+    Nk = min(N, te * W4_KV) - ts * W4_KV;
+    Kb += (int64_t)ts * W4_KV * ldk;
+    Vb += (int64_t)ts * W4_KV * ldv;
   }
 
   // ---- Q fragments of the wave's two q-blocks, pre-scaled into the exp2 domain (one extra bf16 rounding of q).  All sixteen
@@ -344,8 +419,11 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)((uint32_t)(Nk - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
   const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)((uint32_t)(Nk - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
   // the next item's K / V (persistent form; its first tile is requested after this item's output stores -- load_tile(0) below -- and flies under the next prologue)
-  const auto rsK2 = __builtin_amdgcn_make_buffer_rsrc((void*)(Kp + b2 * k_bs + h2 * W4_HD), 0, (int)((uint32_t)(N - 1) * (uint32_t)ldk2 + 256u), 0x00020000);
-  const auto rsV2 = __builtin_amdgcn_make_buffer_rsrc((void*)(Vp + b2 * v_bs + h2 * W4_HD), 0, (int)((uint32_t)(N - 1) * (uint32_t)ldv2 + 256u), 0x00020000);
+  // (stream-K: the next pass may start at tile ts2 of its item -- the first piece of this CU's tail range)
+  const auto rsK2 = __builtin_amdgcn_make_buffer_rsrc((void*)(Kp + b2 * k_bs + h2 * W4_HD + (int64_t)ts2 * W4_KV * ldk), 0,
+                                                      (int)((uint32_t)(N - 1 - ts2 * W4_KV) * (uint32_t)ldk2 + 256u), 0x00020000);
+  const auto rsV2 = __builtin_amdgcn_make_buffer_rsrc((void*)(Vp + b2 * v_bs + h2 * W4_HD + (int64_t)ts2 * W4_KV * ldv), 0,
+                                                      (int)((uint32_t)(N - 1 - ts2 * W4_KV) * (uint32_t)ldv2 + 256u), 0x00020000);
   // piece i (rows t / 16 + 16 i) of tile j: global -> registers.  Rows are clamped to the last valid key (a no-op on full
   // tiles), tiles to the last tile (the pipeline requests up to two tiles past the end; nobody reads those buffers)
   // tile j: global -> registers, piece i = rows t / 16 + 16 i.  Full tiles: one per-lane offset (rebuilt per burst: as a loop
@@ -936,24 +1014,21 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   }
 
   // ---- tail split: un-normalised O (fp32), row sum and reference maximum of this key range -> part [tile][range][row][132]
-  if (kpart >= 0) {
-    float* pp = part + ((int64_t)ptile * nsplit + kpart) * (256 * W4_PROW);
+  if (kpart >= 0 || pslot >= 0) {
+    float* pp = part + (kpart >= 0 ? (int64_t)ptile * nsplit + kpart : (int64_t)pslot) * (256 * W4_PROW);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      float* pr = pp + (wave * 64 + qb * 32 + l31) * W4_PROW;
+      float* pr = pp + (wave * 2 + qb) * (16 * 256) + lane * 4;        // w4_part_off: 1 KiB contiguous per store instruction
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd)
-          *reinterpret_cast<f32x4*>(pr + db * 32 + qd * 8 + hi * 4) =
+          *reinterpret_cast<f32x4*>(pr + (db * 4 + qd) * 256) =
               f32x4{o[qb][db][qd * 4 + 0], o[qb][db][qd * 4 + 1], o[qb][db][qd * 4 + 2], o[qb][db][qd * 4 + 3]};
-      if (hi == 0) {
-        pr[128] = ltot[qb];
-        pr[129] = m_ref[qb];
-      }
+      if (hi == 0) *reinterpret_cast<float2*>(pp + W4_PART_LM + (wave * 64 + qb * 32 + l31) * 2) = float2{ltot[qb], m_ref[qb]};
     }
-    return;
-  }
+    if (kpart >= 0) return;
+  } else {
   // ---- finish.  The normalised bf16 rows go through a wave-private LDS
   // tile (the K / V ring is free: every wave's last fragment read lies before the last barrier) and leave as whole 256-byte
   // rows, 16 lanes x 16 bytes each (row-per-lane 8-byte stores touch 32 lines per instruction and queue up at the end of
@@ -983,6 +1058,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
     const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OROW + ch * 16);
     if (row0 + row < N) *reinterpret_cast<u32x4*>(Ob + (int64_t)(row0 + row) * ldo + ch * 8) = v;
   }
+  }    // (whole item)
 #ifdef TFX_BENCH
   W4_STAMP(3);
   w4_sum[0] += w4_stamp[1] - w4_stamp[0]; w4_sum[1] += w4_stamp[2] - w4_stamp[1]; w4_sum[2] += w4_stamp[3] - w4_stamp[2]; w4_sum[3] += 1;
@@ -994,6 +1070,7 @@ __global__ __launch_bounds__(256, 1) void attn_w4_kernel(const bf16_t* Q, const 
   rsVs = rsV2;
   load_tile(0);                                   // the next item's first K / V tile (its descriptors; kreg / vreg are idle until the next prologue writes them)
   item = item2; b = b2; h = h2; qblk = qblk2;
+  if (sk_share > 0) { ++sk_u; int it_; sk_unit(sk_u, it_, ts, te); }
   have_pref = true;
   // every wave has read its output tile out of LDS: the ring buffers are free for the next item.  A bare barrier behind an LDS-only
   // wait -- __syncthreads() would also wait for the next item's requests that were just issued (4.6 k cycles per item, measured)
@@ -1013,23 +1090,93 @@ __global__ __launch_bounds__(256) void attn_w4_merge_kernel(const float* part, b
   const int pair = H * nqb - xsplit + ptile % xsplit, b = ptile / xsplit, h = pair / nqb, qblk = pair % nqb;
   const int row = qblk * 256 + r;
   if (row >= N) return;
-  const float* pr = part + ((int64_t)ptile * nsplit * 256 + r) * W4_PROW;
+  const float* pr = part + (int64_t)ptile * nsplit * (256 * W4_PROW);
+  const int po = w4_part_off(r, c), lo = W4_PART_LM + r * 2;
   float m = -INFINITY;
-  for (int k = 0; k < nsplit; ++k) m = fmaxf(m, pr[(int64_t)k * 256 * W4_PROW + 129]);
+  for (int k = 0; k < nsplit; ++k) m = fmaxf(m, pr[(int64_t)k * 256 * W4_PROW + lo + 1]);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float l = 0.f;
   for (int k = 0; k < nsplit; ++k) {
     const float* pk = pr + (int64_t)k * 256 * W4_PROW;
-    const float w = __builtin_amdgcn_exp2f(pk[129] - m);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(pk + c);
+    const float w = __builtin_amdgcn_exp2f(pk[lo + 1] - m);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(pk + po);
     acc += v * w;
-    l += pk[128] * w;
+    l += pk[lo] * w;
   }
   const float inv = 1.0f / l;
   u32x2 o2;
   o2[0] = pack_bf2(acc[0] * inv, acc[1] * inv);
   o2[1] = pack_bf2(acc[2] * inv, acc[3] * inv);
   *reinterpret_cast<u32x2*>(O + b * o_bs + (int64_t)row * ldo + h * W4_HD + c) = o2;
+}
+
+// Stream-K: adds up the partials of every tail item that a CU boundary cuts.  8 blocks per (sample, boundary), one per 32-row block of the item;
+// the blocks of a boundary that cuts nothing, or that is not the FIRST boundary inside its item, leave at once.  Parts of tail item i, in key
+// order: slot B (2 L + 1) of the CU whose range contains the item's first tile, then slot A (2 L) of every CU whose non-empty range starts
+// inside the item.  Threads read in the producer's register order (w4_part_off: wave w = column block db, 1 KiB contiguous per load
+// instruction; the first version read row-major positions out of that layout and ran at 1.6 TB/s -- 36 us per launch, more than the
+// dealing saves), the bf16 rows leave through an LDS tile as whole 256-byte rows.  Same arithmetic as attn_w4_merge_kernel (the reference
+// maxima are all 0 on the reference-free stream: the weights are 1, the merge a plain sum).
+__global__ __launch_bounds__(256) void attn_w4_merge_sk_kernel(const float* part, bf16_t* O, int64_t ldo, int64_t o_bs, int H, int N, int nqb,
+                                                               int group, int share, int Tp) {
+  __shared__ __attribute__((aligned(16))) unsigned short sm[32][128 + 8];
+  const int bi = blockIdx.x >> 3, wq = blockIdx.x & 7;
+  const int sample = bi / group, c = bi - sample * group;
+  if (c == 0) return;
+  const int nkv = (N + W4_KV - 1) / W4_KV, full = (Tp / group) * group, total = (Tp - full) * nkv;
+  const int p = w4_sk_bound(c, group, share, nkv, total);
+  if (p >= total || p % nkv == 0) return;
+  const int il = p / nkv, istart = il * nkv, iend = istart + nkv;
+  if (w4_sk_bound(c - 1, group, share, nkv, total) > istart) return;
+  const int gi = full + il, h = gi / nqb, qblk = gi - h * nqb;
+  if (qblk * 256 + wq * 32 >= N) return;
+  int slots[8], np = 0;
+  slots[np++] = 2 * (sample * group + c - 1) + 1;
+  for (int j = c; j < group && np < 8; ++j) {
+    const int lo = w4_sk_bound(j, group, share, nkv, total), hi = w4_sk_bound(j + 1, group, share, nkv, total);
+    if (lo >= iend || lo >= total) break;
+    if (hi > lo) slots[np++] = 2 * (sample * group + j);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int lmo = W4_PART_LM + (wq * 32 + l31) * 2, vo = ((wq * 4 + w) * 4 * 64 + lane) * 4;
+  float2 lm[8];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    lm[k] = float2{0.f, -INFINITY};
+    if (k < np) lm[k] = *reinterpret_cast<const float2*>(part + (int64_t)slots[k] * (256 * W4_PROW) + lmo);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m = fmaxf(m, lm[k].y);
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float l = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < np) {            // block-uniform
+      const float* pk = part + (int64_t)slots[k] * (256 * W4_PROW) + vo;
+      f32x4 v[4];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) v[qd] = *reinterpret_cast<const f32x4*>(pk + qd * 256);
+      const float wgt = __builtin_amdgcn_exp2f(lm[k].y - m);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) acc[qd] += v[qd] * wgt;
+      l += lm[k].x * wgt;
+    }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    u32x2 o2;
+    o2[0] = pack_bf2(acc[qd][0] * inv, acc[qd][1] * inv);
+    o2[1] = pack_bf2(acc[qd][2] * inv, acc[qd][3] * inv);
+    *reinterpret_cast<u32x2*>(&sm[l31][w * 32 + qd * 8 + hi * 4]) = o2;
+  }
+  __syncthreads();
+  const int orow = tid >> 3, och = tid & 7, row = qblk * 256 + wq * 32 + orow;
+  if (row < N) {
+    bf16_t* dst = O + sample * o_bs + (int64_t)row * ldo + h * W4_HD + och * 16;
+    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(&sm[orow][och * 16]);
+    *reinterpret_cast<u32x4*>(dst + 8) = *reinterpret_cast<const u32x4*>(&sm[orow][och * 16 + 8]);
+  }
 }
 
 // scratch of the tail split: one per (device, stream) that ever ran a split launch -- two launches in flight on different streams
@@ -1087,6 +1234,11 @@ int attention_w4_prepare(hipStream_t st) {
   return w4_scratch(st, true) ? 0 : fail("attention: cannot allocate the tail-split scratch");
 }
 
+// tfx_set_option attention_streamk: 1 (default) = deal (item, key tile) units instead of whole items when the estimate below says it pays and
+// the caller passed a workspace (AttnArgs::workspace); 0 = whole items only (a sample's bits then do not depend on the batch size); 2 = always
+// when admissible (tests).
+static int g_w4_streamk = 1;
+void set_attention_streamk(int v) { g_w4_streamk = v; }
 static int g_w4_persist = 1;     // tfx_set_option attention_persistent: 0 = one workgroup per (b, h, q-tile) item (round 3)
 void set_attention_persistent(int v) { g_w4_persist = v; }
 static int g_w4_grid() {         // workgroups of the persistent form: one per CU, a whole number per XCD
@@ -1107,7 +1259,8 @@ extern "C" void tfx_bench_attn_timers(unsigned long long* dev) {
 #endif
 
 template <int MODE>
-static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, int nfull, int nparts, int nsplit, int xsplit, float* part) {
+static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, int nfull, int nparts, int nsplit, int xsplit, float* part,
+                     int sk_group, int sk_share) {
   static bool attr_set = false;
   const void* fn = (const void*)attn_w4_kernel<MODE>;
   if (!attr_set) {
@@ -1124,13 +1277,17 @@ static int w4_launch(const AttnArgs& a, hipStream_t st, unsigned grid, int nqb, 
   }
   // persistent form: one workgroup per CU over all (b, h, q-tile) items, when there are more items than CUs and no tail split
   int T_items = 0;
-  if (g_w4_persist && nsplit == 1 && (int)grid > g_w4_grid()) {
+  if (sk_share > 0) {            // stream-K: one workgroup per CU, T_items = items of one sample, nfull = samples
+    T_items = a.H * nqb;
+    nfull = a.B;
+    grid = (unsigned)g_w4_grid();
+  } else if (g_w4_persist && nsplit == 1 && (int)grid > g_w4_grid()) {
     T_items = (int)grid;
     grid = (unsigned)g_w4_grid();
   }
   attn_w4_kernel<MODE><<<grid, 256, ATT_LDS_W4 + ((W4_ABL & 256) ? 4096 : 0), st>>>((const bf16_t*)a.q, (const bf16_t*)a.k, (const bf16_t*)a.v, (bf16_t*)a.o, a.ldq,
                                                        a.ldk, a.ldv, a.ldo, a.q_bstride, a.k_bstride, a.v_bstride, a.o_bstride, a.H,
-                                                       a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, part, T_items);
+                                                       a.N, nqb, a.scale * 1.4426950408889634f, nfull, nparts, nsplit, xsplit, part, T_items, sk_group, sk_share);
   return 0;
 }
 
@@ -1160,19 +1317,41 @@ int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode) {
       }
     }
   }
+  // Stream-K tail (see w4_sk_bound): per sample, the R items of the partly filled last round are dealt as (item, tile) units to the sample's
+  // group of C / B CUs.  Estimate in 64-key tile times on the slowest CU: whole items cost ceil(Tp / group) (nkv + F); the dealt form
+  // floor(Tp / group) (nkv + F) + share + (share / nkv + 1) F + M -- F = an item's prologue + output (tools/attn_item_timers.py: 6 - 9 tile
+  // times), M = the partial stores, the merge pass (10 - 12 us) and the gap in front of it.  A piece count per item <= 8 (attn_w4_merge_sk_kernel) needs share >= nkv / 6.
+  int sk_group = 0, sk_share = 0;
+  if (g_w4_streamk && g_w4_persist && nsplit == 1 && a.workspace && a.B <= g_w4_grid()) {
+    const int C = g_w4_grid(), nkv = (a.N + W4_KV - 1) / W4_KV, Tp = a.H * nqb, group = C / a.B;
+    const int full = (Tp / group) * group, R = Tp - full;
+    const int share = R ? (R * nkv + group - 1) / group : 0;
+    const int64_t need = (int64_t)2 * a.B * group * 256 * W4_PROW * (int64_t)sizeof(float);
+    const float F = 7.f, M = 20.f;      // fitted to nine shapes (tools/attn_streamk_time.py, profiles/r06_attn_streamk.log): 0.65 F + M = 25 +- 10
+    const float t_whole = (float)(full / group) * ((float)nkv + F);
+    const float t_now = t_whole + (float)nkv + F, t_sk = t_whole + (float)share + ((float)share / (float)nkv + 1.f) * F + M;
+    if (R > 0 && nkv >= 16 && share * 6 >= nkv && share >= 8 && need <= a.workspace_bytes && ((uintptr_t)a.workspace & 15) == 0 &&
+        (g_w4_streamk >= 2 || t_sk < 0.99f * t_now)) {
+      sk_group = group; sk_share = share; part = (float*)a.workspace;
+    }
+  }
   const unsigned grid = nsplit > 1 ? (unsigned)(((nfull + 7) & ~7) + nparts) : (unsigned)T;
 #ifdef TFX_BENCH
-  const int rc = mode == 4 ? w4_launch<4>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
-               : mode == 3 ? w4_launch<3>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
-               : mode == 2 ? w4_launch<2>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
-               : mode == 1 ? w4_launch<1>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
-                           : w4_launch<0>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part);
+  const int rc = mode == 4 ? w4_launch<4>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part, sk_group, sk_share)
+               : mode == 3 ? w4_launch<3>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part, sk_group, sk_share)
+               : mode == 2 ? w4_launch<2>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part, sk_group, sk_share)
+               : mode == 1 ? w4_launch<1>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part, sk_group, sk_share)
+                           : w4_launch<0>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part, sk_group, sk_share);
 #else   // product library: the reference-free stream and the guarded form; modes 1 .. 3 are A/B builds (round 4), bench library only
   if (mode != 4 && mode != 0) return fail("attention: attn_w4_kernel<%d> is bench-only (libtextflux_hip_bench.so)", mode);
-  const int rc = mode == 4 ? w4_launch<4>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part)
-                           : w4_launch<0>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part);
+  const int rc = mode == 4 ? w4_launch<4>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part, sk_group, sk_share)
+                           : w4_launch<0>(a, st, grid, nqb, nfull, nparts, nsplit, xsplit, part, sk_group, sk_share);
 #endif
   if (rc) return rc;
+  if (sk_share > 0) attention_note_streamk();
+  if (sk_share > 0)
+    attn_w4_merge_sk_kernel<<<(unsigned)(a.B * sk_group * 8), 256, 0, st>>>(part, (bf16_t*)a.o, a.ldo, a.o_bstride, a.H, a.N, nqb, sk_group,
+                                                                             sk_share, a.H * nqb);
   if (nsplit > 1)
     attn_w4_merge_kernel<<<(unsigned)(xsplit * a.B * 32), 256, 0, st>>>(part, (bf16_t*)a.o, a.ldo, a.o_bstride, a.H, a.N, nqb,
                                                                               xsplit, nsplit);

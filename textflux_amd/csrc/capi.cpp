@@ -128,6 +128,7 @@ int dit_forward(const tfx_dit_desc& d, hipStream_t st) {
     a.ldq = a.ldk = a.ldv = a.ldo = D7;
     a.q_bstride = a.k_bstride = a.v_bstride = a.o_bstride = y_bs;
     a.B = B; a.H = H; a.N = N; a.scale = att_scale; a.score_bound = block_bound > 0.f ? block_bound : d.attn_score_bound;
+    a.workspace = d.gemm_workspace; a.workspace_bytes = d.gemm_workspace_bytes;   // the split-K scratch is idle between GEMMs: stream-K partials
     return joint_attention(a, st);
   };
 
@@ -455,6 +456,7 @@ int tfx_joint_attention(const tfx_attn_args* g, tfx_stream stream) {
   a.ldq = g->ldq; a.ldk = g->ldk; a.ldv = g->ldv; a.ldo = g->ldo;
   a.q_bstride = g->q_bstride; a.k_bstride = g->k_bstride; a.v_bstride = g->v_bstride; a.o_bstride = g->o_bstride;
   a.B = g->B; a.H = g->H; a.N = g->N; a.scale = g->scale; a.score_bound = g->score_bound;
+  a.workspace = g->workspace; a.workspace_bytes = g->workspace ? g->workspace_bytes : 0;
   return joint_attention(a, S(stream));
 }
 
@@ -641,6 +643,7 @@ int tfx_set_option(const char* name, int value) {
   if (!std::strcmp(name, "attention_tail_split")) { set_attention_tail_split(value); return 0; }
   if (!std::strcmp(name, "attention_use_bound")) { set_attention_use_bound(value); return 0; }
   if (!std::strcmp(name, "attention_persistent")) { set_attention_persistent(value); return 0; }
+  if (!std::strcmp(name, "attention_streamk")) { set_attention_streamk(value); return 0; }
   if (!std::strcmp(name, "gemm_place")) { set_gemm_place(value); return 0; }
   if (!std::strcmp(name, "gemm_waves")) {
 #ifndef TFX_BENCH
@@ -675,7 +678,7 @@ int tfx_workspace_layout(int32_t B, int32_t Sn, int32_t T, int32_t D, int32_t fl
   if (B <= 0 || Sn <= 0 || T < 0 || D <= 0 || !off) return fail("tfx_workspace_layout: bad arguments");
   const int64_t N = (int64_t)Sn + T, hid = align256(B * N * D * 2), y = align256(B * N * 7 * (int64_t)D * 2);
   const bool fp8 = (flags & 4) != 0;
-  const int64_t q8 = fp8 ? align256(B * N * 5 * (int64_t)D) : 0, q8s = fp8 ? align256(B * N * 4) : 0, gws = 64ll << 20;
+  const int64_t q8 = fp8 ? align256(B * N * 5 * (int64_t)D) : 0, q8s = fp8 ? align256(B * N * 4) : 0, gws = 128ll << 20;
   int64_t o = 0;
   off[0] = o; o += hid;
   off[1] = o; o += hid;

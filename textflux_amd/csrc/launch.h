@@ -96,6 +96,8 @@ struct AttnArgs {
   int B, H, N;
   float scale;
   float score_bound = 0.f;   // caller's promise |scale * q . k| <= score_bound (0 = unknown): see tfx_attn_args
+  void* workspace = nullptr; // optional scratch (tfx_attn_args.workspace): lets the head-dim-128 kernel deal (item, key tile) units (stream-K)
+  int64_t workspace_bytes = 0;
 };
 int joint_attention(const AttnArgs& a, hipStream_t st);
 int joint_attention_hp(const AttnArgs& a, hipStream_t st);   // half-tile software-pipelined kernel (attention_hp.hip)
@@ -107,10 +109,12 @@ int joint_attention_w4(const AttnArgs& a, hipStream_t st, int mode);   // one wa
 void set_attention_ablation(int a);
 void set_attention_use_bound(int v);
 int attention_mode_counts(int64_t* counts, int n, int reset);   // tfx_attention_mode_counts
+void attention_note_streamk();                                   // counts[8]: a w4 launch whose last round ran as the stream-K tail
 int blend_edge(const void* a, int64_t a_bs, int64_t a_ts, int64_t a_us, void* b, int64_t b_bs, int64_t b_ts, int64_t b_us, int batch,
                int extent, int len, int C, hipStream_t st);
 int gate_residual(const void* x, int64_t ldx, int64_t x_bs, const void* gate, int64_t gate_bs, const void* res, int64_t ldr, int64_t r_bs,
                   void* out, int64_t ldo, int64_t o_bs, int rows, int batch, int D, hipStream_t st);   // 0: ignore AttnArgs::score_bound
+void set_attention_streamk(int v);     // 0: whole (b, h, q-tile) items only; 1 (default): stream-K dealing when it pays and a workspace was passed; 2: whenever admissible
 void set_attention_persistent(int v);  // 0: one workgroup per (b, h, q-tile) item instead of one per CU
 void set_attention_debug(void* p);
 void set_attention_waves(int nw);  // 8 (one 512-thread workgroup per CU) or 4 (two independent 256-thread workgroups)

@@ -231,10 +231,11 @@ def gate_residual(x: torch.Tensor, gate: torch.Tensor, res: torch.Tensor, out: O
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: Optional[torch.Tensor] = None,
-              scale: Optional[float] = None, score_bound: float = 0.0) -> torch.Tensor:
+              scale: Optional[float] = None, score_bound: float = 0.0, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q,k,v: [B,N,H*128] (views with row/batch strides allowed) -> out [B,N,H*128].  score_bound: the caller's promise
-    |scale * q . k| <= score_bound (0 = unknown), see tfx_attn_args."""
-    _chk_dev(q, k, v, out)
+    |scale * q . k| <= score_bound (0 = unknown), see tfx_attn_args.  workspace: optional device scratch (>= 69.2 MB) that lets the
+    kernel deal (item, key tile) units to the CUs (stream-K, tfx_attn_args.workspace)."""
+    _chk_dev(q, k, v, out, workspace)
     B, N, HD = q.shape
     H = HD // 128
     assert HD % 128 == 0 and q.dtype == BF16
@@ -247,6 +248,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: Optional[t
     a.B, a.H, a.N = B, H, N
     a.scale = scale if scale is not None else 128 ** -0.5
     a.score_bound = float(score_bound)
+    if workspace is not None:
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     L.check(L.lib().tfx_joint_attention(C.byref(a), _stream()), "joint_attention")
     return out
 
@@ -369,13 +372,14 @@ def mfma_peak_probe(operands: torch.Tensor, fp8: bool = False, seconds: float = 
             "dtype": "e4m3" if fp8 else "bf16", "flops_per_launch": fl.value}
 
 
-ATTENTION_MODES = ("w4_guarded", "w4_valu_rowsum", "w4_lazy_valu", "w4_lazy", "w4_reference_free", "hp", "w16", "other")
+ATTENTION_MODES = ("w4_guarded", "w4_valu_rowsum", "w4_lazy_valu", "w4_lazy", "w4_reference_free", "hp", "w16", "other",
+                   "streamk_tail")     # the last: launches (already counted under their kernel form) whose last round was dealt as (item, tile) units
 
 
 def attention_mode_counts(reset: bool = False) -> dict:
     """Attention launches since the last reset by kernel form (tfx_attention_mode_counts): which stream the score bound selected."""
-    c = (C.c_int64 * 8)()
-    L.lib().tfx_attention_mode_counts(c, 8, 1 if reset else 0)
+    c = (C.c_int64 * 9)()
+    L.lib().tfx_attention_mode_counts(c, 9, 1 if reset else 0)
     return {name: int(c[i]) for i, name in enumerate(ATTENTION_MODES)}
 
 
