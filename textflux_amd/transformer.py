@@ -482,7 +482,8 @@ class DitSession:
         if self.fp8:
             d.q8, d.q8_scale = self.q8.data_ptr(), self.q8_scale.data_ptr()
         # scratch for the split-K path of few-tile GEMMs (text stream, small batch x resolution): fp32 partials of at most
-        # slices x tiles <= 256 tiles of 256 x 256, i.e. 64 MiB whatever the problem size
+        # slices x tiles <= 256 tiles of 256 x 256, i.e. 64 MiB whatever the problem size (the library sizes the scratch at 128 MiB: the attention
+        # launches of the blocks put their stream-K partials, 69.2 MB, in the same memory between GEMMs)
         d.gemm_workspace, d.gemm_workspace_bytes = self.gemm_ws.data_ptr(), self.gemm_ws.numel() * 4
         self.graphs = {}        # (sampler, ...) -> C-level step graph handle (tfx_dit_step_capture)
         self._gb = None
