@@ -521,7 +521,8 @@ def test_attention_tail_split_matches_unsplit_and_reference(ops, B, N):
 
 
 @pytest.mark.parametrize("B,H,N,bound", [(1, 24, 4608, 30.0), (8, 24, 1100, 30.0), (2, 5, 2304, 0.0), (3, 24, 2304, 30.0), (1, 24, 1664, 0.0),
-                                         (4, 24, 3100, 30.0), (8, 24, 4608, 30.0)])
+                                         (4, 24, 3100, 30.0), (8, 24, 4608, 30.0), (5, 24, 4608, 30.0), (1, 3, 8704, 30.0), (2, 24, 5000, 0.0),
+                                         (1, 48, 1100, 30.0)])   # ... groups of 51 CUs, three heads, a ragged last key tile inside a dealt piece, 48 heads
 def test_attention_streamk_dealing_matches_whole_items(ops, B, H, N, bound):
     """Round 6: with a workspace the persistent kernel deals the items of a sample's partly filled LAST round as (item, 64-key tile) units to
     the sample's group of CUs instead of leaving part of the chip idle (attention_w4.hip::w4_sk_bound; option attention_streamk: 1 = when
